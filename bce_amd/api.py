@@ -1,0 +1,296 @@
+"""ctypes binding of include/bce_hip.h, shaped like the reference's own objects.
+
+reference                                   here
+------------------------------------------  ---------------------------------------------
+RankFile(name)  (bce.cpp:932-984)           RankFile(data)      rotate+BWT (K1), planes (K2)
+  .size() .offset() .status() .ranks          .size() .offset() .status() .zeros / .rank1()
+BCE<AdaptiveCoder<31>,...>::encode(file)    BCE(config).encode(rank_file) -> archive bytes
+  (bce.cpp:1117-1167)
+AdaptiveCoder::load_config (bce.cpp:626)    BCE(config=288 bytes) / BCE.load_config(path)
+main -c (bce.cpp:1403-1427)                 compress(data, config) ; bce_amd/bin/bce
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libbcehip.so")
+_lib = None
+
+CONFIG_BYTES = 288
+
+
+class BceError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__("%s failed: status %d (%s)%s" % (where, status, _strerror(status), (" -- " + detail) if detail else ""))
+
+
+class Stats(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("nodes", C.c_uint64), ("symbols", C.c_uint64), ("rounds", C.c_uint32),
+                ("sort_rounds", C.c_uint32), ("flushes", C.c_uint32), ("reserved", C.c_uint32),
+                ("t_load", C.c_double), ("t_bwt", C.c_double), ("t_planes", C.c_double), ("t_enum", C.c_double),
+                ("t_model", C.c_double), ("t_coder", C.c_double), ("t_total", C.c_double),
+                ("k3_ms", C.c_double), ("k3_launches", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/bce_hip.h declares: (name, restype, argtypes)
+_u8p, _u32p, _vp = C.c_void_p, C.c_void_p, C.c_void_p
+SYMBOLS = [
+    ("bce_hip_create", C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    ("bce_hip_destroy", None, [C.c_void_p]),
+    ("bce_hip_strerror", C.c_char_p, [C.c_int]),
+    ("bce_hip_last_error", C.c_char_p, [C.c_void_p]),
+    ("bce_hip_set_config", C.c_int, [C.c_void_p, _u8p]),
+    ("bce_hip_set_symbol_capacity", C.c_int, [C.c_void_p, C.c_uint64]),
+    ("bce_hip_load_host", C.c_int, [C.c_void_p, _u8p, C.c_uint32]),
+    ("bce_hip_load_device", C.c_int, [C.c_void_p, _vp, C.c_uint32]),
+    ("bce_hip_bwt", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("bce_hip_set_bwt", C.c_int, [C.c_void_p, _u8p, C.c_uint32, C.c_uint32]),
+    ("bce_hip_get_bwt", C.c_int, [C.c_void_p, _u8p]),
+    ("bce_hip_build_planes", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("bce_hip_get_plane_bits", C.c_int, [C.c_void_p, C.c_int, _u8p]),
+    ("bce_hip_rank1", C.c_int, [C.c_void_p, C.c_int, _u32p, C.c_uint32, _u32p]),
+    ("bce_hip_encode", C.c_int, [C.c_void_p]),
+    ("bce_hip_archive_size", C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    ("bce_hip_archive_copy", C.c_int, [C.c_void_p, _u8p, C.c_size_t]),
+    ("bce_hip_compress", C.c_int, [C.c_void_p, _u8p, C.c_uint32, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("bce_hip_compress_device", C.c_int, [C.c_void_p, _vp, C.c_uint32, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("bce_hip_enum_begin", C.c_int, [C.c_void_p]),
+    ("bce_hip_enum_nodes", C.c_int, [C.c_void_p, C.c_int, _u32p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("bce_hip_enum_round", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("bce_hip_enum_symbols", C.c_int, [C.c_void_p, _u32p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("bce_hip_enum_model", C.c_int, [C.c_void_p, _u32p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("bce_hip_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    ("bce_hip_synth_text", None, [C.c_uint64, _u8p, C.c_size_t]),
+    ("bce_hip_synth_rand", None, [C.c_uint64, _u8p, C.c_size_t]),
+]
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libbcehip.so (no fallback: raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(or make -C bce_amd/csrc) first; there is no CPU fallback" % _LIB_PATH)
+        lib = C.CDLL(_LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _strerror(status):
+    try:
+        return load_library().bce_hip_strerror(status).decode()
+    except Exception:  # pragma: no cover
+        return "?"
+
+
+def _as_u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+class _Ctx:
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.bce_hip_create(C.byref(h), device)
+        if rc != 0:
+            raise BceError(rc, "bce_hip_create", "no usable HIP device %d (a GPU is required; there is no CPU path)" % device)
+        self.h = h
+
+    def check(self, rc, where):
+        if rc != 0:
+            raise BceError(rc, where, self.lib.bce_hip_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.bce_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RankFile:
+    """The reference's RankFile (bce.cpp:932-984) on the GPU: input -> rotate + BWT (K1) -> 8 planes (K2).
+
+    `data` may be bytes / a numpy u8 array (host) or an int device pointer with `n` (input resident in HBM).
+    """
+
+    def __init__(self, data=None, n=None, device=0, device_ptr=None, bwt=None, offset=None, ctx=None, build=True):
+        self._c = ctx or _Ctx(device)
+        lib = self._c.lib
+        self._status = 0
+        if bwt is not None:                      # test hook: inject a BWT, skip K1
+            a = _as_u8(bwt)
+            self._c.check(lib.bce_hip_set_bwt(self._c.h, a.ctypes.data, len(a), int(offset)), "bce_hip_set_bwt")
+            self._n, self._offset = len(a), int(offset)
+        else:
+            if device_ptr is not None:
+                self._c.check(lib.bce_hip_load_device(self._c.h, int(device_ptr), int(n)), "bce_hip_load_device")
+                self._n = int(n)
+            else:
+                a = _as_u8(data)
+                if len(a) == 0:
+                    self._status = 1               # reference: `Error loading file` path; (empty input crashes it, Q12)
+                    raise BceError(-1, "RankFile", "empty input")
+                self._c.check(lib.bce_hip_load_host(self._c.h, a.ctypes.data, len(a)), "bce_hip_load_host")
+                self._n = len(a)
+            off = C.c_uint32()
+            self._c.check(lib.bce_hip_bwt(self._c.h, C.byref(off)), "bce_hip_bwt")
+            self._offset = off.value
+        self.zeros = None
+        if build:
+            z = (C.c_uint32 * 8)()
+            self._c.check(lib.bce_hip_build_planes(self._c.h, z), "bce_hip_build_planes")
+            self.zeros = list(z)
+
+    def size(self):
+        return self._n
+
+    def offset(self):
+        return self._offset
+
+    def status(self):
+        return self._status
+
+    def bwt(self):
+        out = np.empty(self._n, dtype=np.uint8)
+        self._c.check(self._c.lib.bce_hip_get_bwt(self._c.h, out.ctypes.data), "bce_hip_get_bwt")
+        return out
+
+    def plane_bits(self, plane):
+        out = np.empty(self._n, dtype=np.uint8)
+        self._c.check(self._c.lib.bce_hip_get_plane_bits(self._c.h, plane, out.ctypes.data), "bce_hip_get_plane_bits")
+        return out
+
+    def rank1(self, plane, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        out = np.empty(len(idx), dtype=np.uint32)
+        self._c.check(self._c.lib.bce_hip_rank1(self._c.h, plane, idx.ctypes.data, len(idx), out.ctypes.data), "bce_hip_rank1")
+        return out
+
+    def close(self):
+        self._c.close()
+
+
+class BCE:
+    """The reference's BCE<AdaptiveCoder<31>, ...> (bce.cpp:1111-1374), encode side."""
+
+    max = 31
+
+    def __init__(self, config=None, symbol_capacity=0):
+        if config is not None and len(config) != CONFIG_BYTES:
+            raise ValueError("Config not found or wrong size.")   # bce.cpp:629-631
+        self.config = None if config is None else bytes(config)
+        self.symbol_capacity = symbol_capacity
+
+    @staticmethod
+    def load_config(path):
+        with open(path, "rb") as f:
+            return f.read()
+
+    def _apply(self, rf):
+        lib, h = rf._c.lib, rf._c.h
+        cfg = None
+        if self.config is not None:
+            cfg = _as_u8(self.config)
+        rf._c.check(lib.bce_hip_set_config(h, cfg.ctypes.data if cfg is not None else None), "bce_hip_set_config")
+        rf._c.check(lib.bce_hip_set_symbol_capacity(h, self.symbol_capacity), "bce_hip_set_symbol_capacity")
+
+    def encode(self, rf: RankFile) -> bytes:
+        self._apply(rf)
+        lib, h = rf._c.lib, rf._c.h
+        rf._c.check(lib.bce_hip_encode(h), "bce_hip_encode")
+        n = C.c_size_t()
+        rf._c.check(lib.bce_hip_archive_size(h, C.byref(n)), "bce_hip_archive_size")
+        out = np.empty(n.value, dtype=np.uint8)
+        rf._c.check(lib.bce_hip_archive_copy(h, out.ctypes.data, n.value), "bce_hip_archive_copy")
+        return out.tobytes()
+
+    # --- BCE::code one round at a time (parity tests) ---
+    def code_begin(self, rf: RankFile):
+        self._apply(rf)
+        rf._c.check(rf._c.lib.bce_hip_enum_begin(rf._c.h), "bce_hip_enum_begin")
+
+    def code_nodes(self, rf: RankFile, plane):
+        cap = rf.size() // 2 + 2
+        out = np.empty((cap, 3), dtype=np.uint32)
+        cnt = C.c_uint32()
+        rf._c.check(rf._c.lib.bce_hip_enum_nodes(rf._c.h, plane, out.ctypes.data, cap, C.byref(cnt)), "bce_hip_enum_nodes")
+        return out[:cnt.value].copy()
+
+    def code_round(self, rf: RankFile):
+        nxt = C.c_uint64()
+        rf._c.check(rf._c.lib.bce_hip_enum_round(rf._c.h, C.byref(nxt)), "bce_hip_enum_round")
+        return nxt.value
+
+    def code_symbols(self, rf: RankFile, cap):
+        out = np.empty((max(cap, 1), 6), dtype=np.uint32)
+        cnt = C.c_uint64()
+        rf._c.check(rf._c.lib.bce_hip_enum_symbols(rf._c.h, out.ctypes.data, cap, C.byref(cnt)), "bce_hip_enum_symbols")
+        return out[:cnt.value].copy()
+
+    def code_model(self, rf: RankFile, cap):
+        out = np.empty((max(cap, 1), 3), dtype=np.uint32)
+        cnt = C.c_uint64()
+        rf._c.check(rf._c.lib.bce_hip_enum_model(rf._c.h, out.ctypes.data, cap, C.byref(cnt)), "bce_hip_enum_model")
+        return out[:cnt.value].copy()
+
+
+def stats(rf: RankFile) -> dict:
+    st = Stats()
+    rf._c.check(rf._c.lib.bce_hip_get_stats(rf._c.h, C.byref(st)), "bce_hip_get_stats")
+    return st.as_dict()
+
+
+def compress(data, config=None, device=0) -> bytes:
+    """`bce -c` on an in-memory buffer (bce.cpp:1403-1427 minus file I/O) -> archive bytes."""
+    rf = RankFile(data, device=device)
+    try:
+        return BCE(config).encode(rf)
+    finally:
+        rf.close()
+
+
+def compress_device(device_ptr, n, config=None, device=0, ctx=None):
+    """Same with the input already resident in HBM.  Returns (archive bytes, stats dict)."""
+    own = ctx is None
+    c = ctx or _Ctx(device)
+    try:
+        rf = RankFile(n=n, device_ptr=device_ptr, ctx=c)
+        arch = BCE(config).encode(rf)
+        return arch, stats(rf)
+    finally:
+        if own:
+            c.close()
+
+
+def synth_text(seed, n) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint8)
+    load_library().bce_hip_synth_text(seed, out.ctypes.data, n)
+    return out
+
+
+def synth_rand(seed, n) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint8)
+    load_library().bce_hip_synth_rand(seed, out.ctypes.data, n)
+    return out

@@ -1,0 +1,351 @@
+// api.hip -- the C ABI of libbcehip.so (include/bce_hip.h): context lifetime, stage entry points and
+// the host-side driver of BCE::encode (bce.cpp:1117-1167).
+#include <new>
+
+#include "common.h"
+#include "host_coder.h"
+
+using namespace bce;
+
+namespace {
+
+int check_stage(bce_hip_ctx *c, int need) {
+  if (!c) return BCE_HIP_E_ARG;
+  if (c->stage < need) { snprintf(c->err, sizeof c->err, "stage %d required, have %d", need, c->stage); return BCE_HIP_E_STATE; }
+  return BCE_HIP_OK;
+}
+
+int set_input(bce_hip_ctx *c, const void *src, uint32_t n, hipMemcpyKind kind) {
+  if (!c || !src || n == 0 || n >= 0x80000000u) return BCE_HIP_E_ARG;   // n < 2^31 (saidx_t, getv: SURVEY section 5)
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  const double t0 = now_s();
+  BCE_TRY(ensure(c, c->text, n));
+  BCE_HIP_TRY(c, hipMemcpyAsync(c->text.p, src, n, kind, c->stream));
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->n = n;
+  c->stage = 1;
+  c->enum_active = false;
+  c->archive.clear();
+  memset(&c->stats, 0, sizeof c->stats);
+  c->stats.n = n;
+  c->stats.t_load = now_s() - t0;
+  return BCE_HIP_OK;
+}
+
+// flush the model for the symbols buffered so far and feed the host coders
+int flush_symbols(bce_hip_ctx *c, uint64_t nsym) {
+  if (nsym) {
+    const double t0 = now_s();
+    BCE_TRY(k4_flush(c, nsym));
+    const double t1 = now_s();
+    std::vector<SymRun> runs[8];
+    for (int p = 0; p < 8; ++p) {
+      runs[p].reserve(c->run_log[p].size());
+      for (const RunEntry &e : c->run_log[p]) runs[p].push_back(SymRun{e.start, e.count, e.round});
+    }
+    c->coder->consume_all(runs, c->h_out, c->h_esc, 8);
+    c->stats.t_model += t1 - t0;
+    c->stats.t_coder += now_s() - t1;
+    c->stats.flushes++;
+    c->stats.symbols += nsym;
+  }
+  return k3_reset_symbols(c);
+}
+
+}  // namespace
+
+extern "C" {
+
+int bce_hip_create(bce_hip_ctx **out, int device) {
+  if (!out) return BCE_HIP_E_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return BCE_HIP_E_DEVICE;
+  bce_hip_ctx *c = new (std::nothrow) bce_hip_ctx();
+  if (!c) return BCE_HIP_E_NOMEM;
+  c->device = device;
+  memcpy(c->config, kDefaultConfig, sizeof c->config);
+  memset(&c->stats, 0, sizeof c->stats);
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c;
+    return BCE_HIP_E_DEVICE;
+  }
+  c->coder = new (std::nothrow) HostCoder();
+  if (!c->coder) { bce_hip_destroy(c); return BCE_HIP_E_NOMEM; }
+  *out = c;
+  return BCE_HIP_OK;
+}
+
+void bce_hip_destroy(bce_hip_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  DevBuf *bufs[] = {&c->text, &c->bwt, &c->sa[0], &c->sa[1], &c->key[0], &c->key[1], &c->rank, &c->k2, &c->nrk,
+                    &c->rs_hist, &c->blk, &c->ptmp[0], &c->ptmp[1], &c->gran, &c->nodes, &c->ctl, &c->tilecnt,
+                    &c->tileoff, &c->runs, &c->syms, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
+                    &c->sesc, &c->stat, &c->dcfg};
+  for (DevBuf *b : bufs) release(*b);
+  if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+  if (c->h_runs) (void)hipHostFree(c->h_runs);
+  if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->h_esc) (void)hipHostFree(c->h_esc);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c->coder;
+  delete c;
+}
+
+const char *bce_hip_strerror(int status) {
+  switch (status) {
+    case BCE_HIP_OK: return "ok";
+    case BCE_HIP_E_ARG: return "bad argument";
+    case BCE_HIP_E_DEVICE: return "HIP device/runtime error";
+    case BCE_HIP_E_NOMEM: return "out of memory";
+    case BCE_HIP_E_STATE: return "stage called out of order";
+    case BCE_HIP_E_OVERFLOW: return "buffer capacity exceeded";
+    case BCE_HIP_E_INTERNAL: return "internal consistency check failed";
+    default: return "unknown status";
+  }
+}
+const char *bce_hip_last_error(const bce_hip_ctx *c) { return c ? c->err : ""; }
+
+int bce_hip_set_config(bce_hip_ctx *c, const uint8_t *config288) {
+  if (!c) return BCE_HIP_E_ARG;
+  if (config288) {
+    for (uint32_t i = 0; i < BCE_HIP_CONFIG_BYTES; ++i)
+      if (config288[i] > 5) {
+        // context bits above 5 cannot be serialised by the preamble (set(bit, 6), bce.cpp:689)
+        snprintf(c->err, sizeof c->err, "config entry %u = %u > 5", i, config288[i]);
+        return BCE_HIP_E_ARG;
+      }
+    memcpy(c->config, config288, BCE_HIP_CONFIG_BYTES);
+  } else {
+    memcpy(c->config, kDefaultConfig, sizeof c->config);
+  }
+  return BCE_HIP_OK;
+}
+
+int bce_hip_set_symbol_capacity(bce_hip_ctx *c, uint64_t records) {
+  if (!c || records >= (1ull << 31)) return BCE_HIP_E_ARG;
+  c->sym_cap_user = records;
+  return BCE_HIP_OK;
+}
+
+int bce_hip_load_host(bce_hip_ctx *c, const uint8_t *in, uint32_t n) { return set_input(c, in, n, hipMemcpyHostToDevice); }
+int bce_hip_load_device(bce_hip_ctx *c, const void *d_in, uint32_t n) { return set_input(c, d_in, n, hipMemcpyDeviceToDevice); }
+
+int bce_hip_bwt(bce_hip_ctx *c, uint32_t *offset) {
+  BCE_TRY(check_stage(c, 1));
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  const double t0 = now_s();
+  BCE_TRY(k1_bwt(c));
+  c->stats.t_bwt = now_s() - t0;
+  c->stage = 2;
+  if (offset) *offset = c->offset;
+  return BCE_HIP_OK;
+}
+
+int bce_hip_set_bwt(bce_hip_ctx *c, const uint8_t *bwt, uint32_t n, uint32_t offset) {
+  if (!c || !bwt || n == 0 || n >= 0x80000000u || offset >= n) return BCE_HIP_E_ARG;
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  BCE_TRY(ensure(c, c->bwt, n));
+  BCE_HIP_TRY(c, hipMemcpy(c->bwt.p, bwt, n, hipMemcpyHostToDevice));
+  c->n = n; c->offset = offset; c->stage = 2; c->enum_active = false;
+  c->archive.clear();
+  memset(&c->stats, 0, sizeof c->stats);
+  c->stats.n = n;
+  return BCE_HIP_OK;
+}
+
+int bce_hip_get_bwt(bce_hip_ctx *c, uint8_t *out) {
+  BCE_TRY(check_stage(c, 2));
+  if (!out) return BCE_HIP_E_ARG;
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  BCE_HIP_TRY(c, hipMemcpy(out, c->bwt.p, c->n, hipMemcpyDeviceToHost));
+  return BCE_HIP_OK;
+}
+
+int bce_hip_build_planes(bce_hip_ctx *c, uint32_t zeros[8]) {
+  BCE_TRY(check_stage(c, 2));
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  const double t0 = now_s();
+  BCE_TRY(k2_build_planes(c));
+  c->stats.t_planes = now_s() - t0;
+  c->stage = 3;
+  if (zeros) memcpy(zeros, c->zeros, sizeof c->zeros);
+  return BCE_HIP_OK;
+}
+
+int bce_hip_get_plane_bits(bce_hip_ctx *c, int plane, uint8_t *out) {
+  BCE_TRY(check_stage(c, 3));
+  if (!out || plane < 0 || plane > 7) return BCE_HIP_E_ARG;
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  return k2_get_plane_bits(c, plane, out);
+}
+
+int bce_hip_rank1(bce_hip_ctx *c, int plane, const uint32_t *idx, uint32_t count, uint32_t *out) {
+  BCE_TRY(check_stage(c, 3));
+  if (!idx || !out || plane < 0 || plane > 7) return BCE_HIP_E_ARG;
+  for (uint32_t i = 0; i < count; ++i) if (idx[i] > c->n) return BCE_HIP_E_ARG;
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  return k2_rank1(c, plane, idx, count, out);
+}
+
+// ---- stepping interface ---------------------------------------------------------------------------
+int bce_hip_enum_begin(bce_hip_ctx *c) {
+  BCE_TRY(check_stage(c, 3));
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  BCE_TRY(k4_prepare(c));
+  BCE_TRY(k3_begin(c));
+  return BCE_HIP_OK;
+}
+
+int bce_hip_enum_nodes(bce_hip_ctx *c, int plane, uint32_t *out, uint32_t cap_nodes, uint32_t *count) {
+  if (!c || !c->enum_active || !out || !count || plane < 0 || plane > 7) return BCE_HIP_E_ARG;
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  return k3_get_nodes(c, plane, out, cap_nodes, count);
+}
+
+int bce_hip_enum_round(bce_hip_ctx *c, uint64_t *next_nodes) {
+  if (!c || !c->enum_active) return BCE_HIP_E_STATE;
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t first = c->round;
+  BCE_TRY(k3_rounds(c, 1));
+  EnumCtl ctl;
+  BCE_TRY(k3_sync_ctl(c, &ctl));
+  if (ctl.overflow) return BCE_HIP_E_OVERFLOW;
+  if (ctl.need_flush) return BCE_HIP_E_OVERFLOW;   // the stepping interface never flushes
+  BCE_TRY(k3_fetch_runs(c, first, 1));
+  c->round = first + 1;
+  if (next_nodes) *next_nodes = ctl.next_nodes;
+  return BCE_HIP_OK;
+}
+
+int bce_hip_enum_symbols(bce_hip_ctx *c, uint32_t *out, uint64_t cap_records, uint64_t *count) {
+  if (!c || !c->enum_active || !out || !count) return BCE_HIP_E_ARG;
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  EnumCtl ctl;
+  BCE_TRY(k3_sync_ctl(c, &ctl));
+  *count = ctl.sym_total;
+  if (ctl.sym_total > cap_records) return BCE_HIP_E_OVERFLOW;
+  std::vector<uint64_t> recs(ctl.sym_total);
+  if (ctl.sym_total)
+    BCE_HIP_TRY(c, hipMemcpy(recs.data(), c->syms.p, ctl.sym_total * 8, hipMemcpyDeviceToHost));
+  for (uint64_t i = 0; i < ctl.sym_total; ++i) {
+    const uint64_t r = recs[i];
+    out[6 * i + 0] = sym_plane(r); out[6 * i + 1] = sym_sym(r); out[6 * i + 2] = sym_k(r);
+    out[6 * i + 3] = sym_nesc(r); out[6 * i + 4] = sym_esc(r); out[6 * i + 5] = sym_slot(r);
+  }
+  return BCE_HIP_OK;
+}
+
+int bce_hip_enum_model(bce_hip_ctx *c, uint32_t *out, uint64_t cap_records, uint64_t *count) {
+  if (!c || !c->enum_active || !out || !count) return BCE_HIP_E_ARG;
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  EnumCtl ctl;
+  BCE_TRY(k3_sync_ctl(c, &ctl));
+  *count = ctl.sym_total;
+  if (ctl.sym_total > cap_records) return BCE_HIP_E_OVERFLOW;
+  BCE_TRY(k4_flush(c, ctl.sym_total));
+  for (uint64_t i = 0; i < ctl.sym_total; ++i) {
+    const uint64_t o = c->h_out[i];
+    out[3 * i + 0] = (uint32_t)(o & 0xFFFF); out[3 * i + 1] = (uint32_t)((o >> 16) & 0xFFFF); out[3 * i + 2] = (uint32_t)((o >> 32) & 0xFFFF);
+  }
+  BCE_TRY(k3_reset_symbols(c));
+  return BCE_HIP_OK;
+}
+
+// ---- BCE::encode ------------------------------------------------------------------------------------
+int bce_hip_encode(bce_hip_ctx *c) {
+  BCE_TRY(check_stage(c, 3));
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  const double t0 = now_s();
+  const uint32_t n = c->n;
+  BCE_TRY(k4_prepare(c));
+  BCE_TRY(k3_begin(c));
+  uint32_t C[8];
+  for (int i = 0; i < 8; ++i) C[i] = c->zeros[(i + 7) & 7];   // bce.cpp:1128
+  c->coder->begin(c->config, C, n);
+  c->stats.symbols = 0; c->stats.flushes = 0; c->stats.t_model = 0; c->stats.t_coder = 0;
+
+  uint64_t cur_nodes = 0;
+  for (int i = 0; i < 8; ++i) cur_nodes += (C[i] && n - C[i]) ? 1 : 0;
+  EnumCtl ctl;
+  for (;;) {
+    // wide rounds: sync often (the round dominates); narrow rounds: queue many per sync
+    uint32_t batch = cur_nodes > (1u << 20) ? 4u : (cur_nodes > (1u << 14) ? 16u : 64u);
+    const uint32_t first = c->round;
+    BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    BCE_TRY(k3_rounds(c, batch));
+    BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    BCE_TRY(k3_sync_ctl(c, &ctl));
+    { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms; }
+    if (ctl.overflow) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
+    const uint32_t executed = ctl.need_flush ? ctl.skip_round - first : batch;
+    BCE_TRY(k3_fetch_runs(c, first, executed));
+    c->round = first + executed;
+    cur_nodes = ctl.next_nodes;
+    const bool done = ctl.done_round != 0xFFFFFFFFu;
+    if (ctl.need_flush) {
+      if (ctl.sym_total == 0) { snprintf(c->err, sizeof c->err, "one round exceeds the symbol buffer (%llu records)", (unsigned long long)c->sym_cap); return BCE_HIP_E_OVERFLOW; }
+      BCE_TRY(flush_symbols(c, ctl.sym_total));
+      continue;
+    }
+    if (done) {
+      BCE_TRY(flush_symbols(c, ctl.sym_total));
+      break;
+    }
+  }
+  c->stats.rounds = ctl.done_round;
+  c->stats.nodes = ctl.nodes_total;
+  c->coder->finish(c->config, n, c->offset, c->archive);
+  c->enum_active = false;
+  c->stage = 4;
+  c->stats.t_enum = now_s() - t0 - c->stats.t_model - c->stats.t_coder;
+  return BCE_HIP_OK;
+}
+
+int bce_hip_archive_size(bce_hip_ctx *c, size_t *bytes) {
+  BCE_TRY(check_stage(c, 4));
+  if (!bytes) return BCE_HIP_E_ARG;
+  *bytes = c->archive.size() * 2;
+  return BCE_HIP_OK;
+}
+
+int bce_hip_archive_copy(bce_hip_ctx *c, uint8_t *out, size_t cap) {
+  BCE_TRY(check_stage(c, 4));
+  if (!out) return BCE_HIP_E_ARG;
+  if (cap < c->archive.size() * 2) return BCE_HIP_E_OVERFLOW;
+  memcpy(out, c->archive.data(), c->archive.size() * 2);
+  return BCE_HIP_OK;
+}
+
+static int compress_loaded(bce_hip_ctx *c, uint8_t *out, size_t cap, size_t *out_len) {
+  const double t0 = now_s();
+  BCE_TRY(bce_hip_bwt(c, nullptr));
+  BCE_TRY(bce_hip_build_planes(c, nullptr));
+  BCE_TRY(bce_hip_encode(c));
+  c->stats.t_total = now_s() - t0 + c->stats.t_load;
+  if (out_len) *out_len = c->archive.size() * 2;
+  if (out) return bce_hip_archive_copy(c, out, cap);
+  return BCE_HIP_OK;
+}
+
+int bce_hip_compress(bce_hip_ctx *c, const uint8_t *in, uint32_t n, uint8_t *out, size_t cap, size_t *out_len) {
+  BCE_TRY(bce_hip_load_host(c, in, n));
+  return compress_loaded(c, out, cap, out_len);
+}
+int bce_hip_compress_device(bce_hip_ctx *c, const void *d_in, uint32_t n, uint8_t *out, size_t cap, size_t *out_len) {
+  BCE_TRY(bce_hip_load_device(c, d_in, n));
+  return compress_loaded(c, out, cap, out_len);
+}
+
+int bce_hip_get_stats(const bce_hip_ctx *c, bce_hip_stats *out) {
+  if (!c || !out) return BCE_HIP_E_ARG;
+  *out = c->stats;
+  return BCE_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+// bce_core.h -- per-element arithmetic shared by the HIP kernels (device) and the CPU unit tests
+// (host, tests/ only).  Nothing here loops over the input: the product runs these functions inside
+// kernels only.
+//
+// Data layout decisions (MI355X-first, not the reference's):
+//  * rank directory: 16-byte granules {cum, w0, w1, w2} = running popcount + 96 payload bits, so one
+//    rank query is ONE global_load_dwordx4 (the reference's 32+32-bit words, bce.cpp:138-151, are a
+//    CPU choice; planes never reach the archive).
+//  * node = absolute (s, x0, x1) u32 triple (the reference stores gamma-coded deltas, bce.cpp:226-356).
+//  * symbol record = one u64: plane|slot|k|sym|nesc|escbits (see pack_symbol).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BCE_HD __host__ __device__ __forceinline__
+#else
+#define BCE_HD inline
+#endif
+
+namespace bce {
+
+constexpr int kMaxK = 31;              // AdaptiveCoder<31>::max, bce.cpp:1381
+constexpr uint32_t kGranuleBits = 96;  // payload bits per rank granule
+
+struct Granule { uint32_t cum, w0, w1, w2; };
+struct Node { uint32_t s, x0, x1; };
+
+BCE_HD uint32_t popc32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__popc(x);
+#else
+  return (uint32_t)__builtin_popcount(x);
+#endif
+}
+
+// floor(s / 96) for any 32-bit s: s/3 = (s * 0xAAAAAAAB) >> 33, then / 32.
+BCE_HD uint32_t div96(uint32_t s) { return (uint32_t)(((uint64_t)s * 0xAAAAAAABull) >> 38); }
+
+// rank1 inside one granule for offset o in [0, 96)
+BCE_HD uint32_t granule_rank1(const Granule &g, uint32_t o) {
+  uint32_t m0 = o >= 32 ? 0xFFFFFFFFu : ((1u << o) - 1u);
+  uint32_t m1 = o >= 64 ? 0xFFFFFFFFu : (o > 32 ? ((1u << (o - 32)) - 1u) : 0u);
+  uint32_t m2 = o > 64 ? ((1u << (o - 64)) - 1u) : 0u;
+  return g.cum + popc32(g.w0 & m0) + popc32(g.w1 & m1) + popc32(g.w2 & m2);
+}
+
+// Per-plane model geometry derived from one config row (AdaptiveCoder::init, bce.cpp:700-705).
+struct PlaneCfg {
+  uint8_t bits[32];      // context bits per k
+  uint32_t off[32];      // byte offset of k's counter block inside the plane's stat array (off_ & 0xFFFFFF)
+  uint32_t ctxoff[32];   // first slot id of k (slot = ctxoff[k] + ctx)
+  uint32_t stat_bytes;   // total counter bytes (= `start`, bce.cpp:705)
+  uint32_t nslots;
+};
+
+BCE_HD void plane_cfg_init(PlaneCfg &c, const uint8_t row[32]) {
+  uint32_t start = 0, slots = 0;
+  for (int k = 0; k < 32; ++k) { c.bits[k] = row[k]; c.off[k] = 0; c.ctxoff[k] = 0; }
+  for (int k = 2; k <= kMaxK; ++k) {
+    c.off[k] = start;
+    c.ctxoff[k] = slots;
+    start += (uint32_t)k << (row[k] * 2);
+    slots += 1u << (row[k] * 2);
+  }
+  c.stat_bytes = start;
+  c.nslots = slots;
+}
+
+// Result of one node of BCE::code (bce.cpp:1261-1351), encode mode.
+struct StepOut {
+  uint32_t has0, has1, hassym;
+  Node c0, c1;                 // children, absolute positions in plane (p+1)%8
+  uint32_t sym, k, ctx1, ctx2, ctxs;   // coder_.set(sym, k, c1, c2, cs) arguments (bce.cpp:1302)
+};
+
+// rank1(pos) is supplied by the caller (a global-memory gather on the device).
+// zeros_p = rank0_p(n): child1 lists are indexed from C[p+1] = zeros(plane p) (bce.cpp:1128,1259).
+template <class Rank1>
+BCE_HD void node_step(const Node &nd, uint32_t zeros_p, Rank1 rank1, StepOut &o) {
+  const uint32_t s = nd.s, x0 = nd.x0, x1 = nd.x1;
+  const uint32_t x = x0 + x1;
+  const uint32_t s1 = rank1(s);                       // :1265
+  const uint32_t n1x = rank1(s + x) - s1;             // _1x, :1271
+  const uint32_t s0 = s - s1;                         // :1272
+  o.has0 = o.has1 = o.hassym = 0;
+  if (n1x == 0) {                                     // :1274-1279
+    o.has0 = 1; o.c0.s = s0; o.c0.x0 = x0; o.c0.x1 = x1;
+    return;
+  }
+  const uint32_t n0x = x - n1x;                       // _0x, :1281
+  if (n0x == 0) {                                     // :1282-1287
+    o.has1 = 1; o.c1.s = zeros_p + s1; o.c1.x0 = x0; o.c1.x1 = x1;
+    return;
+  }
+  uint32_t mn = x0 - n1x, mx = n1x - x1;              // :1290-1294
+  mn = ((int32_t)mn < 0) ? 0u : mn;
+  mx = ((int32_t)mx < 0) ? 0u : mx;
+  mx = x0 - mx;
+  uint32_t n0x0 = mn;                                 // :1297
+  if (mx != mn) {                                     // :1299-1302
+    n0x0 = (s + x0 - rank1(s + x0)) - s0;             // rank0(s + x0) - s0
+    o.hassym = 1; o.sym = n0x0 - mn; o.k = mx - mn + 1; o.ctx1 = n0x; o.ctx2 = x1; o.ctxs = x;
+  }
+  const uint32_t n0x1 = n0x - n0x0;                   // :1337
+  if (n0x0 && n0x1) { o.has0 = 1; o.c0.s = s0; o.c0.x0 = n0x0; o.c0.x1 = n0x1; }
+  const uint32_t n1x1 = x1 - n0x1;                    // :1343-1344
+  const uint32_t n1x0 = n1x - n1x1;
+  if (n1x0 && n1x1) { o.has1 = 1; o.c1.s = zeros_p + s1; o.c1.x0 = n1x0; o.c1.x1 = n1x1; }
+}
+
+// Symbol record layout (u64):
+//   [26:0] escbits  [31:27] nesc  [36:32] sym  [41:37] k  [57:42] slot  [60:58] plane
+// The k > 31 escape (bce.cpp:507-510) is unrolled here: nesc uniform bits (LSB first in escbits),
+// then the residual (sym, k <= 31).  slot = ctxoff[k] + ctx with ctx as in get_context
+// (bce.cpp:671-677), including its uint32 wrap-around.
+constexpr int kSymKeyShift = 42;        // (record >> 42) = plane<<16 | slot : the K4 sort key (19 bits)
+constexpr int kSymKeyBits = 19;
+
+BCE_HD uint64_t pack_symbol(const PlaneCfg &cfg, uint32_t plane, uint32_t sym, uint32_t k,
+                            uint32_t c1, uint32_t c2, uint32_t cs) {
+  uint32_t nesc = 0, esc = 0;
+  while (k > (uint32_t)kMaxK) {
+    esc |= (sym & 1u) << nesc;
+    ++nesc;
+    k = (k + (~sym & 1u)) >> 1;
+    sym >>= 1;
+  }
+  const uint32_t bits = cfg.bits[k];
+  const uint32_t ctx = (((uint32_t)(c1 << bits) / cs) << bits) | ((uint32_t)(c2 << bits) / cs);
+  const uint32_t slot = cfg.ctxoff[k] + ctx;
+  return (uint64_t)esc | ((uint64_t)nesc << 27) | ((uint64_t)sym << 32) | ((uint64_t)k << 37) |
+         ((uint64_t)slot << 42) | ((uint64_t)plane << 58);
+}
+BCE_HD uint32_t sym_esc(uint64_t r) { return (uint32_t)(r & 0x7FFFFFFu); }
+BCE_HD uint32_t sym_nesc(uint64_t r) { return (uint32_t)((r >> 27) & 31u); }
+BCE_HD uint32_t sym_sym(uint64_t r) { return (uint32_t)((r >> 32) & 31u); }
+BCE_HD uint32_t sym_k(uint64_t r) { return (uint32_t)((r >> 37) & 31u); }
+BCE_HD uint32_t sym_slot(uint64_t r) { return (uint32_t)((r >> 42) & 0xFFFFu); }
+BCE_HD uint32_t sym_plane(uint64_t r) { return (uint32_t)((r >> 58) & 7u); }
+
+// One adaptive-model step on a slot's k byte counters (bce.cpp:512-518,529,531-533).
+// Output record for the host range coder: cum | freq<<16 | total<<32 | nesc<<48.
+BCE_HD uint64_t model_step(uint8_t *ctr, uint32_t k, uint32_t s, uint32_t nesc) {
+  uint32_t l = 0;
+  for (uint32_t i = 0; i < s; ++i) l += ctr[i];
+  const uint32_t cum = l + s;
+  for (uint32_t i = s; i < k; ++i) l += ctr[i];
+  const uint32_t total = l + k;
+  const uint32_t freq = (uint32_t)ctr[s] + 1u;
+  if (++ctr[s] == 0xFF)
+    for (uint32_t i = 0; i < k; ++i) ctr[i] >>= 1;
+  return (uint64_t)cum | ((uint64_t)freq << 16) | ((uint64_t)total << 32) | ((uint64_t)nesc << 48);
+}
+
+}  // namespace bce

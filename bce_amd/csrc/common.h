@@ -1,0 +1,142 @@
+// common.h -- context object and helpers shared by the stage implementations of libbcehip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <chrono>
+#include <vector>
+
+#include "../../include/bce_hip.h"
+#include "bce_core.h"
+
+namespace bce {
+
+// grow-only device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct HostCoder;  // host_coder.cpp
+
+// Device-resident control block of the enumeration (K3).  Everything a round needs to know about
+// the previous round lives here, so rounds can be queued back to back without host round trips.
+struct EnumCtl {
+  uint32_t cnt[2][8][2];     // [parity][plane][seg] node counts (seg0 = child0 list, seg1 = child1 list)
+  uint64_t sym_total;        // symbol records in the buffer (since the last flush)
+  uint64_t sym_cap;          // capacity of the symbol buffer
+  uint64_t nodes_total;      // nodes visited so far
+  uint32_t need_flush;       // a round was skipped because the symbol buffer could overflow
+  uint32_t skip_round;       // first skipped round
+  uint32_t done_round;       // first round whose successor is empty (0xFFFFFFFF while running)
+  uint32_t overflow;         // node buffer overflow (fatal)
+  uint32_t next_nodes;       // node total of the next round (after the last executed round)
+  uint32_t pad;
+};
+
+struct RunEntry { uint64_t start; uint32_t count; uint32_t round; };  // symbols of (round, plane): [start, start+count)
+
+}  // namespace bce
+
+struct bce_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  char err[256] = {0};
+
+  uint32_t n = 0;
+  int stage = 0;  // 0 empty, 1 loaded, 2 bwt, 3 planes, 4 encoded
+  uint32_t offset = 0;
+  uint8_t config[9][32];
+  bce::PlaneCfg cfg[8];
+  uint32_t zeros[8] = {0};
+  uint64_t sym_cap_user = 0;
+
+  // device buffers (grow-only)
+  bce::DevBuf text, bwt;                         // n bytes each
+  bce::DevBuf sa[2], key[2], rank, k2, nrk;      // K1: 7 x 4n
+  bce::DevBuf rs_hist, blk;                      // radix histograms [256][nb]; per-block scratch
+  bce::DevBuf ptmp[2];                           // K2 byte ping-pong
+  bce::DevBuf gran;                              // 8 planes x ngran x 16 B
+  uint32_t ngran = 0;                            // granules per plane
+  bce::DevBuf nodes;                             // 2 parities x 8 planes x capP nodes
+  uint32_t capP = 0;
+  bce::DevBuf ctl, tilecnt, tileoff, runs;       // K3 control
+  bce::DevBuf syms, skey[2], sval[2], sout, sesc; // K4: records, sort keys/vals, outputs
+  uint64_t sym_cap = 0;
+  bce::DevBuf stat, dcfg;                        // K4 counters, device copy of PlaneCfg[8]
+  uint32_t stat_off[8] = {0};
+
+  // pinned host staging
+  void *h_ctl = nullptr, *h_runs = nullptr;
+  uint64_t *h_out = nullptr; uint32_t *h_esc = nullptr; size_t h_out_cap = 0;
+
+  // enumeration stepping state
+  uint32_t round = 0;
+  bool enum_active = false;
+  std::vector<bce::RunEntry> run_log[8];         // runs since the last flush, per plane
+
+  bce::HostCoder *coder = nullptr;
+  std::vector<uint16_t> archive;
+  bce_hip_stats stats;
+};
+
+namespace bce {
+
+inline int set_err(bce_hip_ctx *c, hipError_t e, const char *what, int line) {
+  snprintf(c->err, sizeof c->err, "%s:%d: %s", what, line, hipGetErrorString(e));
+  return e == hipErrorOutOfMemory ? BCE_HIP_E_NOMEM : BCE_HIP_E_DEVICE;
+}
+
+#define BCE_HIP_TRY(ctx, expr)                                        \
+  do {                                                                \
+    hipError_t _e = (expr);                                           \
+    if (_e != hipSuccess) return bce::set_err((ctx), _e, #expr, __LINE__); \
+  } while (0)
+
+#define BCE_TRY(expr)                 \
+  do {                                \
+    int _rc = (expr);                 \
+    if (_rc != BCE_HIP_OK) return _rc; \
+  } while (0)
+
+inline int ensure(bce_hip_ctx *c, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return BCE_HIP_OK;
+  if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+  BCE_HIP_TRY(c, hipMalloc(&b.p, bytes));
+  b.cap = bytes;
+  return BCE_HIP_OK;
+}
+inline void release(DevBuf &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr; b.cap = 0;
+}
+
+inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+inline uint32_t ceil_log2(uint32_t v) { uint32_t b = 0; while ((1ull << b) < v) ++b; return b; }
+
+// ---- stage implementations (one .hip file each) ----
+int k1_bwt(bce_hip_ctx *c);                         // k1_bwt.hip
+int k2_build_planes(bce_hip_ctx *c);                // k2_planes.hip
+int k2_get_plane_bits(bce_hip_ctx *c, int plane, uint8_t *out);
+int k2_rank1(bce_hip_ctx *c, int plane, const uint32_t *idx, uint32_t count, uint32_t *out);
+int k3_begin(bce_hip_ctx *c);                       // k3_enumerate.hip
+int k3_rounds(bce_hip_ctx *c, uint32_t count);      // queue `count` rounds starting at c->round (no sync)
+int k3_sync_ctl(bce_hip_ctx *c, EnumCtl *out);      // copy the control block back (syncs the stream)
+int k3_fetch_runs(bce_hip_ctx *c, uint32_t first_round, uint32_t count);  // append run-table rows to run_log
+int k3_get_nodes(bce_hip_ctx *c, int plane, uint32_t *out, uint32_t cap, uint32_t *count);
+int k3_reset_symbols(bce_hip_ctx *c);               // after a flush: sym_total = 0, need_flush = 0
+int k4_prepare(bce_hip_ctx *c);                     // k4_model.hip: counters to zero, cfg upload
+int k4_flush(bce_hip_ctx *c, uint64_t nsym);        // sort + simulate + D2H into h_out/h_esc
+
+// radix sort (radix_sort.hip): stable LSD sort of (key,val) u32 pairs on `bits` low key bits.
+// Result is left in key[res]/val[res]; returns res (0 or 1) through *res.
+int radix_sort_pairs(bce_hip_ctx *c, uint32_t *key[2], uint32_t *val[2], uint32_t n, uint32_t bits, int *res);
+
+}  // namespace bce

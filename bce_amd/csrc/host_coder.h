@@ -1,0 +1,62 @@
+// host_coder.h -- the sequential half of the encoder that stays on the host (north star): the 64-bit
+// carry-less range coder of AdaptiveCoder (bce.cpp:520-529,538-553,610-615,655-661), the stream
+// preambles (bce.cpp:682-691,1126-1130), VCoder::setv (bce.cpp:364-370) and the archive framing of
+// BCE::encode (bce.cpp:1134-1157).  It consumes (cum, freq, total) records computed by the GPU model
+// kernel (K4); it never touches the adaptive counters itself.  No HIP dependency.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+namespace bce {
+
+class RangeCoder {
+ public:
+  RangeCoder() : l_(0), h_(~0ull) {}
+  // one coding step: the shared tail of set(s,k) (cum=s, freq=1, total=k) and set(s,k,c1,c2,cs)
+  inline void encode(uint32_t cum, uint32_t freq, uint32_t total) {
+    if (__builtin_expect(h_ - l_ < total, 0)) {        // :520-525 / :541-546
+      for (int i = 0; i < 4; ++i) data_.push_back((uint16_t)(l_ >> (48 - 16 * i)));
+      l_ = 0; h_ = ~0ull;
+    }
+    const uint64_t step = (h_ - l_) / total;            // :527 / :548
+    l_ += step * cum;                                   // :528 / :549
+    h_ = l_ + step * freq - 1;                          // :529 / :550
+    while (!((h_ ^ l_) >> 48)) {                        // shift_out :655-661
+      data_.push_back((uint16_t)(h_ >> 48));
+      l_ = (l_ << 16) + 0x0000;
+      h_ = (h_ << 16) + 0xFFFF;
+    }
+  }
+  inline void uniform(uint32_t s, uint32_t k) { encode(s, 1, k); }
+  void setv(uint32_t s);                                // VCoder::setv :364-370
+  void preamble(const uint8_t row[32]);                 // init(1, i) :682-691
+  void flush();                                         // :610-615
+  const std::vector<uint16_t> &data() const { return data_; }
+  std::vector<uint16_t> &data() { return data_; }
+
+ private:
+  uint64_t l_, h_;
+  std::vector<uint16_t> data_;
+};
+
+// One GPU model record: cum | freq<<16 | total<<32 | nesc<<48 (bce_core.h model_step); esc bits aside.
+struct SymRun { uint64_t start; uint32_t count; uint32_t round; };
+
+struct HostCoder {
+  RangeCoder plane[8];
+  // BCE::encode :1124-1130: construct the 8 coders (preamble from config rows 0..7) and code
+  // C[i] = zeros(plane (i+7)%8) with range n+1.
+  void begin(const uint8_t config[9][32], const uint32_t C[8], uint32_t n);
+  // Feed plane p's records of one flush, run by run (coder_[i].set(...), bce.cpp:1302, coder half).
+  void consume(int p, const SymRun *runs, size_t nruns, const uint64_t *out, const uint32_t *esc);
+  // Same for all 8 planes on 8 threads (one per plane, as the reference's OpenMP loop :1250-1252).
+  void consume_all(const std::vector<SymRun> runs[8], const uint64_t *out, const uint32_t *esc, int threads);
+  // BCE::encode :1134-1157: flush, header coder main(-1) (config row 8), concatenate.
+  void finish(const uint8_t config[9][32], uint32_t n, uint32_t offset, std::vector<uint16_t> &archive);
+};
+
+extern const uint8_t kDefaultConfig[9][32];             // AdaptiveCoder<31>::init_ :713-724
+
+}  // namespace bce

@@ -1,0 +1,123 @@
+/*
+ * bce_hip.h -- C ABI of libbcehip.so, the MI355X (gfx950) implementation of the `bce -c` hot path.
+ *
+ * The reference (akamiru/bce, /root/reference/bce.cpp) exposes no FFI; its seams are C++ template
+ * policies inside one translation unit plus the libdivsufsort C ABI.  Each entry point below names
+ * the reference interface it replaces (file:line).  All functions return 0 on success and a negative
+ * bce_hip_status on failure (the reference's convention is status ints + printf, no exceptions:
+ * CMakeLists.txt:25).  The context owns every device buffer; callers own every host buffer they
+ * pass.  A context is used from one host thread at a time.
+ */
+#ifndef BCE_HIP_H
+#define BCE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bce_hip_ctx bce_hip_ctx;
+
+enum bce_hip_status {
+  BCE_HIP_OK = 0,
+  BCE_HIP_E_ARG = -1,       /* bad argument (null pointer, n == 0, n >= 2^31, wrong config size) */
+  BCE_HIP_E_DEVICE = -2,    /* HIP runtime error (no device, launch failure, ...) */
+  BCE_HIP_E_NOMEM = -3,     /* device or host allocation failed */
+  BCE_HIP_E_STATE = -4,     /* stage called out of order */
+  BCE_HIP_E_OVERFLOW = -5,  /* output buffer too small / internal capacity exceeded */
+  BCE_HIP_E_INTERNAL = -6   /* device-side consistency check failed */
+};
+
+#define BCE_HIP_CONFIG_BYTES 288u /* (31+1)*9, bce.cpp:629 */
+
+/* ---- lifetime ---------------------------------------------------------------------------------- */
+int bce_hip_create(bce_hip_ctx **out, int device);
+void bce_hip_destroy(bce_hip_ctx *ctx);
+const char *bce_hip_strerror(int status);
+/* last HIP error string seen by this context (for diagnostics) */
+const char *bce_hip_last_error(const bce_hip_ctx *ctx);
+
+/* ---- configuration ----------------------------------------------------------------------------- */
+/* AdaptiveCoder<31>::load_config (bce.cpp:626-641): 9 rows x 32 context-bit counts.  NULL restores
+ * the built-in defaults (bce.cpp:713-724). */
+int bce_hip_set_config(bce_hip_ctx *ctx, const uint8_t *config288);
+/* capacity (in symbol records) of the device symbol buffer between model flushes; 0 = automatic */
+int bce_hip_set_symbol_capacity(bce_hip_ctx *ctx, uint64_t records);
+
+/* ---- stage 0: input ---------------------------------------------------------------------------- */
+/* File::File (bce.cpp:842-856): take the n input bytes.  _host copies host->HBM, _device copies
+ * HBM->HBM from a device pointer of the same GPU (input already resident). 1 <= n < 2^31. */
+int bce_hip_load_host(bce_hip_ctx *ctx, const uint8_t *in, uint32_t n);
+int bce_hip_load_device(bce_hip_ctx *ctx, const void *d_in, uint32_t n);
+
+/* ---- stage 1 (K1): rotation + BWT --------------------------------------------------------------- */
+/* File::rotate + File::bwt (bce.cpp:858-910), i.e. the libdivsufsort call
+ *   saidx_t divbwt(const sauchar_t *T, sauchar_t *U, saidx_t *A, saidx_t n)   (bce.cpp:901)
+ * plus the two std::rotate fix-ups: sorts all cyclic rotations on the GPU, leaves the n-byte BWT in
+ * HBM and returns offset_ (index of the first minimal rotation, bce.cpp:893). */
+int bce_hip_bwt(bce_hip_ctx *ctx, uint32_t *offset);
+/* Test hook: inject a BWT computed elsewhere instead of running K1. */
+int bce_hip_set_bwt(bce_hip_ctx *ctx, const uint8_t *bwt, uint32_t n, uint32_t offset);
+/* Copy the BWT bytes back (n bytes). */
+int bce_hip_get_bwt(bce_hip_ctx *ctx, uint8_t *bwt_out);
+
+/* ---- stage 2 (K2): wavelet-matrix bit planes + rank directory ----------------------------------- */
+/* RankFile ctor body + Rank::build (bce.cpp:944-970, 138-145).  zeros[j] = rank0_j(n). */
+int bce_hip_build_planes(bce_hip_ctx *ctx, uint32_t zeros[8]);
+/* Test hook: plane j, positions [0,n) -> one byte (0/1) each, as Rank::bit (bce.cpp:196-198). */
+int bce_hip_get_plane_bits(bce_hip_ctx *ctx, int plane, uint8_t *bits_out);
+/* Test hook: rank1_j(index) for an array of query positions, as Rank::get<1> (bce.cpp:147-151). */
+int bce_hip_rank1(bce_hip_ctx *ctx, int plane, const uint32_t *idx, uint32_t count, uint32_t *out);
+
+/* ---- stage 3+4 (K3, K4) + host coder: BCE::encode ------------------------------------------------ */
+/* BCE::encode (bce.cpp:1117-1167): runs BCE::code mode 1 (bce.cpp:1236-1374) as per-round GPU
+ * passes (K3), the AdaptiveCoder model half (bce.cpp:506-518,531-533,671-677) on the GPU (K4), the
+ * range-coder half (bce.cpp:520-529,538-553,610-615,655-661) on 8 host threads, then frames the
+ * archive (bce.cpp:1140-1157).  The archive is kept in the context until the next load. */
+int bce_hip_encode(bce_hip_ctx *ctx);
+/* size of / copy of the finished archive (native-endian u16 words, bce.cpp:1426) */
+int bce_hip_archive_size(bce_hip_ctx *ctx, size_t *bytes);
+int bce_hip_archive_copy(bce_hip_ctx *ctx, uint8_t *out, size_t cap);
+
+/* ---- one-shot: main() -c branch minus file I/O (bce.cpp:1403-1427) -------------------------------- */
+int bce_hip_compress(bce_hip_ctx *ctx, const uint8_t *in, uint32_t n, uint8_t *out, size_t cap, size_t *out_len);
+/* same with the input already in HBM */
+int bce_hip_compress_device(bce_hip_ctx *ctx, const void *d_in, uint32_t n, uint8_t *out, size_t cap, size_t *out_len);
+
+/* ---- stepping interface for parity tests (BCE::code one round at a time) --------------------------- */
+/* begin: sets up the roots (bce.cpp:1237-1240).  round: runs one round over all 8 planes and
+ * reports how many nodes the NEXT round holds.  nodes: copies plane p's current node list as
+ * (s absolute, x0, x1) triples, sorted by s (j=0 list then j=1 list, bce.cpp:1256-1264). */
+int bce_hip_enum_begin(bce_hip_ctx *ctx);
+int bce_hip_enum_nodes(bce_hip_ctx *ctx, int plane, uint32_t *triples_out, uint32_t cap_nodes, uint32_t *count);
+int bce_hip_enum_round(bce_hip_ctx *ctx, uint64_t *next_nodes);
+/* symbol records emitted so far and not yet flushed, in (round, plane, s) order.  Each record:
+ * out[6*i+0..5] = plane, s, k, nesc, escbits, slot  (s,k after the k>31 escape, bce.cpp:507-510) */
+int bce_hip_enum_symbols(bce_hip_ctx *ctx, uint32_t *out, uint64_t cap_records, uint64_t *count);
+/* run K4 on the symbols emitted so far: out[3*i+0..2] = cum, freq, total per record (same order) */
+int bce_hip_enum_model(bce_hip_ctx *ctx, uint32_t *out, uint64_t cap_records, uint64_t *count);
+
+/* ---- statistics of the last bce_hip_encode / bce_hip_compress ------------------------------------ */
+typedef struct bce_hip_stats {
+  uint64_t n;            /* input bytes */
+  uint64_t nodes;        /* nodes visited (= 8n-8 on primitive inputs) */
+  uint64_t symbols;      /* coded symbols (adaptive calls, bce.cpp:1302) */
+  uint32_t rounds;       /* rounds of BCE::code */
+  uint32_t sort_rounds;  /* prefix-doubling rounds of K1 */
+  uint32_t flushes;      /* K4 model flushes */
+  uint32_t reserved;
+  double t_load, t_bwt, t_planes, t_enum, t_model, t_coder, t_total;   /* host wall seconds */
+  double k3_ms, k3_launches;   /* HIP-event time and launch count of the interval-count kernels */
+} bce_hip_stats;
+int bce_hip_get_stats(const bce_hip_ctx *ctx, bce_hip_stats *out);
+
+/* ---- synthetic inputs (SURVEY.md section 8c generators; host side, for benchmarks and tests) ------- */
+void bce_hip_synth_text(uint64_t seed, uint8_t *out, size_t n);
+void bce_hip_synth_rand(uint64_t seed, uint8_t *out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BCE_HIP_H */

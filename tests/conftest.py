@@ -1,0 +1,59 @@
+import hashlib
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden():
+    with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+        return json.load(f)["vectors"]
+
+
+def golden_input(v):
+    import oracle
+    if v["gen"] == "literal":
+        return v["literal"].encode()
+    d = getattr(oracle, v["gen"])(v["seed"], v["n"])
+    assert hashlib.sha256(d).hexdigest() == v["input_sha256"]
+    return d
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden()
+
+
+def edge_inputs():
+    """Small inputs covering the edge cases of the path (ragged sizes, periodic, constant planes)."""
+    import oracle
+    return [
+        ("one-byte", b"a"),
+        ("two-bytes", b"ab"),
+        ("two-equal", b"aa"),
+        ("three", b"abc"),
+        ("constant-100", b"a" * 100),             # periodic, no roots at all
+        ("period2-100", b"ab" * 50),              # periodic (Q8/Q9)
+        ("period3-99", b"abc" * 33),
+        ("abracadabra", b"abracadabra"),
+        ("len-95", oracle.synth_text(5, 95)),     # granule boundaries (96) and chunk boundaries (3072, 2048)
+        ("len-96", oracle.synth_text(5, 96)),
+        ("len-97", oracle.synth_text(5, 97)),
+        ("len-2047", oracle.synth_text(6, 2047)),
+        ("len-2048", oracle.synth_rand(6, 2048)),
+        ("len-3071", oracle.synth_text(7, 3071)),
+        ("len-3072", oracle.synth_rand(7, 3072)),
+        ("len-3073", oracle.synth_text(7, 3073)),
+        ("all-bytes", bytes(range(256)) * 3),
+        ("binary-zeros-tail", oracle.synth_rand(8, 5000) + b"\x00" * 3000),
+        ("long-repeat", oracle.synth_text(9, 20000) + oracle.synth_text(9, 6000) + oracle.synth_text(10, 3000)),
+    ]

@@ -1,0 +1,107 @@
+// core_emul.cpp -- TEST-ONLY harness: drives the per-element functions of bce_amd/csrc/bce_core.h and
+// the host coder (host_coder.cpp) sequentially on the CPU, so their arithmetic can be checked against
+// the oracle without a GPU.  It is NOT a product path and is never loaded by bce_amd/.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../bce_amd/csrc/bce_core.h"
+#include "../bce_amd/csrc/host_coder.h"
+
+using namespace bce;
+
+namespace {
+// wavelet-matrix level order + granules, the layout k2_planes.hip produces
+void build(const uint8_t *bwt, uint32_t n, std::vector<Granule> G[8], uint32_t zeros[8]) {
+  std::vector<uint8_t> cur(bwt, bwt + n), nxt(n);
+  const uint32_t ng = n / 96 + 1;
+  for (int j = 0; j < 8; ++j) {
+    G[j].assign(ng, Granule{0, 0, 0, 0});
+    uint32_t ones = 0, z = 0;
+    for (uint32_t p = 0; p <= n; ++p) {
+      if (p % 96 == 0) G[j][p / 96].cum = ones;
+      if (p == n) break;
+      const uint32_t bit = (cur[p] >> j) & 1u;
+      if (bit) {
+        uint32_t o = p % 96;
+        uint32_t *w = o < 32 ? &G[j][p / 96].w0 : (o < 64 ? &G[j][p / 96].w1 : &G[j][p / 96].w2);
+        *w |= 1u << (o & 31);
+        ++ones;
+      } else ++z;
+    }
+    zeros[j] = z;
+    uint32_t zi = 0, oi = z;
+    for (uint32_t p = 0; p < n; ++p) { if ((cur[p] >> j) & 1u) nxt[oi++] = cur[p]; else nxt[zi++] = cur[p]; }
+    cur.swap(nxt);
+  }
+}
+}  // namespace
+
+extern "C" int emul_rank1(const uint8_t *bwt, uint32_t n, int plane, const uint32_t *idx, uint32_t cnt, uint32_t *out) {
+  std::vector<Granule> G[8];
+  uint32_t zeros[8];
+  build(bwt, n, G, zeros);
+  for (uint32_t i = 0; i < cnt; ++i) { const uint32_t g = div96(idx[i]); out[i] = granule_rank1(G[plane][g], idx[i] - g * 96); }
+  return 0;
+}
+
+// BWT -> archive through bce_core.h + host_coder.cpp; returns malloc'd bytes
+extern "C" int emul_encode_from_bwt(const uint8_t *bwt, uint32_t n, uint32_t offset, const uint8_t *config,
+                                    uint8_t **out, size_t *out_len, uint64_t *nodes_out, uint64_t *syms_out) {
+  uint8_t cfgb[9][32];
+  memcpy(cfgb, config ? config : &kDefaultConfig[0][0], 288);
+  std::vector<Granule> G[8];
+  uint32_t zeros[8];
+  build(bwt, n, G, zeros);
+  PlaneCfg cfg[8];
+  std::vector<uint8_t> stat[8];
+  for (int p = 0; p < 8; ++p) { plane_cfg_init(cfg[p], cfgb[p]); stat[p].assign(cfg[p].stat_bytes + 1, 0); }
+  uint32_t C[8];
+  for (int i = 0; i < 8; ++i) C[i] = zeros[(i + 7) & 7];
+  HostCoder hc;
+  hc.begin(cfgb, C, n);
+  std::vector<Node> cur[8][2], nxt[8][2];
+  for (int i = 0; i < 8; ++i)
+    if (C[i] && n - C[i]) cur[i][0].push_back(Node{0, C[i], n - C[i]});
+  uint64_t nodes = 0, syms = 0;
+  for (;;) {
+    bool any = false;
+    for (int p = 0; p < 8; ++p) {
+      std::vector<uint64_t> outrec;
+      std::vector<uint32_t> esc;
+      auto rank1 = [&](uint32_t s) { const uint32_t g = div96(s); return granule_rank1(G[p][g], s - g * 96); };
+      for (int j = 0; j < 2; ++j)
+        for (const Node &nd : cur[p][j]) {
+          StepOut so;
+          node_step(nd, zeros[p], rank1, so);
+          ++nodes;
+          if (so.has0) nxt[(p + 1) & 7][0].push_back(so.c0);
+          if (so.has1) nxt[(p + 1) & 7][1].push_back(so.c1);
+          if (so.hassym) {
+            const uint64_t r = pack_symbol(cfg[p], (uint32_t)p, so.sym, so.k, so.ctx1, so.ctx2, so.ctxs);
+            const uint32_t k = sym_k(r);
+            uint8_t *ctr = stat[p].data() + cfg[p].off[k] + (sym_slot(r) - cfg[p].ctxoff[k]) * k;
+            outrec.push_back(model_step(ctr, k, sym_sym(r), sym_nesc(r)));
+            esc.push_back(sym_esc(r));
+            ++syms;
+          }
+        }
+      SymRun run{0, (uint32_t)outrec.size(), 0};
+      hc.consume(p, &run, 1, outrec.data(), esc.data());
+    }
+    for (int p = 0; p < 8; ++p)
+      for (int j = 0; j < 2; ++j) { cur[p][j].swap(nxt[p][j]); nxt[p][j].clear(); if (!cur[p][j].empty()) any = true; }
+    if (!any) break;
+  }
+  std::vector<uint16_t> arch;
+  hc.finish(cfgb, n, offset, arch);
+  *out_len = arch.size() * 2;
+  *out = (uint8_t *)malloc(*out_len ? *out_len : 1);
+  memcpy(*out, arch.data(), *out_len);
+  if (nodes_out) *nodes_out = nodes;
+  if (syms_out) *syms_out = syms;
+  return 0;
+}
+extern "C" void emul_free(void *p) { free(p); }

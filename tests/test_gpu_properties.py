@@ -1,0 +1,48 @@
+"""GPU: size-independent properties at sizes the oracle is too slow for (BASELINE configs)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import bce_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_input(arr):
+    t = torch.from_numpy(arr).to("cuda:0")
+    torch.cuda.synchronize()
+    return t
+
+
+@pytest.mark.parametrize("gen,n", [("synth_text", 32 << 20), ("synth_rand", 4 << 20)])
+def test_full_pipeline_properties(gen, n):
+    data = getattr(bce_amd, gen)(1, n)
+    t = dev_input(data)
+    arch1, st1 = bce_amd.compress_device(t.data_ptr(), n)
+    # every internal node of the 8 binary tries is visited exactly once (primitive input): 8n - 8
+    assert st1["nodes"] == 8 * n - 8
+    assert 0 < st1["symbols"] <= st1["nodes"]
+    # BWT is a permutation of the input and offset names a minimal rotation
+    rf = bce_amd.RankFile(n=n, device_ptr=t.data_ptr(), build=False)
+    try:
+        bwt = rf.bwt()
+        assert (np.bincount(bwt, minlength=256) == np.bincount(data, minlength=256)).all()
+        off = rf.offset()
+        rot = np.concatenate([data[off:], data[:off]])[:4096].tobytes()
+        rs = np.random.RandomState(0)
+        for q in rs.randint(0, n, 200):
+            other = np.concatenate([data[q:q + 4096], data[:max(0, q + 4096 - n)]])[:4096].tobytes()
+            assert rot <= other
+    finally:
+        rf.close()
+    # determinism + independence from the flush granularity (model state carried across K4 flushes)
+    c = bce_amd.api._Ctx(0)
+    try:
+        rf2 = bce_amd.RankFile(n=n, device_ptr=t.data_ptr(), ctx=c)
+        arch2 = bce_amd.BCE(symbol_capacity=max(1 << 20, st1["symbols"] // 7)).encode(rf2)
+        assert bce_amd.stats(rf2)["flushes"] >= 2
+    finally:
+        c.close()
+    assert hashlib.sha256(arch1).hexdigest() == hashlib.sha256(arch2).hexdigest()

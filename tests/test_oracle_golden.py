@@ -1,0 +1,48 @@
+"""CPU: the oracle against the reference's recorded outputs -- this is what pins it."""
+import hashlib
+
+import pytest
+
+import oracle
+from conftest import golden_input, load_golden
+
+
+@pytest.mark.parametrize("v", load_golden(), ids=lambda v: v["name"])
+def test_oracle_matches_reference_archive(v):
+    d = golden_input(v)
+    a = oracle.compress(d)
+    assert len(a) == v["archive_bytes"]
+    assert hashlib.sha256(a).hexdigest() == v["archive_sha256"]
+    if "archive_hex" in v:
+        assert a.hex() == v["archive_hex"]
+
+
+def test_oracle_abracadabra_stages():
+    v = [x for x in load_golden() if x["name"] == "abracadabra"][0]
+    bwt, off = oracle.bwt_stage(b"abracadabra")
+    assert bytes(bwt) == v["bwt"].encode() and off == v["offset"]
+    tr = oracle.trace_encode_from_bwt(bwt, off)
+    assert len(tr["nodes"]) == v["nodes"] and len(tr["syms"]) == v["symbols"] and tr["rounds"] == v["rounds"]
+    # first traced nodes of SURVEY section 0: (round, plane, s, x0, x1)
+    assert tr["nodes"][0].tolist() == [0, 1, 0, 5, 6]
+    assert tr["archive"].hex() == v["archive_hex"]
+
+
+def test_oracle_bwt_is_cyclic_rotation_bwt():
+    """File::rotate + File::bwt == BWT of all cyclic rotations, offset = first minimal rotation."""
+    import random
+    rnd = random.Random(1)
+    for _ in range(200):
+        n = rnd.randint(1, 40)
+        s = bytes(rnd.choice(b"ab" if rnd.random() < 0.5 else b"abcd") for _ in range(n))
+        rots = sorted(range(n), key=lambda i: (s[i:] + s[:i], i))
+        expect = bytes(s[(i - 1) % n] for i in rots)
+        mn = min(s[i:] + s[:i] for i in range(n))
+        first = min(i for i in range(n) if s[i:] + s[:i] == mn)
+        bwt, off = oracle.bwt_stage(s)
+        assert bytes(bwt) == expect and off == first, s
+
+
+def test_oracle_rejects_empty():
+    with pytest.raises(ValueError):
+        oracle.compress(b"")
