@@ -83,7 +83,7 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf *bufs[] = {&c->text, &c->bwt, &c->sa[0], &c->sa[1], &c->key[0], &c->key[1], &c->rank, &c->k2, &c->nrk,
                     &c->rs_hist, &c->blk, &c->ptmp[0], &c->ptmp[1], &c->gran, &c->nodes, &c->ctl, &c->tilecnt,
-                    &c->tileoff, &c->runs, &c->syms, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
+                    &c->tileoff, &c->runs, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
                     &c->sesc, &c->stat, &c->dcfg};
   for (DevBuf *b : bufs) release(*b);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
@@ -230,13 +230,14 @@ int bce_hip_enum_symbols(bce_hip_ctx *c, uint32_t *out, uint64_t cap_records, ui
   BCE_TRY(k3_sync_ctl(c, &ctl));
   *count = ctl.sym_total;
   if (ctl.sym_total > cap_records) return BCE_HIP_E_OVERFLOW;
-  std::vector<uint64_t> recs(ctl.sym_total);
-  if (ctl.sym_total)
-    BCE_HIP_TRY(c, hipMemcpy(recs.data(), c->syms.p, ctl.sym_total * 8, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> kw(ctl.sym_total), ew(ctl.sym_total);
+  if (ctl.sym_total) {
+    BCE_HIP_TRY(c, hipMemcpy(kw.data(), c->skey[0].p, ctl.sym_total * 4, hipMemcpyDeviceToHost));
+    BCE_HIP_TRY(c, hipMemcpy(ew.data(), c->sesc.p, ctl.sym_total * 4, hipMemcpyDeviceToHost));
+  }
   for (uint64_t i = 0; i < ctl.sym_total; ++i) {
-    const uint64_t r = recs[i];
-    out[6 * i + 0] = sym_plane(r); out[6 * i + 1] = sym_sym(r); out[6 * i + 2] = sym_k(r);
-    out[6 * i + 3] = sym_nesc(r); out[6 * i + 4] = sym_esc(r); out[6 * i + 5] = sym_slot(r);
+    out[6 * i + 0] = key_plane(kw[i]); out[6 * i + 1] = key_sym(kw[i]); out[6 * i + 2] = key_k(kw[i]);
+    out[6 * i + 3] = esc_n(ew[i]); out[6 * i + 4] = esc_bits(ew[i]); out[6 * i + 5] = key_slot(kw[i]);
   }
   return BCE_HIP_OK;
 }

@@ -7,7 +7,7 @@
 //    rank query is ONE global_load_dwordx4 (the reference's 32+32-bit words, bce.cpp:138-151, are a
 //    CPU choice; planes never reach the archive).
 //  * node = absolute (s, x0, x1) u32 triple (the reference stores gamma-coded deltas, bce.cpp:226-356).
-//  * symbol record = one u64: plane|slot|k|sym|nesc|escbits (see pack_symbol).
+//  * symbol record = two u32 words (key word, escape word) in two arrays (see pack_symbol).
 #pragma once
 #include <stdint.h>
 
@@ -108,16 +108,17 @@ BCE_HD void node_step(const Node &nd, uint32_t zeros_p, Rank1 rank1, StepOut &o)
   if (n1x0 && n1x1) { o.has1 = 1; o.c1.s = zeros_p + s1; o.c1.x0 = n1x0; o.c1.x1 = n1x1; }
 }
 
-// Symbol record layout (u64):
-//   [26:0] escbits  [31:27] nesc  [36:32] sym  [41:37] k  [57:42] slot  [60:58] plane
+// Symbol record = two u32 words kept in two arrays (SoA):
+//   key word: [4:0] sym  [9:5] k  [25:10] slot  [28:26] plane      (sorted by K4 on bits 10..28)
+//   esc word: [26:0] escbits  [31:27] nesc                         (goes to the host range coder as is)
 // The k > 31 escape (bce.cpp:507-510) is unrolled here: nesc uniform bits (LSB first in escbits),
 // then the residual (sym, k <= 31).  slot = ctxoff[k] + ctx with ctx as in get_context
 // (bce.cpp:671-677), including its uint32 wrap-around.
-constexpr int kSymKeyShift = 42;        // (record >> 42) = plane<<16 | slot : the K4 sort key (19 bits)
-constexpr int kSymKeyBits = 19;
+constexpr int kSymRunShift = 10;        // key >> 10 = plane<<16 | slot : one model slot = one sorted run
+constexpr int kSymRunBits = 19;
 
-BCE_HD uint64_t pack_symbol(const PlaneCfg &cfg, uint32_t plane, uint32_t sym, uint32_t k,
-                            uint32_t c1, uint32_t c2, uint32_t cs) {
+BCE_HD void pack_symbol(const PlaneCfg &cfg, uint32_t plane, uint32_t sym, uint32_t k, uint32_t c1, uint32_t c2,
+                        uint32_t cs, uint32_t &key_word, uint32_t &esc_word) {
   uint32_t nesc = 0, esc = 0;
   while (k > (uint32_t)kMaxK) {
     esc |= (sym & 1u) << nesc;
@@ -128,19 +129,20 @@ BCE_HD uint64_t pack_symbol(const PlaneCfg &cfg, uint32_t plane, uint32_t sym, u
   const uint32_t bits = cfg.bits[k];
   const uint32_t ctx = (((uint32_t)(c1 << bits) / cs) << bits) | ((uint32_t)(c2 << bits) / cs);
   const uint32_t slot = cfg.ctxoff[k] + ctx;
-  return (uint64_t)esc | ((uint64_t)nesc << 27) | ((uint64_t)sym << 32) | ((uint64_t)k << 37) |
-         ((uint64_t)slot << 42) | ((uint64_t)plane << 58);
+  key_word = sym | (k << 5) | (slot << 10) | (plane << 26);
+  esc_word = esc | (nesc << 27);
 }
-BCE_HD uint32_t sym_esc(uint64_t r) { return (uint32_t)(r & 0x7FFFFFFu); }
-BCE_HD uint32_t sym_nesc(uint64_t r) { return (uint32_t)((r >> 27) & 31u); }
-BCE_HD uint32_t sym_sym(uint64_t r) { return (uint32_t)((r >> 32) & 31u); }
-BCE_HD uint32_t sym_k(uint64_t r) { return (uint32_t)((r >> 37) & 31u); }
-BCE_HD uint32_t sym_slot(uint64_t r) { return (uint32_t)((r >> 42) & 0xFFFFu); }
-BCE_HD uint32_t sym_plane(uint64_t r) { return (uint32_t)((r >> 58) & 7u); }
+BCE_HD uint32_t key_sym(uint32_t k) { return k & 31u; }
+BCE_HD uint32_t key_k(uint32_t k) { return (k >> 5) & 31u; }
+BCE_HD uint32_t key_slot(uint32_t k) { return (k >> 10) & 0xFFFFu; }
+BCE_HD uint32_t key_plane(uint32_t k) { return (k >> 26) & 7u; }
+BCE_HD uint32_t esc_bits(uint32_t e) { return e & 0x7FFFFFFu; }
+BCE_HD uint32_t esc_n(uint32_t e) { return e >> 27; }
 
-// One adaptive-model step on a slot's k byte counters (bce.cpp:512-518,529,531-533).
-// Output record for the host range coder: cum | freq<<16 | total<<32 | nesc<<48.
-BCE_HD uint64_t model_step(uint8_t *ctr, uint32_t k, uint32_t s, uint32_t nesc) {
+// One adaptive-model step on a slot's k byte counters (bce.cpp:512-518,529,531-533), the sequential
+// definition the K4 kernel is tested against.  Output record for the host range coder:
+// cum | freq<<16 | total<<32.
+BCE_HD uint64_t model_step(uint8_t *ctr, uint32_t k, uint32_t s) {
   uint32_t l = 0;
   for (uint32_t i = 0; i < s; ++i) l += ctr[i];
   const uint32_t cum = l + s;
@@ -149,7 +151,7 @@ BCE_HD uint64_t model_step(uint8_t *ctr, uint32_t k, uint32_t s, uint32_t nesc) 
   const uint32_t freq = (uint32_t)ctr[s] + 1u;
   if (++ctr[s] == 0xFF)
     for (uint32_t i = 0; i < k; ++i) ctr[i] >>= 1;
-  return (uint64_t)cum | ((uint64_t)freq << 16) | ((uint64_t)total << 32) | ((uint64_t)nesc << 48);
+  return (uint64_t)cum | ((uint64_t)freq << 16) | ((uint64_t)total << 32);
 }
 
 }  // namespace bce

@@ -65,7 +65,7 @@ struct bce_hip_ctx {
   bce::DevBuf nodes;                             // 2 parities x 8 planes x capP nodes
   uint32_t capP = 0;
   bce::DevBuf ctl, tilecnt, tileoff, runs;       // K3 control
-  bce::DevBuf syms, skey[2], sval[2], sout, sesc; // K4: records, sort keys/vals, outputs
+  bce::DevBuf skey[2], sval[2], sout, sesc;       // K3->K4: symbol keys (skey[0]) + escape words (sesc); sort ping-pong; outputs
   uint64_t sym_cap = 0;
   bce::DevBuf stat, dcfg;                        // K4 counters, device copy of PlaneCfg[8]
   uint32_t stat_off[8] = {0};
@@ -135,8 +135,8 @@ int k3_reset_symbols(bce_hip_ctx *c);               // after a flush: sym_total 
 int k4_prepare(bce_hip_ctx *c);                     // k4_model.hip: counters to zero, cfg upload
 int k4_flush(bce_hip_ctx *c, uint64_t nsym);        // sort + simulate + D2H into h_out/h_esc
 
-// radix sort (radix_sort.hip): stable LSD sort of (key,val) u32 pairs on `bits` low key bits.
+// radix sort (radix_sort.hip): stable LSD sort of (key,val) u32 pairs on key bits [first_bit, first_bit+bits).
 // Result is left in key[res]/val[res]; returns res (0 or 1) through *res.
-int radix_sort_pairs(bce_hip_ctx *c, uint32_t *key[2], uint32_t *val[2], uint32_t n, uint32_t bits, int *res);
+int radix_sort_pairs(bce_hip_ctx *c, uint32_t *key[2], uint32_t *val[2], uint32_t n, uint32_t first_bit, uint32_t bits, int *res);
 
 }  // namespace bce

@@ -57,10 +57,9 @@ void HostCoder::consume(int p, const SymRun *runs, size_t nruns, const uint64_t 
     const uint64_t b = runs[r].start, e = b + runs[r].count;
     for (uint64_t i = b; i < e; ++i) {
       const uint64_t o = out[i];
-      uint32_t nesc = (uint32_t)(o >> 48);
-      if (__builtin_expect(nesc != 0, 0)) {            // k > 31 escape bits, bce.cpp:507-510
-        uint32_t bits = esc[i];
-        for (; nesc; --nesc, bits >>= 1) rc.uniform(bits & 1, 2);
+      uint32_t bits = esc[i];                           // [26:0] escape bits, [31:27] their count
+      if (__builtin_expect(bits != 0, 0)) {             // k > 31 escape, bce.cpp:507-510
+        for (uint32_t nesc = bits >> 27; nesc; --nesc, bits >>= 1) rc.uniform(bits & 1, 2);
       }
       rc.encode((uint32_t)(o & 0xFFFF), (uint32_t)((o >> 16) & 0xFFFF), (uint32_t)((o >> 32) & 0xFFFF));
     }

@@ -41,7 +41,8 @@ class RangeCoder {
   std::vector<uint16_t> data_;
 };
 
-// One GPU model record: cum | freq<<16 | total<<32 | nesc<<48 (bce_core.h model_step); esc bits aside.
+// One GPU model record: cum | freq<<16 | total<<32 (bce_core.h model_step); escape word aside
+// ([26:0] bits, [31:27] count; bce_core.h pack_symbol).
 struct SymRun { uint64_t start; uint32_t count; uint32_t round; };
 
 struct HostCoder {

@@ -174,7 +174,7 @@ int k1_bwt(bce_hip_ctx *c) {
   uint32_t *val[2] = {c->sa[0].as<uint32_t>(), c->sa[1].as<uint32_t>()};
   hipLaunchKernelGGL(k1_init_kernel, dim3(g), dim3(K1_T), 0, c->stream, T, n, key[0], val[0]);
   int res = 0;
-  BCE_TRY(radix_sort_pairs(c, key, val, n, 32, &res));
+  BCE_TRY(radix_sort_pairs(c, key, val, n, 0, 32, &res));
   uint32_t groups = 0;
   auto rerank = [&](const uint32_t *k1s, const uint32_t *k2s, const uint32_t *sa) -> int {
     BCE_HIP_TRY(c, hipMemsetAsync(scalars, 0, 4, c->stream));
@@ -196,7 +196,7 @@ int k1_bwt(bce_hip_ctx *c) {
     hipLaunchKernelGGL(k1_gather_prev_kernel, dim3(g), dim3(K1_T), 0, c->stream, val[res], rank, n, (uint32_t)h,
                        ki[0], vi[0]);
     int r2 = 0;
-    BCE_TRY(radix_sort_pairs(c, ki, vi, n, bits, &r2));
+    BCE_TRY(radix_sort_pairs(c, ki, vi, n, 0, bits, &r2));
     uint32_t *sk = ki[r2], *ssa = vi[r2];
     hipLaunchKernelGGL(k1_gather_next_kernel, dim3(g), dim3(K1_T), 0, c->stream, ssa, rank, n, (uint32_t)h, k2);
     BCE_TRY(rerank(sk, k2, ssa));

@@ -31,7 +31,8 @@ struct K3Args {
   Node *nodes;            // [2][8][capP]
   const Granule *gran;    // [8][ngran]
   const PlaneCfg *cfg;    // [8]
-  uint64_t *syms;         // symbol records
+  uint32_t *symkey;       // symbol records: key words (K4 sort input)
+  uint32_t *symesc;       // symbol records: escape words
   uint32_t *tilecnt;      // [tiles][4]
   uint32_t *tileoff;      // [tiles][4]
   RunEntry *runs;         // [K3_MAXBATCH][8]
@@ -121,8 +122,12 @@ __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t ti
       }
       if (so[it].has0) dst[o0 + b0 + pre0[it]] = so[it].c0;
       if (so[it].has1) dst[a.capP - 1u - (o1 + b1 + pre1[it])] = so[it].c1;
-      if (so[it].hassym)
-        a.syms[os + bs + pres[it]] = pack_symbol(cfg, p, so[it].sym, so[it].k, so[it].ctx1, so[it].ctx2, so[it].ctxs);
+      if (so[it].hassym) {
+        uint32_t kw, ew;
+        pack_symbol(cfg, p, so[it].sym, so[it].k, so[it].ctx1, so[it].ctx2, so[it].ctxs, kw, ew);
+        a.symkey[os + bs + pres[it]] = kw;
+        a.symesc[os + bs + pres[it]] = ew;
+      }
     }
   }
   __syncthreads();
@@ -218,7 +223,8 @@ static K3Args make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot) {
   a.nodes = c->nodes.as<Node>();
   a.gran = c->gran.as<Granule>();
   a.cfg = c->dcfg.as<PlaneCfg>();
-  a.syms = c->syms.as<uint64_t>();
+  a.symkey = c->skey[0].as<uint32_t>();
+  a.symesc = c->sesc.as<uint32_t>();
   a.tilecnt = c->tilecnt.as<uint32_t>();
   a.tileoff = c->tileoff.as<uint32_t>();
   a.runs = c->runs.as<RunEntry>();
@@ -253,7 +259,8 @@ int k3_begin(bce_hip_ctx *c) {
     cap = want < soft ? want : soft;
   }
   c->sym_cap = cap;
-  BCE_TRY(ensure(c, c->syms, (size_t)cap * 8));
+  BCE_TRY(ensure(c, c->skey[0], (size_t)cap * 4));
+  BCE_TRY(ensure(c, c->sesc, (size_t)cap * 4));
   // roots: (0, C[i], n - C[i]) with C[i] = zeros(plane (i+7)%8), only where both are non-zero (bce.cpp:1237-1240)
   EnumCtl ctl;
   memset(&ctl, 0, sizeof ctl);

@@ -147,15 +147,16 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
   }
 }
 
-int radix_sort_pairs(bce_hip_ctx *c, uint32_t *key[2], uint32_t *val[2], uint32_t n, uint32_t bits, int *res) {
+int radix_sort_pairs(bce_hip_ctx *c, uint32_t *key[2], uint32_t *val[2], uint32_t n, uint32_t first_bit, uint32_t bits, int *res) {
   *res = 0;
   if (n <= 1 || bits == 0) return BCE_HIP_OK;
   const RsPlan pl = rs_plan(n);
   BCE_TRY(ensure(c, c->rs_hist, (size_t)256 * pl.nb * sizeof(uint32_t)));
   uint32_t *hist = c->rs_hist.as<uint32_t>();
   int cur = 0;
-  for (uint32_t shift = 0; shift < bits; shift += 8) {
-    const int nbits = (int)((bits - shift) < 8 ? (bits - shift) : 8);
+  for (uint32_t done = 0; done < bits; done += 8) {
+    const uint32_t shift = first_bit + done;
+    const int nbits = (int)((bits - done) < 8 ? (bits - done) : 8);
     const uint32_t nbins = 1u << nbits;
     hipLaunchKernelGGL(rs_hist_kernel, dim3(pl.nb), dim3(RS_THREADS), 0, c->stream, key[cur], n, pl.per_block, pl.nb,
                        (int)shift, nbits, hist);

@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the `bce -c` hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one full compression (K1 rotation sort/BWT, K2 planes, K3 enumeration, K4 model, host range
+coders, framing) of one input block per GPU, input already resident in HBM, archive bytes ready on the
+host at the end.  N > 1 (launched by torch.distributed.run, one rank per GPU): every rank compresses
+its own block (weak scaling, no data-path collective) and the coded streams are gathered to rank 0
+over RCCL inside the timed step.  Rank 0 prints ONE JSON line.
+
+Workload: BASELINE.json config[1] is enwik8 (10^8 bytes).  The corpus is not available offline; if a
+file is given with --file (or $BCE_BENCH_FILE) it is used, otherwise the stand-in is synth-text v1
+(SURVEY 8c generator) at 10^8 bytes, seed 1 + rank.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import bce_amd  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=100_000_000, help="input bytes per GPU (enwik8 = 10^8)")
+    ap.add_argument("--workload", default="synth-text", choices=["synth-text", "synth-rand"])
+    ap.add_argument("--file", default=os.environ.get("BCE_BENCH_FILE"))
+    ap.add_argument("--cpu-sample", type=int, default=24 << 20, help="bytes of the workload the CPU baseline compresses")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def make_input(args, rank):
+    if args.file:
+        data = np.fromfile(args.file, dtype=np.uint8)
+        per = len(data) // max(1, args.gpus)
+        blk = data[rank * per:(rank + 1) * per] if args.gpus > 1 else data
+        return np.ascontiguousarray(blk), "file:%s[%d B, sha256 %s]" % (os.path.basename(args.file), len(data), hashlib.sha256(data.tobytes()).hexdigest()[:16])
+    gen = bce_amd.synth_text if args.workload == "synth-text" else bce_amd.synth_rand
+    return gen(1 + rank, args.size), "%s-v1 seed %d, %d B per GPU (enwik8-sized stand-in: the corpus is not available offline)" % (args.workload, 1 + rank, args.size)
+
+
+def cpu_baseline(data, sample_bytes):
+    """The oracle (bit-exact CPU restatement of bce -c) timed on this host, 1 thread, bounded sample."""
+    import oracle
+    oracle.build()
+    sample = data[:sample_bytes].tobytes()
+    t0 = time.time()
+    arch = oracle.compress(sample)
+    dt = time.time() - t0
+    return {"value": round(len(sample) / dt / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+            "sample": "first %d B of the workload, oracle/bce_oracle.c single thread, %.1f s, archive %d B" % (len(sample), dt, len(arch)),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    n_gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    data, workload = make_input(args, rank)
+    n = len(data)
+    t_in = torch.from_numpy(data).to(dev)       # input resident in HBM before the timed region
+    torch.cuda.synchronize()
+    ctx = bce_amd.api._Ctx(local)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gathered = [None]
+
+    def step():
+        arch, st = bce_amd.compress_device(t_in.data_ptr(), n, ctx=ctx)
+        if dist is not None:
+            # RCCL gather of the per-block coded streams to rank 0 (size exchange, then padded gather)
+            a = torch.frombuffer(bytearray(arch), dtype=torch.uint8).to(dev)
+            sz = torch.tensor([a.numel()], dtype=torch.int64, device=dev)
+            sizes = [torch.zeros_like(sz) for _ in range(world)]
+            dist.all_gather(sizes, sz)
+            mx = int(max(int(s.item()) for s in sizes))
+            pad = torch.zeros(mx, dtype=torch.uint8, device=dev)
+            pad[:a.numel()] = a
+            outs = [torch.empty(mx, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+            dist.gather(pad, outs, dst=0)
+            if rank == 0:
+                gathered[0] = [o[:int(s.item())].cpu().numpy().tobytes() for o, s in zip(outs, sizes)]
+        return arch, st
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    sts = []
+    arch = None
+    for _ in range(args.steps):
+        arch, st = step()
+        sts.append(st)
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+
+    if rank == 0:
+        steps = max(1, args.steps)
+        st = sts[-1]
+        k3_s = sum(s["k3_ms"] for s in sts) / len(sts) / 1e3
+        alg_bytes = 384.0 * n + 16.0 * st["symbols"]     # 48 B/node x 8n nodes + 16 B/symbol
+        roof = {"bound": "hbm", "kernel": "K3 interval-count (k3_tiles_kernel<count> + k3_scan_kernel + k3_tiles_kernel<write>, all rounds of one compression)",
+                "achieved": round(alg_bytes / k3_s / 1e9, 2) if k3_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(alg_bytes / k3_s / 1e9 / HBM_PEAK_GBS, 5) if k3_s > 0 else None,
+                "traffic": None, "algorithmic_bytes": alg_bytes, "k3_ms_per_step": round(k3_s * 1e3, 3),
+                "k3_launches_per_step": st["k3_launches"]}
+        out = {
+            "metric": "MB/s compressed", "value": round(n_gpus * n * steps / dt / 1e6, 3), "unit": "MB/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32 integer",
+            "data": "synthetic" if not args.file else "file",
+            "config": {"workload": workload, "bytes_per_gpu": n, "coder_config": "default AdaptiveCoder<31> tables",
+                       "sharding": "one independent block per GPU, RCCL gather of coded streams to rank 0" if n_gpus > 1 else "single block"},
+            "archive_bytes": len(arch), "archive_sha256": hashlib.sha256(arch).hexdigest(),
+            "ratio": round(len(arch) / n, 5),
+            "roofline": roof,
+            "breakdown_s": {k: round(st[k], 4) for k in ("t_load", "t_bwt", "t_planes", "t_enum", "t_model", "t_coder", "t_total")},
+            "counts": {"nodes": st["nodes"], "symbols": st["symbols"], "rounds": st["rounds"], "sort_rounds": st["sort_rounds"], "flushes": st["flushes"]},
+        }
+        if n_gpus == 1 and not args.no_cpu:
+            cb = cpu_baseline(data, min(args.cpu_sample, n))
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = round(out["value"] / cb["value"], 2)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,11 +80,12 @@ extern "C" int emul_encode_from_bwt(const uint8_t *bwt, uint32_t n, uint32_t off
           if (so.has0) nxt[(p + 1) & 7][0].push_back(so.c0);
           if (so.has1) nxt[(p + 1) & 7][1].push_back(so.c1);
           if (so.hassym) {
-            const uint64_t r = pack_symbol(cfg[p], (uint32_t)p, so.sym, so.k, so.ctx1, so.ctx2, so.ctxs);
-            const uint32_t k = sym_k(r);
-            uint8_t *ctr = stat[p].data() + cfg[p].off[k] + (sym_slot(r) - cfg[p].ctxoff[k]) * k;
-            outrec.push_back(model_step(ctr, k, sym_sym(r), sym_nesc(r)));
-            esc.push_back(sym_esc(r));
+            uint32_t kw, ew;
+            pack_symbol(cfg[p], (uint32_t)p, so.sym, so.k, so.ctx1, so.ctx2, so.ctxs, kw, ew);
+            const uint32_t k = key_k(kw);
+            uint8_t *ctr = stat[p].data() + cfg[p].off[k] + (key_slot(kw) - cfg[p].ctxoff[k]) * k;
+            outrec.push_back(model_step(ctr, k, key_sym(kw)));
+            esc.push_back(ew);
             ++syms;
           }
         }
