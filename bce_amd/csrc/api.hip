@@ -32,20 +32,26 @@ int set_input(bce_hip_ctx *c, const void *src, uint32_t n, hipMemcpyKind kind) {
   return BCE_HIP_OK;
 }
 
-// flush the model for the symbols buffered so far and feed the host coders
+// Flush the model (K4) for the symbols buffered so far and hand the result to the coder threads.
+// The GPU part is synchronous; the range coding of this batch overlaps the next rounds / flushes.
 int flush_symbols(bce_hip_ctx *c, uint64_t nsym) {
   if (nsym) {
-    const double t0 = now_s();
-    BCE_TRY(k4_flush(c, nsym));
-    const double t1 = now_s();
-    std::vector<SymRun> runs[8];
+    FlushSlot &slot = c->slot[c->slot_next];
+    c->slot_next = (c->slot_next + 1) % 3;
+    double t0 = now_s();
+    c->coder->wait(&slot.batch);                 // the slot's previous batch must be fully coded
+    double t1 = now_s();
+    c->stats.t_coder += t1 - t0;
+    BCE_TRY(k4_flush(c, nsym, slot));
+    c->stats.t_model += now_s() - t1;
+    slot.batch.out = slot.h_out;
+    slot.batch.esc = slot.h_esc;
     for (int p = 0; p < 8; ++p) {
-      runs[p].reserve(c->run_log[p].size());
-      for (const RunEntry &e : c->run_log[p]) runs[p].push_back(SymRun{e.start, e.count, e.round});
+      slot.batch.runs[p].clear();
+      slot.batch.runs[p].reserve(c->run_log[p].size());
+      for (const RunEntry &e : c->run_log[p]) slot.batch.runs[p].push_back(SymRun{e.start, e.count, e.round});
     }
-    c->coder->consume_all(runs, c->h_out, c->h_esc, 8);
-    c->stats.t_model += t1 - t0;
-    c->stats.t_coder += now_s() - t1;
+    c->coder->submit(&slot.batch);
     c->stats.flushes++;
     c->stats.symbols += nsym;
   }
@@ -88,8 +94,11 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   for (DevBuf *b : bufs) release(*b);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   if (c->h_runs) (void)hipHostFree(c->h_runs);
-  if (c->h_out) (void)hipHostFree(c->h_out);
-  if (c->h_esc) (void)hipHostFree(c->h_esc);
+  if (c->coder) c->coder->drain();
+  for (FlushSlot &sl : c->slot) {
+    if (sl.h_out) (void)hipHostFree(sl.h_out);
+    if (sl.h_esc) (void)hipHostFree(sl.h_esc);
+  }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -249,9 +258,10 @@ int bce_hip_enum_model(bce_hip_ctx *c, uint32_t *out, uint64_t cap_records, uint
   BCE_TRY(k3_sync_ctl(c, &ctl));
   *count = ctl.sym_total;
   if (ctl.sym_total > cap_records) return BCE_HIP_E_OVERFLOW;
-  BCE_TRY(k4_flush(c, ctl.sym_total));
+  c->coder->drain();
+  BCE_TRY(k4_flush(c, ctl.sym_total, c->slot[0]));
   for (uint64_t i = 0; i < ctl.sym_total; ++i) {
-    const uint64_t o = c->h_out[i];
+    const uint64_t o = c->slot[0].h_out[i];
     out[3 * i + 0] = (uint32_t)(o & 0xFFFF); out[3 * i + 1] = (uint32_t)((o >> 16) & 0xFFFF); out[3 * i + 2] = (uint32_t)((o >> 32) & 0xFFFF);
   }
   BCE_TRY(k3_reset_symbols(c));
@@ -290,7 +300,13 @@ int bce_hip_encode(bce_hip_ctx *c) {
     cur_nodes = ctl.next_nodes;
     const bool done = ctl.done_round != 0xFFFFFFFFu;
     if (ctl.need_flush) {
-      if (ctl.sym_total == 0) { snprintf(c->err, sizeof c->err, "one round exceeds the symbol buffer (%llu records)", (unsigned long long)c->sym_cap); return BCE_HIP_E_OVERFLOW; }
+      if (ctl.sym_total == 0) {
+        // one round alone exceeds the symbol buffer: enlarge it and run the round again
+        uint64_t want = ctl.want_syms + (ctl.want_syms >> 3) + 1024;
+        if (want >= (1ull << 31)) { snprintf(c->err, sizeof c->err, "one round emits %llu symbols (> 2^31)", (unsigned long long)ctl.want_syms); return BCE_HIP_E_OVERFLOW; }
+        BCE_TRY(k3_grow_symbols(c, want));
+        continue;
+      }
       BCE_TRY(flush_symbols(c, ctl.sym_total));
       continue;
     }
@@ -299,6 +315,12 @@ int bce_hip_encode(bce_hip_ctx *c) {
       break;
     }
   }
+  {
+    const double tw = now_s();
+    c->coder->drain();                           // coding of the last batches (the exposed part)
+    c->stats.t_coder += now_s() - tw;
+  }
+  c->stats.t_coder_busy = c->coder->busy_seconds();
   c->stats.rounds = ctl.done_round;
   c->stats.nodes = ctl.nodes_total;
   c->coder->finish(c->config, n, c->offset, c->archive);

@@ -10,6 +10,7 @@
 
 #include "../../include/bce_hip.h"
 #include "bce_core.h"
+#include "host_coder.h"
 
 namespace bce {
 
@@ -19,8 +20,6 @@ struct DevBuf {
   size_t cap = 0;
   template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
-
-struct HostCoder;  // host_coder.cpp
 
 // Device-resident control block of the enumeration (K3).  Everything a round needs to know about
 // the previous round lives here, so rounds can be queued back to back without host round trips.
@@ -35,6 +34,15 @@ struct EnumCtl {
   uint32_t overflow;         // node buffer overflow (fatal)
   uint32_t next_nodes;       // node total of the next round (after the last executed round)
   uint32_t pad;
+  uint64_t want_syms;        // symbol records of the skipped round (to grow the buffer when one round exceeds it)
+};
+
+// Pinned host staging of one model flush + the batch descriptor handed to the coder threads.
+struct FlushSlot {
+  uint64_t *h_out = nullptr;
+  uint32_t *h_esc = nullptr;
+  size_t cap = 0;
+  CoderBatch batch;
 };
 
 struct RunEntry { uint64_t start; uint32_t count; uint32_t round; };  // symbols of (round, plane): [start, start+count)
@@ -72,7 +80,8 @@ struct bce_hip_ctx {
 
   // pinned host staging
   void *h_ctl = nullptr, *h_runs = nullptr;
-  uint64_t *h_out = nullptr; uint32_t *h_esc = nullptr; size_t h_out_cap = 0;
+  bce::FlushSlot slot[3];                        // flushes in flight: GPU fills one while the coders drain the others
+  int slot_next = 0;
 
   // enumeration stepping state
   uint32_t round = 0;
@@ -132,8 +141,9 @@ int k3_sync_ctl(bce_hip_ctx *c, EnumCtl *out);      // copy the control block ba
 int k3_fetch_runs(bce_hip_ctx *c, uint32_t first_round, uint32_t count);  // append run-table rows to run_log
 int k3_get_nodes(bce_hip_ctx *c, int plane, uint32_t *out, uint32_t cap, uint32_t *count);
 int k3_reset_symbols(bce_hip_ctx *c);               // after a flush: sym_total = 0, need_flush = 0
+int k3_grow_symbols(bce_hip_ctx *c, uint64_t cap);  // enlarge the (empty) symbol buffer, clear need_flush
 int k4_prepare(bce_hip_ctx *c);                     // k4_model.hip: counters to zero, cfg upload
-int k4_flush(bce_hip_ctx *c, uint64_t nsym);        // sort + simulate + D2H into h_out/h_esc
+int k4_flush(bce_hip_ctx *c, uint64_t nsym, FlushSlot &slot);   // sort + replay + D2H into the slot (synchronous)
 
 // radix sort (radix_sort.hip): stable LSD sort of (key,val) u32 pairs on key bits [first_bit, first_bit+bits).
 // Result is left in key[res]/val[res]; returns res (0 or 1) through *res.

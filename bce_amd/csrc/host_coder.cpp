@@ -1,6 +1,11 @@
 // host_coder.cpp -- see host_coder.h.  Plain C++ (no HIP).
 #include "host_coder.h"
 
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
 #include <thread>
 
 namespace bce {
@@ -44,37 +49,107 @@ void RangeCoder::flush() {
 }
 
 void HostCoder::begin(const uint8_t config[9][32], const uint32_t C[8], uint32_t n) {
+  drain();
   for (int i = 0; i < 8; ++i) {
+    w_[i].busy = 0;
     plane[i] = RangeCoder();
     plane[i].preamble(config[i]);
     plane[i].uniform(C[i], n + 1);
   }
 }
 
+// Same arithmetic as encode() (bce.cpp:520-529 + shift_out :655-661), with l/h in locals.
+void RangeCoder::encode_run(const uint64_t *out, const uint32_t *esc, uint64_t begin, uint64_t end) {
+  uint64_t l = l_, h = h_;
+  auto step1 = [&](uint32_t cum, uint32_t freq, uint32_t total) {
+    if (__builtin_expect(h - l < total, 0)) {
+      for (int i = 0; i < 4; ++i) data_.push_back((uint16_t)(l >> (48 - 16 * i)));
+      l = 0; h = ~0ull;
+    }
+    const uint64_t step = (h - l) / total;
+    l += step * cum;
+    h = l + step * freq - 1;
+    while (!((h ^ l) >> 48)) {
+      data_.push_back((uint16_t)(h >> 48));
+      l = (l << 16) + 0x0000;
+      h = (h << 16) + 0xFFFF;
+    }
+  };
+  for (uint64_t i = begin; i < end; ++i) {
+    const uint64_t o = out[i];
+    uint32_t bits = esc[i];                             // [26:0] escape bits, [31:27] their count
+    if (__builtin_expect(bits != 0, 0))                 // k > 31 escape, bce.cpp:507-510
+      for (uint32_t nesc = bits >> 27; nesc; --nesc, bits >>= 1) step1(bits & 1, 1, 2);
+    step1((uint32_t)(o & 0xFFFF), (uint32_t)((o >> 16) & 0xFFFF), (uint32_t)((o >> 32) & 0xFFFF));
+  }
+  l_ = l; h_ = h;
+}
+
 void HostCoder::consume(int p, const SymRun *runs, size_t nruns, const uint64_t *out, const uint32_t *esc) {
   RangeCoder &rc = plane[p];
-  for (size_t r = 0; r < nruns; ++r) {
-    const uint64_t b = runs[r].start, e = b + runs[r].count;
-    for (uint64_t i = b; i < e; ++i) {
-      const uint64_t o = out[i];
-      uint32_t bits = esc[i];                           // [26:0] escape bits, [31:27] their count
-      if (__builtin_expect(bits != 0, 0)) {             // k > 31 escape, bce.cpp:507-510
-        for (uint32_t nesc = bits >> 27; nesc; --nesc, bits >>= 1) rc.uniform(bits & 1, 2);
-      }
-      rc.encode((uint32_t)(o & 0xFFFF), (uint32_t)((o >> 16) & 0xFFFF), (uint32_t)((o >> 32) & 0xFFFF));
+  for (size_t r = 0; r < nruns; ++r) rc.encode_run(out, esc, runs[r].start, runs[r].start + runs[r].count);
+}
+
+HostCoder::HostCoder() {
+  for (int p = 0; p < 8; ++p) w_[p].th = std::thread([this, p]() { run(p); });
+}
+
+HostCoder::~HostCoder() {
+  for (int p = 0; p < 8; ++p) {
+    { std::lock_guard<std::mutex> g(w_[p].mu); w_[p].stop = true; }
+    w_[p].cv.notify_all();
+  }
+  for (int p = 0; p < 8; ++p) if (w_[p].th.joinable()) w_[p].th.join();
+}
+
+void HostCoder::run(int p) {
+  Worker &w = w_[p];
+  for (;;) {
+    CoderBatch *b = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(w.mu);
+      w.cv.wait(lk, [&] { return w.stop || !w.q.empty(); });
+      if (w.q.empty()) return;          // stop requested and nothing left
+      b = w.q.front();
+      w.q.pop_front();
     }
+    const auto t0 = std::chrono::steady_clock::now();
+    consume(p, b->runs[p].data(), b->runs[p].size(), b->out, b->esc);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    {
+      std::lock_guard<std::mutex> g(done_mu_);
+      w.busy += dt;
+      b->pending.fetch_sub(1);
+      ++completed_;
+    }
+    done_cv_.notify_all();
   }
 }
 
-void HostCoder::consume_all(const std::vector<SymRun> runs[8], const uint64_t *out, const uint32_t *esc, int threads) {
-  if (threads <= 1) {
-    for (int p = 0; p < 8; ++p) consume(p, runs[p].data(), runs[p].size(), out, esc);
-    return;
+void HostCoder::submit(CoderBatch *b) {
+  b->pending.store(8);
+  { std::lock_guard<std::mutex> g(done_mu_); submitted_ += 8; }
+  for (int p = 0; p < 8; ++p) {
+    { std::lock_guard<std::mutex> g(w_[p].mu); w_[p].q.push_back(b); }
+    w_[p].cv.notify_one();
   }
-  std::thread th[8];
-  for (int p = 0; p < 8; ++p)
-    th[p] = std::thread([this, p, runs, out, esc]() { consume(p, runs[p].data(), runs[p].size(), out, esc); });
-  for (int p = 0; p < 8; ++p) th[p].join();
+}
+
+void HostCoder::wait(CoderBatch *b) {
+  std::unique_lock<std::mutex> lk(done_mu_);
+  done_cv_.wait(lk, [&] { return b->pending.load() == 0; });
+}
+
+void HostCoder::drain() {
+  std::unique_lock<std::mutex> lk(done_mu_);
+  done_cv_.wait(lk, [&] { return completed_ == submitted_; });
+}
+
+double HostCoder::busy_seconds() {
+  std::lock_guard<std::mutex> g(done_mu_);
+  double m = 0;
+  for (int p = 0; p < 8; ++p) m = w_[p].busy > m ? w_[p].busy : m;
+  return m;
 }
 
 void HostCoder::finish(const uint8_t config[9][32], uint32_t n, uint32_t offset, std::vector<uint16_t> &archive) {

@@ -7,11 +7,18 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace bce {
 
-class RangeCoder {
+// Each coder is driven by its own thread: keep every instance on its own cache lines (the l_/h_ state is
+// rewritten on every symbol; eight 40-byte coders side by side false-share and run ~6x slower).
+class alignas(128) RangeCoder {
  public:
   RangeCoder() : l_(0), h_(~0ull) {}
   // one coding step: the shared tail of set(s,k) (cum=s, freq=1, total=k) and set(s,k,c1,c2,cs)
@@ -35,6 +42,8 @@ class RangeCoder {
   void flush();                                         // :610-615
   const std::vector<uint16_t> &data() const { return data_; }
   std::vector<uint16_t> &data() { return data_; }
+  // bulk form of encode() for the GPU model records of one run (state kept in registers)
+  void encode_run(const uint64_t *out, const uint32_t *esc, uint64_t begin, uint64_t end);
 
  private:
   uint64_t l_, h_;
@@ -45,17 +54,47 @@ class RangeCoder {
 // ([26:0] bits, [31:27] count; bce_core.h pack_symbol).
 struct SymRun { uint64_t start; uint32_t count; uint32_t round; };
 
+// One model flush handed to the coder threads: the GPU outputs of its records (pinned host memory
+// owned by the caller) and, per plane, the (round-ordered) runs of record indices that belong to it.
+struct CoderBatch {
+  const uint64_t *out = nullptr;
+  const uint32_t *esc = nullptr;
+  std::vector<SymRun> runs[8];
+  std::atomic<int> pending{0};      // planes that have not finished this batch yet
+};
+
 struct HostCoder {
   RangeCoder plane[8];
+  HostCoder();
+  ~HostCoder();
   // BCE::encode :1124-1130: construct the 8 coders (preamble from config rows 0..7) and code
   // C[i] = zeros(plane (i+7)%8) with range n+1.
   void begin(const uint8_t config[9][32], const uint32_t C[8], uint32_t n);
   // Feed plane p's records of one flush, run by run (coder_[i].set(...), bce.cpp:1302, coder half).
   void consume(int p, const SymRun *runs, size_t nruns, const uint64_t *out, const uint32_t *esc);
-  // Same for all 8 planes on 8 threads (one per plane, as the reference's OpenMP loop :1250-1252).
-  void consume_all(const std::vector<SymRun> runs[8], const uint64_t *out, const uint32_t *esc, int threads);
+  // Asynchronous form: 8 persistent threads, one per plane (the reference's OpenMP loop :1250-1252 has
+  // the same 8-way split); batches are coded in submission order while the GPU produces the next one.
+  void submit(CoderBatch *b);
+  void wait(CoderBatch *b);          // until every plane has finished batch b
+  void drain();                      // until every submitted batch is finished
   // BCE::encode :1134-1157: flush, header coder main(-1) (config row 8), concatenate.
   void finish(const uint8_t config[9][32], uint32_t n, uint32_t offset, std::vector<uint16_t> &archive);
+  double busy_seconds();             // max over planes of the time spent coding since begin()
+
+ private:
+  struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<CoderBatch *> q;
+    double busy = 0;
+    bool stop = false;
+  };
+  Worker w_[8];
+  std::mutex done_mu_;
+  std::condition_variable done_cv_;
+  uint64_t submitted_ = 0, completed_ = 0;   // in units of (batch, plane); guarded by done_mu_
+  void run(int p);
 };
 
 extern const uint8_t kDefaultConfig[9][32];             // AdaptiveCoder<31>::init_ :713-724

@@ -16,6 +16,8 @@
 // without reading anything back.  If the symbol buffer could overflow the scan kernel marks the round
 // as skipped (need_flush) and every later queued round becomes a no-op; the host flushes the model
 // (K4) and resumes from that round.
+#include <stdlib.h>
+
 #include "common.h"
 #include "scan_util.h"
 
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(1024) void k3_scan_kernel(K3Args a) {
   const bool flush = ctl->sym_total + symsum > ctl->sym_cap;
   __syncthreads();   // everyone has read ctl before thread 0 changes it
   if (ovf) { if (tid == 0) ctl->overflow = 1; return; }
-  if (flush) { if (tid == 0) { ctl->need_flush = 1; ctl->skip_round = a.round; } return; }
+  if (flush) { if (tid == 0) { ctl->need_flush = 1; ctl->skip_round = a.round; ctl->want_syms = symsum; } return; }
   // fold the symbol bases into the tile offsets (64-bit: low in [2], high in [3])
   for (uint32_t p = 0; p < 8; ++p)
     for (uint32_t t = tp[p] + tid; t < tp[p + 1]; t += 1024) {
@@ -255,7 +257,10 @@ int k3_begin(bce_hip_ctx *c) {
   // symbol buffer capacity
   uint64_t cap = c->sym_cap_user;
   if (!cap) {
-    const uint64_t want = (uint64_t)8 * n + 1024, soft = (uint64_t)1 << 27;   // 128M records per flush by default
+    // default flush granularity: 16M records (pipelines with the host coders); a round that needs more
+    // grows the buffer on demand (k3_grow_symbols)
+    const char *env = getenv("BCE_HIP_FLUSH_RECORDS");
+    const uint64_t want = (uint64_t)8 * n + 1024, soft = env ? strtoull(env, nullptr, 10) : ((uint64_t)1 << 24);
     cap = want < soft ? want : soft;
   }
   c->sym_cap = cap;
@@ -325,6 +330,20 @@ int k3_reset_symbols(bce_hip_ctx *c) {
   BCE_HIP_TRY(c, hipMemsetAsync(&d->sym_total, 0, sizeof(uint64_t), c->stream));
   BCE_HIP_TRY(c, hipMemsetAsync(&d->need_flush, 0, sizeof(uint32_t), c->stream));
   for (int p = 0; p < 8; ++p) c->run_log[p].clear();
+  return BCE_HIP_OK;
+}
+
+int k3_grow_symbols(bce_hip_ctx *c, uint64_t cap) {
+  if (cap >= (1ull << 31)) return BCE_HIP_E_OVERFLOW;
+  // the buffer is empty (sym_total == 0): nothing to preserve
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  BCE_TRY(ensure(c, c->skey[0], (size_t)cap * 4));
+  BCE_TRY(ensure(c, c->sesc, (size_t)cap * 4));
+  c->sym_cap = cap;
+  EnumCtl *d = c->ctl.as<EnumCtl>();
+  BCE_HIP_TRY(c, hipMemcpyAsync(&d->sym_cap, &c->sym_cap, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  BCE_HIP_TRY(c, hipMemsetAsync(&d->need_flush, 0, sizeof(uint32_t), c->stream));
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
   return BCE_HIP_OK;
 }
 

@@ -140,7 +140,7 @@ int k4_prepare(bce_hip_ctx *c) {
   return BCE_HIP_OK;
 }
 
-int k4_flush(bce_hip_ctx *c, uint64_t nsym64) {
+int k4_flush(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   if (nsym64 == 0) return BCE_HIP_OK;
   if (nsym64 >= (1ull << 31)) return BCE_HIP_E_OVERFLOW;
   const uint32_t nsym = (uint32_t)nsym64;
@@ -148,19 +148,17 @@ int k4_flush(bce_hip_ctx *c, uint64_t nsym64) {
   BCE_TRY(ensure(c, c->skey[1], b4));
   for (int i = 0; i < 2; ++i) BCE_TRY(ensure(c, c->sval[i], b4));
   BCE_TRY(ensure(c, c->sout, (size_t)nsym * 8));
-  if (c->h_out_cap < nsym) {
-    if (c->h_out) (void)hipHostFree(c->h_out);
-    if (c->h_esc) (void)hipHostFree(c->h_esc);
-    c->h_out = nullptr; c->h_esc = nullptr; c->h_out_cap = 0;
-    size_t cap = nsym + (nsym >> 2) + 1024;
-    if (cap > c->sym_cap) cap = (size_t)c->sym_cap;
-    if (cap < nsym) cap = nsym;
-    BCE_HIP_TRY(c, hipHostMalloc((void **)&c->h_out, cap * 8, hipHostMallocDefault));
-    BCE_HIP_TRY(c, hipHostMalloc((void **)&c->h_esc, cap * 4, hipHostMallocDefault));
-    c->h_out_cap = cap;
+  if (slot.cap < nsym) {
+    if (slot.h_out) (void)hipHostFree(slot.h_out);
+    if (slot.h_esc) (void)hipHostFree(slot.h_esc);
+    slot.h_out = nullptr; slot.h_esc = nullptr; slot.cap = 0;
+    size_t cap = (size_t)c->sym_cap > nsym ? (size_t)c->sym_cap : nsym;
+    BCE_HIP_TRY(c, hipHostMalloc((void **)&slot.h_out, cap * 8, hipHostMallocDefault));
+    BCE_HIP_TRY(c, hipHostMalloc((void **)&slot.h_esc, cap * 4, hipHostMallocDefault));
+    slot.cap = cap;
   }
   // the escape words are final as K3 wrote them: start their copy first
-  BCE_HIP_TRY(c, hipMemcpyAsync(c->h_esc, c->sesc.p, b4, hipMemcpyDeviceToHost, c->stream));
+  BCE_HIP_TRY(c, hipMemcpyAsync(slot.h_esc, c->sesc.p, b4, hipMemcpyDeviceToHost, c->stream));
   uint32_t *key[2] = {c->skey[0].as<uint32_t>(), c->skey[1].as<uint32_t>()};
   uint32_t *val[2] = {c->sval[0].as<uint32_t>(), c->sval[1].as<uint32_t>()};
   uint64_t gb = ((uint64_t)nsym + K4_T - 1) / K4_T;
@@ -179,7 +177,7 @@ int k4_flush(bce_hip_ctx *c, uint64_t nsym64) {
   uint64_t wb = ((uint64_t)nsym + 64 * (K4_T / 64) - 1) / (64 * (K4_T / 64));
   const uint32_t sgrid = (uint32_t)(wb < 16384 ? (wb ? wb : 1) : 16384);
   hipLaunchKernelGGL(k4_simulate_kernel, dim3(sgrid), dim3(K4_T), 0, c->stream, a);
-  BCE_HIP_TRY(c, hipMemcpyAsync(c->h_out, c->sout.p, (size_t)nsym * 8, hipMemcpyDeviceToHost, c->stream));
+  BCE_HIP_TRY(c, hipMemcpyAsync(slot.h_out, c->sout.p, (size_t)nsym * 8, hipMemcpyDeviceToHost, c->stream));
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
   BCE_HIP_TRY(c, hipGetLastError());
   return BCE_HIP_OK;

@@ -147,7 +147,7 @@ def main():
             "archive_bytes": len(arch), "archive_sha256": hashlib.sha256(arch).hexdigest(),
             "ratio": round(len(arch) / n, 5),
             "roofline": roof,
-            "breakdown_s": {k: round(st[k], 4) for k in ("t_load", "t_bwt", "t_planes", "t_enum", "t_model", "t_coder", "t_total")},
+            "breakdown_s": {k: round(st[k], 4) for k in ("t_load", "t_bwt", "t_planes", "t_enum", "t_model", "t_coder", "t_coder_busy")},
             "counts": {"nodes": st["nodes"], "symbols": st["symbols"], "rounds": st["rounds"], "sort_rounds": st["sort_rounds"], "flushes": st["flushes"]},
         }
         if n_gpus == 1 and not args.no_cpu:

@@ -110,6 +110,7 @@ typedef struct bce_hip_stats {
   uint32_t reserved;
   double t_load, t_bwt, t_planes, t_enum, t_model, t_coder, t_total;   /* host wall seconds */
   double k3_ms, k3_launches;   /* HIP-event time and launch count of the interval-count kernels */
+  double t_coder_busy;         /* busiest host coder thread (t_coder is only the part not hidden behind GPU work) */
 } bce_hip_stats;
 int bce_hip_get_stats(const bce_hip_ctx *ctx, bce_hip_stats *out);
 

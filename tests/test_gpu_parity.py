@@ -183,3 +183,14 @@ def test_rejects_bad_arguments():
             bce_amd.BCE(bytes([9]) * 288).encode(rf)     # context bits > 5 cannot be serialised
     finally:
         rf.close()
+
+
+def test_symbol_buffer_grows_when_one_round_exceeds_it():
+    """A round that emits more symbols than the whole buffer makes the driver enlarge it (k3_grow_symbols)."""
+    data = oracle.synth_rand(1, 65536)
+    rf = bce_amd.RankFile(data)
+    try:
+        assert bce_amd.BCE(symbol_capacity=1000).encode(rf) == oracle.compress(data)
+        assert bce_amd.stats(rf)["flushes"] > 5
+    finally:
+        rf.close()
