@@ -26,6 +26,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import bce_amd  # noqa: E402
+from bce_amd import sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -98,17 +99,7 @@ def main():
         arch, st = bce_amd.compress_device(t_in.data_ptr(), n, ctx=ctx)
         if dist is not None:
             # RCCL gather of the per-block coded streams to rank 0 (size exchange, then padded gather)
-            a = torch.frombuffer(bytearray(arch), dtype=torch.uint8).to(dev)
-            sz = torch.tensor([a.numel()], dtype=torch.int64, device=dev)
-            sizes = [torch.zeros_like(sz) for _ in range(world)]
-            dist.all_gather(sizes, sz)
-            mx = int(max(int(s.item()) for s in sizes))
-            pad = torch.zeros(mx, dtype=torch.uint8, device=dev)
-            pad[:a.numel()] = a
-            outs = [torch.empty(mx, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-            dist.gather(pad, outs, dst=0)
-            if rank == 0:
-                gathered[0] = [o[:int(s.item())].cpu().numpy().tobytes() for o, s in zip(outs, sizes)]
+            gathered[0] = sharding.gather_streams(arch, dist, dev)
         return arch, st
 
     for _ in range(args.warmup):
