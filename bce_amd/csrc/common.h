@@ -75,7 +75,7 @@ struct bce_hip_ctx {
   bce::DevBuf ctl, tilecnt, tileoff, runs;       // K3 control
   bce::DevBuf skey[2], sval[2], sout, sesc;       // K3->K4: symbol keys (skey[0]) + escape words (sesc); sort ping-pong; outputs
   uint64_t sym_cap = 0;
-  bce::DevBuf stat, dcfg;                        // K4 counters, device copy of PlaneCfg[8]
+  bce::DevBuf stat, dcfg, k4w;                   // K4 counters, device copy of PlaneCfg[8], per-window work arrays
   uint32_t stat_off[8] = {0};
 
   // pinned host staging
@@ -147,6 +147,7 @@ int k4_flush(bce_hip_ctx *c, uint64_t nsym, FlushSlot &slot);   // sort + replay
 
 // radix sort (radix_sort.hip): stable LSD sort of (key,val) u32 pairs on key bits [first_bit, first_bit+bits).
 // Result is left in key[res]/val[res]; returns res (0 or 1) through *res.
-int radix_sort_pairs(bce_hip_ctx *c, uint32_t *key[2], uint32_t *val[2], uint32_t n, uint32_t first_bit, uint32_t bits, int *res);
+int radix_sort_pairs(bce_hip_ctx *c, uint32_t *key[2], uint32_t *val[2], uint32_t n, uint32_t first_bit, uint32_t bits, int *res,
+                     uint32_t max_digit_bits = 8);
 
 }  // namespace bce

@@ -58,18 +58,50 @@ void HostCoder::begin(const uint8_t config[9][32], const uint32_t C[8], uint32_t
   }
 }
 
-// Same arithmetic as encode() (bce.cpp:520-529 + shift_out :655-661), with l/h in locals.
+// Exact floor(x / d) for 64-bit x by multiplication (Granlund-Montgomery round-up method, N = 64):
+//   l = ceil(log2 d), m = floor(2^64 (2^l - d) / d) + 1, t = mulhi(m, x), q = (t + ((x - t) >> 1)) >> (l - 1)
+// valid for every x and 2 <= d < 2^63.  The model totals are < 8192 (k <= 31 counters <= 254, + k), so a
+// table indexed by the divisor replaces the 64-bit divide that sits on the coder's dependency chain
+// (step = (h - l) / total, bce.cpp:527); the quotient is bit-identical.
+namespace {
+struct Recip { uint64_t m; uint32_t sh; };
+constexpr uint32_t kRecipMax = 8192;
+const Recip *recip_table() {
+  static const std::vector<Recip> tab = [] {
+    std::vector<Recip> t(kRecipMax);
+    t[0] = t[1] = Recip{0, 0};
+    for (uint32_t d = 2; d < kRecipMax; ++d) {
+      uint32_t l = 0;
+      while ((1ull << l) < d) ++l;
+      const unsigned __int128 num = (unsigned __int128)((1ull << l) - d) << 64;
+      t[d] = Recip{(uint64_t)(num / d) + 1, l - 1};
+    }
+    return t;
+  }();
+  return tab.data();
+}
+inline uint64_t div_recip(uint64_t x, const Recip &r) {
+  const uint64_t t = (uint64_t)(((unsigned __int128)r.m * x) >> 64);
+  return (t + ((x - t) >> 1)) >> r.sh;
+}
+}  // namespace
+
+uint64_t bce_test_div_recip(uint64_t x, uint32_t d) { return div_recip(x, recip_table()[d]); }
+
+// Same arithmetic as encode() (bce.cpp:520-529 + shift_out :655-661), with l/h in locals and the
+// divide done by reciprocal multiplication.
 void RangeCoder::encode_run(const uint64_t *out, const uint32_t *esc, uint64_t begin, uint64_t end) {
+  const Recip *rt = recip_table();
   uint64_t l = l_, h = h_;
   auto step1 = [&](uint32_t cum, uint32_t freq, uint32_t total) {
     if (__builtin_expect(h - l < total, 0)) {
       for (int i = 0; i < 4; ++i) data_.push_back((uint16_t)(l >> (48 - 16 * i)));
       l = 0; h = ~0ull;
     }
-    const uint64_t step = (h - l) / total;
+    const uint64_t step = total < kRecipMax ? div_recip(h - l, rt[total]) : (h - l) / total;
     l += step * cum;
     h = l + step * freq - 1;
-    while (!((h ^ l) >> 48)) {
+    while (__builtin_expect(!((h ^ l) >> 48), 0)) {
       data_.push_back((uint16_t)(h >> 48));
       l = (l << 16) + 0x0000;
       h = (h << 16) + 0xFFFF;

@@ -97,6 +97,7 @@ struct HostCoder {
   void run(int p);
 };
 
-extern const uint8_t kDefaultConfig[9][32];             // AdaptiveCoder<31>::init_ :713-724
+extern const uint8_t kDefaultConfig[9][32];
+uint64_t bce_test_div_recip(uint64_t x, uint32_t d);   // exposed for tests/core_emul.cpp             // AdaptiveCoder<31>::init_ :713-724
 
 }  // namespace bce

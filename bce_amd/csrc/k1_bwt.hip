@@ -196,7 +196,7 @@ int k1_bwt(bce_hip_ctx *c) {
     hipLaunchKernelGGL(k1_gather_prev_kernel, dim3(g), dim3(K1_T), 0, c->stream, val[res], rank, n, (uint32_t)h,
                        ki[0], vi[0]);
     int r2 = 0;
-    BCE_TRY(radix_sort_pairs(c, ki, vi, n, 0, bits, &r2));
+    BCE_TRY(radix_sort_pairs(c, ki, vi, n, 0, bits, &r2, 9));
     uint32_t *sk = ki[r2], *ssa = vi[r2];
     hipLaunchKernelGGL(k1_gather_next_kernel, dim3(g), dim3(K1_T), 0, c->stream, ssa, rank, n, (uint32_t)h, k2);
     BCE_TRY(rerank(sk, k2, ssa));

@@ -8,7 +8,7 @@
 //   1. stable LSD radix sort of (key word, record index) on key bits 10..28 = plane|slot (3 passes):
 //      every slot's records become one contiguous run, still in stream order; sym and k ride along in
 //      the low key bits, so the replay needs no gather.
-//   2. replay: ONE WAVE PER RUN, 64 events per iteration.  Between two halvings a counter is
+//   2. replay, 64 events (one wave) at a time.  Between two halvings a counter is
 //      base + (number of earlier events with that symbol), so for a 64-event chunk
 //        freq  = C[s] + #{earlier lanes with the same symbol}            (+1)
 //        cum   = sum_{i<s} C[i] + #{earlier lanes with a smaller symbol} (+s)
@@ -16,21 +16,42 @@
 //      with C held one counter per lane (lane i = counter i), the two counts taken from 5 ballots
 //      (bit-sliced less-than / equal masks) and the prefix of C from a 5-step wave scan.  The first
 //      lane whose counter reaches 0xFF ends the chunk: events up to it are committed, all counters are
-//      halved, and the next chunk starts right after it.
+//      halved, and the next chunk starts right after it (k4_replay).
+//      The only truly sequential thing in a slot is WHERE its halvings fall, so long runs (>= 256 events)
+//      are split in three kernels over the 64-aligned windows of the sorted array:
+//        A  k4_window_kernel (all windows in parallel): per-window symbol histogram of the window's
+//           leading run fragment; short runs are replayed on the spot; long runs go to a queue.
+//        B  k4_long_kernel (one wave per long run): walks the run's windows reading only the 32-byte
+//           histograms (prefetched); a window with no counter crossing 0xFF costs ~10 instructions, a
+//           crossing one an exact search inside the window; records the counter state at every window
+//           start.
+//        C  k4_emit_kernel (all windows in parallel): replays each long-run window from its recorded
+//           state and writes the outputs.
 //   3. (cum, freq, total) go back to the record's ORIGINAL index; the host range coders read them in
 //      stream order.
 // Counter state persists in HBM between flushes, so flushes can be arbitrarily small.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace bce {
 
 constexpr int K4_T = 256;
+constexpr uint32_t K4_LONG = 256;        // runs at least this long take the A/B/C route
+constexpr uint8_t K4_NOT_LONG = 0xFE;    // haltW: window's leading fragment is not part of a queued run
+constexpr uint8_t K4_NO_HALVE = 0xFF;    // haltW: long-run window without a halving
 
 struct K4Args {
   const uint32_t *keys, *vals;   // sorted
   uint8_t *stat;
   const PlaneCfg *cfg;
   uint64_t *out;
+  uint8_t *histT;                // [nwin][32] symbol counts of each window's leading run fragment
+  uint8_t *stateW;               // [nwin][32] counters at the window start (long runs)
+  uint32_t *winfo;               // [nwin] runid<<7 | length of the leading fragment
+  uint8_t *haltW;                // [nwin]
+  uint2 *queue;                  // long runs: {start, key word of the first record}
+  uint32_t *qcount;
   uint32_t stat_off[8];
   uint32_t nsym;
 };
@@ -40,17 +61,44 @@ __global__ __launch_bounds__(K4_T) void k4_iota_kernel(uint32_t nsym, uint32_t *
     vals[i] = (uint32_t)i;
 }
 
-// replay one slot run [start, ...) with the whole wave; hkey = key word of its first record
-__device__ __forceinline__ void k4_run(const K4Args &a, uint64_t start, uint32_t hkey, volatile uint32_t *cb,
-                                       uint32_t lane, uint64_t ltm) {
-  const uint32_t runid = hkey >> kSymRunShift;
-  const uint32_t k = key_k(hkey), p = runid >> 16, slot = runid & 0xFFFFu;
+__device__ __forceinline__ uint8_t *k4_counters(const K4Args &a, uint32_t hkey) {
+  const uint32_t runid = hkey >> kSymRunShift, k = key_k(hkey), p = runid >> 16, slot = runid & 0xFFFFu;
   const PlaneCfg &cfg = a.cfg[p];
-  uint8_t *ctr = a.stat + a.stat_off[p] + cfg.off[k] + (slot - cfg.ctxoff[k]) * k;
-  uint32_t C = lane < k ? (uint32_t)ctr[lane] : 0u;
-  uint64_t pos = start;
+  return a.stat + a.stat_off[p] + cfg.off[k] + (slot - cfg.ctxoff[k]) * k;
+}
+
+// lanes with an equal / a smaller symbol among the lanes of `vm`, bit-sliced from the MSB down
+__device__ __forceinline__ void k4_eq_lt(uint32_t s, uint64_t vm, uint64_t &eq, uint64_t &lt) {
+  eq = vm; lt = 0;
+#pragma unroll
+  for (int b = 4; b >= 0; --b) {
+    const bool bit = (s >> b) & 1u;
+    const uint64_t Bb = __ballot(bit);
+    if (bit) { lt |= eq & ~Bb; eq &= Bb; } else { eq &= ~Bb; }
+  }
+}
+
+// lane i (< 32) <- number of lanes in `mask` whose symbol is i   (eq = per-lane equal-symbol mask)
+__device__ __forceinline__ uint32_t k4_symbol_counts(uint32_t s, uint64_t eq, uint64_t mask, bool member,
+                                                    volatile uint32_t *cb, uint32_t lane) {
+  const uint64_t eqm = eq & mask;
+  if (lane < 32) cb[lane] = 0;
+  __builtin_amdgcn_wave_barrier();
+  if (member && (eqm >> lane) == 1ull) cb[s] = (uint32_t)__popcll(eqm);   // highest member lane of its group
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t r = lane < 32 ? cb[lane] : 0u;
+  __builtin_amdgcn_wave_barrier();
+  return r;
+}
+
+// Replay the events [pos, limit) of run `runid` (stops earlier if the run ends) with the whole wave:
+// emits (cum,freq,total), updates the per-lane counters C.  Returns the position reached.
+__device__ __forceinline__ uint64_t k4_replay(const K4Args &a, uint64_t pos, uint64_t limit, uint32_t runid,
+                                              uint32_t k, uint32_t &C, volatile uint32_t *cb, uint32_t lane,
+                                              uint64_t ltm) {
+  if (limit > a.nsym) limit = a.nsym;
   uint64_t j = pos + lane;
-  uint32_t kk = j < a.nsym ? a.keys[j] : 0xFFFFFFFFu;
+  uint32_t kk = j < limit ? a.keys[j] : 0xFFFFFFFFu;
   for (;;) {
     const bool valid = (kk >> kSymRunShift) == runid;     // the run is contiguous: valid lanes form a prefix
     const uint64_t vm = __ballot(valid);
@@ -58,7 +106,7 @@ __device__ __forceinline__ void k4_run(const K4Args &a, uint64_t start, uint32_t
     const uint32_t idx = valid ? a.vals[j] : 0u;
     // speculative load of the next chunk (correct unless a halving cuts this one short)
     const uint64_t jn = j + 64;
-    const uint32_t kn = jn < a.nsym ? a.keys[jn] : 0xFFFFFFFFu;
+    const uint32_t kn = jn < limit ? a.keys[jn] : 0xFFFFFFFFu;
     const uint32_t s = kk & 31u;
     // exclusive prefix of the counters over lanes 0..31 and their total
     uint32_t inc = C;
@@ -70,14 +118,8 @@ __device__ __forceinline__ void k4_run(const K4Args &a, uint64_t start, uint32_t
     const uint32_t T = __shfl(inc, 31);
     const uint32_t Ps = __shfl(inc - C, (int)s);
     const uint32_t Cs = __shfl(C, (int)s);
-    // lanes with an equal / a smaller symbol (valid lanes only), bit-sliced from the MSB down
-    uint64_t eq = vm, lt = 0;
-#pragma unroll
-    for (int b = 4; b >= 0; --b) {
-      const bool bit = (s >> b) & 1u;
-      const uint64_t Bb = __ballot(bit);
-      if (bit) { lt |= eq & ~Bb; eq &= Bb; } else { eq &= ~Bb; }
-    }
+    uint64_t eq, lt;
+    k4_eq_lt(s, vm, eq, lt);
     const uint32_t eqb = (uint32_t)__popcll(eq & ltm), ltb = (uint32_t)__popcll(lt & ltm);
     const uint32_t before = Cs + eqb;                       // counter value this event sees
     const uint64_t hm = __ballot(valid && before + 1u == 0xFFu);
@@ -87,24 +129,18 @@ __device__ __forceinline__ void k4_run(const K4Args &a, uint64_t start, uint32_t
       const uint32_t cum = Ps + ltb + s, total = T + lane + k, freq = before + 1u;
       a.out[idx] = (uint64_t)cum | ((uint64_t)freq << 16) | ((uint64_t)total << 32);
     }
-    // per-symbol counts of the committed events -> lane i gets the count of symbol i
     const uint64_t cm = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);
-    const uint64_t eqc = eq & cm;
-    if (lane < 32) cb[lane] = 0;
-    __builtin_amdgcn_wave_barrier();
-    if (commit && (eqc >> lane) == 1ull) cb[s] = (uint32_t)__popcll(eqc);   // highest committed lane of its group
-    __builtin_amdgcn_wave_barrier();
-    C += lane < 32 ? cb[lane] : 0u;
-    __builtin_amdgcn_wave_barrier();
+    C += k4_symbol_counts(s, eq, cm, commit, cb, lane);
     if (hm) C >>= 1;                                       // bce.cpp:531-533
     pos += nc;
     if (nc == 64) { j = jn; kk = kn; }
-    else { j = pos + lane; kk = j < a.nsym ? a.keys[j] : 0xFFFFFFFFu; }
+    else { j = pos + lane; kk = j < limit ? a.keys[j] : 0xFFFFFFFFu; }
   }
-  if (lane < k) ctr[lane] = (uint8_t)C;
+  return pos;
 }
 
-__global__ __launch_bounds__(K4_T) void k4_simulate_kernel(K4Args a) {
+// A: every 64-record window of the sorted array
+__global__ __launch_bounds__(K4_T) void k4_window_kernel(K4Args a) {
   __shared__ uint32_t cntbuf[K4_T / 64][32];
   const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
   volatile uint32_t *cb = cntbuf[w];
@@ -112,16 +148,115 @@ __global__ __launch_bounds__(K4_T) void k4_simulate_kernel(K4Args a) {
   const uint64_t nwaves = (uint64_t)gridDim.x * (K4_T / 64);
   for (uint64_t win = (uint64_t)blockIdx.x * (K4_T / 64) + w; win * 64 < a.nsym; win += nwaves) {
     const uint64_t j0 = win * 64 + lane;
-    const uint32_t key = j0 < a.nsym ? a.keys[j0] : 0xFFFFFFFFu;
-    const uint32_t prev = (j0 > 0 && j0 < a.nsym) ? a.keys[j0 - 1] : 0xFFFFFFFFu;
-    const bool head = j0 < a.nsym && (j0 == 0 || (key >> kSymRunShift) != (prev >> kSymRunShift));
+    const bool inb = j0 < a.nsym;
+    const uint32_t key = inb ? a.keys[j0] : 0xFFFFFFFFu;
+    const uint32_t prev = (j0 > 0 && inb) ? a.keys[j0 - 1] : 0xFFFFFFFFu;
+    const uint32_t rid = key >> kSymRunShift;
+    const bool head = inb && (j0 == 0 || rid != (prev >> kSymRunShift));
     uint64_t heads = __ballot(head);
-    while (heads) {                                         // runs that START in this 64-record window
+    // histogram of the leading fragment (the lanes that continue the run of lane 0)
+    const uint32_t r0 = __shfl(rid, 0);
+    const bool lead = inb && rid == r0;
+    const uint64_t leadm = __ballot(lead);
+    const uint32_t s = key & 31u;
+    uint64_t eq, lt;
+    k4_eq_lt(s, leadm, eq, lt);
+    const uint32_t h = k4_symbol_counts(s, eq, leadm, lead, cb, lane);
+    if (lane < 32) a.histT[win * 32 + lane] = (uint8_t)h;
+    if (lane == 0) {
+      a.winfo[win] = (r0 << 7) | (uint32_t)__popcll(leadm);
+      a.haltW[win] = K4_NOT_LONG;
+    }
+    while (heads) {                                         // runs that START in this window
       const int hl = __ffsll((long long)heads) - 1;
       heads &= heads - 1;
       const uint32_t hkey = __shfl(key, hl);
-      k4_run(a, win * 64 + (uint64_t)hl, hkey, cb, lane, ltm);
+      const uint64_t start = win * 64 + (uint64_t)hl;
+      const uint64_t probe = start + K4_LONG - 1;
+      const bool is_long = probe < a.nsym && (a.keys[probe] >> kSymRunShift) == (hkey >> kSymRunShift);
+      if (is_long) {
+        if (lane == 0) {
+          const uint32_t q = atomicAdd(a.qcount, 1u);
+          a.queue[q] = make_uint2((uint32_t)start, hkey);
+        }
+      } else {
+        const uint32_t k = key_k(hkey);
+        uint8_t *ctr = k4_counters(a, hkey);
+        uint32_t C = lane < k ? (uint32_t)ctr[lane] : 0u;
+        (void)k4_replay(a, start, ~0ull, hkey >> kSymRunShift, k, C, cb, lane, ltm);
+        if (lane < k) ctr[lane] = (uint8_t)C;
+      }
     }
+  }
+}
+
+// B: one wave per long run
+__global__ __launch_bounds__(K4_T) void k4_long_kernel(K4Args a) {
+  __shared__ uint32_t cntbuf[K4_T / 64][32];
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  volatile uint32_t *cb = cntbuf[w];
+  const uint64_t ltm = (1ull << lane) - 1ull;
+  const uint32_t nq = *a.qcount;
+  const uint32_t nwaves = gridDim.x * (K4_T / 64);
+  const uint64_t nwin = ((uint64_t)a.nsym + 63) / 64;
+  for (uint32_t q = blockIdx.x * (K4_T / 64) + w; q < nq; q += nwaves) {
+    const uint2 e = a.queue[q];
+    const uint32_t hkey = e.y, runid = hkey >> kSymRunShift, k = key_k(hkey);
+    uint8_t *ctr = k4_counters(a, hkey);
+    uint32_t C = lane < k ? (uint32_t)ctr[lane] : 0u;
+    // head fragment: from the run start to the end of its window, replayed directly
+    uint64_t win = (uint64_t)e.x / 64 + 1;
+    (void)k4_replay(a, e.x, win * 64, runid, k, C, cb, lane, ltm);
+    // following windows: histogram walk, one window ahead prefetched
+    uint32_t info = win < nwin ? a.winfo[win] : 0xFFFFFFFFu;
+    uint32_t h = (win < nwin && lane < 32) ? a.histT[win * 32 + lane] : 0u;
+    uint32_t kk = (win < nwin && win * 64 + lane < a.nsym) ? a.keys[win * 64 + lane] : 0xFFFFFFFFu;
+    while (win < nwin && (info >> 7) == runid) {
+      const uint64_t wn = win + 1;
+      const uint32_t info_n = wn < nwin ? a.winfo[wn] : 0xFFFFFFFFu;
+      const uint32_t h_n = (wn < nwin && lane < 32) ? a.histT[wn * 32 + lane] : 0u;
+      const uint32_t kk_n = (wn < nwin && wn * 64 + lane < a.nsym) ? a.keys[wn * 64 + lane] : 0xFFFFFFFFu;
+      const uint32_t f = info & 127u;
+      if (lane < 32) a.stateW[win * 32 + lane] = (uint8_t)C;
+      const uint64_t hm = __ballot(lane < k && C + h >= 0xFFu);
+      if (!hm) {
+        C += h;
+        if (lane == 0) a.haltW[win] = K4_NO_HALVE;
+      } else {
+        // some counter reaches 0xFF inside this window: find the first event that does
+        const bool valid = lane < f;
+        const uint32_t s = kk & 31u;
+        const uint64_t vm = __ballot(valid);
+        uint64_t eq, lt;
+        k4_eq_lt(s, vm, eq, lt);
+        const uint32_t before = __shfl(C, (int)s) + (uint32_t)__popcll(eq & ltm);
+        const uint64_t hit = __ballot(valid && before + 1u == 0xFFu);
+        const uint32_t t = (uint32_t)__ffsll((long long)hit) - 1u;     // hit != 0 by construction
+        const uint64_t cm = (2ull << t) - 1ull;                         // lanes <= t
+        const uint32_t cle = k4_symbol_counts(s, eq, cm, valid && lane <= t, cb, lane);
+        C = ((C + cle) >> 1) + (h - cle);                               // halve (bce.cpp:531-533), then the rest
+        if (lane == 0) a.haltW[win] = (uint8_t)t;
+      }
+      if (f < 64) break;                                                // the run ends inside this window
+      win = wn; info = info_n; h = h_n; kk = kk_n;
+    }
+    if (lane < k) ctr[lane] = (uint8_t)C;
+  }
+}
+
+// C: every window whose leading fragment belongs to a long run (beyond the run's first window)
+__global__ __launch_bounds__(K4_T) void k4_emit_kernel(K4Args a) {
+  __shared__ uint32_t cntbuf[K4_T / 64][32];
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  volatile uint32_t *cb = cntbuf[w];
+  const uint64_t ltm = (1ull << lane) - 1ull;
+  const uint64_t nwaves = (uint64_t)gridDim.x * (K4_T / 64);
+  for (uint64_t win = (uint64_t)blockIdx.x * (K4_T / 64) + w; win * 64 < a.nsym; win += nwaves) {
+    if (a.haltW[win] == K4_NOT_LONG) continue;
+    const uint32_t info = a.winfo[win];
+    const uint32_t hkey = a.keys[win * 64];
+    uint32_t C = lane < 32 ? (uint32_t)a.stateW[win * 32 + lane] : 0u;
+    (void)k4_replay(a, win * 64, win * 64 + (info & 127u), info >> 7, key_k(hkey), C, cb, lane, ltm);
   }
 }
 
@@ -138,6 +273,11 @@ int k4_prepare(bce_hip_ctx *c) {
   BCE_HIP_TRY(c, hipMemcpyAsync(c->dcfg.p, c->cfg, sizeof(PlaneCfg) * 8, hipMemcpyHostToDevice, c->stream));
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
   return BCE_HIP_OK;
+}
+
+static uint32_t k4_digit_bits() {
+  static const uint32_t v = [] { const char *e = getenv("BCE_HIP_K4_DIGIT"); return e ? (uint32_t)atoi(e) : 8u; }();
+  return v;
 }
 
 int k4_flush(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
@@ -165,18 +305,32 @@ int k4_flush(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   const uint32_t grid = (uint32_t)(gb < 8192 ? gb : 8192);
   hipLaunchKernelGGL(k4_iota_kernel, dim3(grid), dim3(K4_T), 0, c->stream, nsym, val[0]);
   int res = 0;
-  BCE_TRY(radix_sort_pairs(c, key, val, nsym, kSymRunShift, kSymRunBits, &res));
+  BCE_TRY(radix_sort_pairs(c, key, val, nsym, kSymRunShift, kSymRunBits, &res, k4_digit_bits()));
+  // per-window work arrays, carved from one buffer: histT | stateW | winfo | queue | haltW | qcount
+  const size_t nwin = ((size_t)nsym + 63) / 64;
+  auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  const size_t o_hist = 0, o_state = o_hist + nwin * 32, o_info = o_state + nwin * 32,
+               o_queue = up16(o_info + nwin * 4), o_halt = o_queue + (nwin / 4 + 2) * 8, o_qc = up16(o_halt + nwin);
+  BCE_TRY(ensure(c, c->k4w, o_qc + 16));
+  uint8_t *wbuf = c->k4w.as<uint8_t>();
   K4Args a;
   a.keys = key[res]; a.vals = val[res];
   a.stat = c->stat.as<uint8_t>();
   a.cfg = c->dcfg.as<PlaneCfg>();
   a.out = c->sout.as<uint64_t>();
+  a.histT = wbuf + o_hist; a.stateW = wbuf + o_state;
+  a.winfo = reinterpret_cast<uint32_t *>(wbuf + o_info);
+  a.queue = reinterpret_cast<uint2 *>(wbuf + o_queue);
+  a.haltW = wbuf + o_halt;
+  a.qcount = reinterpret_cast<uint32_t *>(wbuf + o_qc);
   for (int p = 0; p < 8; ++p) a.stat_off[p] = c->stat_off[p];
   a.nsym = nsym;
-  // one wave per 64-record window; windows without a run head exit at once
-  uint64_t wb = ((uint64_t)nsym + 64 * (K4_T / 64) - 1) / (64 * (K4_T / 64));
+  BCE_HIP_TRY(c, hipMemsetAsync(a.qcount, 0, 16, c->stream));
+  uint64_t wb = ((uint64_t)nwin + (K4_T / 64) - 1) / (K4_T / 64);
   const uint32_t sgrid = (uint32_t)(wb < 16384 ? (wb ? wb : 1) : 16384);
-  hipLaunchKernelGGL(k4_simulate_kernel, dim3(sgrid), dim3(K4_T), 0, c->stream, a);
+  hipLaunchKernelGGL(k4_window_kernel, dim3(sgrid), dim3(K4_T), 0, c->stream, a);
+  hipLaunchKernelGGL(k4_long_kernel, dim3(1024), dim3(K4_T), 0, c->stream, a);
+  hipLaunchKernelGGL(k4_emit_kernel, dim3(sgrid), dim3(K4_T), 0, c->stream, a);
   BCE_HIP_TRY(c, hipMemcpyAsync(slot.h_out, c->sout.p, (size_t)nsym * 8, hipMemcpyDeviceToHost, c->stream));
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
   BCE_HIP_TRY(c, hipGetLastError());

@@ -15,6 +15,8 @@ constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 8;
 constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;  // 2048 keys per block iteration
 constexpr int RS_MAXB = 1024;
+constexpr int RS_MAXBITS = 10;                   // digit width per pass (<= 1024 bins)
+constexpr int RS_MAXBINS = 1 << RS_MAXBITS;
 
 struct RsPlan { uint32_t nb, per_block; };
 static RsPlan rs_plan(uint32_t n) {
@@ -40,10 +42,10 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, int nbits, bool vali
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n,
                                                              uint32_t per_block, uint32_t nb, int shift, int nbits,
                                                              uint32_t *__restrict__ hist) {
-  __shared__ uint32_t lh[256];
+  __shared__ uint32_t lh[RS_MAXBINS];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  const uint32_t mask = (1u << nbits) - 1u;
-  lh[tid] = 0;
+  const uint32_t nbins = 1u << nbits, mask = nbins - 1u;
+  for (uint32_t d = tid; d < nbins; d += RS_THREADS) lh[d] = 0;
   __syncthreads();
   const uint64_t beg = (uint64_t)blockIdx.x * per_block;
   uint64_t end = beg + per_block;
@@ -65,25 +67,24 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t *__r
     }
   }
   __syncthreads();
-  if (tid <= mask) hist[(size_t)tid * nb + blockIdx.x] = lh[tid];
+  for (uint32_t d = tid; d < nbins; d += RS_THREADS) hist[(size_t)d * nb + blockIdx.x] = lh[d];
 }
 
-// exclusive scan of hist[0..total) in place (digit-major, block-minor order); one block of 1024
-__global__ __launch_bounds__(1024) void rs_scan_kernel(uint32_t *__restrict__ hist, uint32_t total) {
-  const uint32_t tid = threadIdx.x;
-  const uint32_t per = (total + 1023u) / 1024u;
-  const uint32_t b = tid * per;
-  uint32_t e = b + per;
-  if (e > total) e = total;
-  uint32_t s = 0;
-  for (uint32_t i = b; i < e; ++i) s += hist[i];
-  uint32_t tot;
-  uint32_t run = block_excl_scan_sum<1024>(s, &tot);
-  for (uint32_t i = b; i < e; ++i) {
-    const uint32_t v = hist[i];
-    hist[i] = run;
-    run += v;
+// One block per digit: exclusive scan of the digit's row hist[d][0..nb) in place (coalesced), row total aside.
+// The digit bases (exclusive scan of the row totals) are folded in by the scatter kernel's prologue.
+__global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t *__restrict__ hist, uint32_t nb,
+                                                             uint32_t *__restrict__ rowtotal) {
+  uint32_t *row = hist + (size_t)blockIdx.x * nb;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nb; base += RS_THREADS) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nb ? row[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan_sum<RS_THREADS>(v, &tot);
+    if (i < nb) row[i] = carry + ex;
+    carry += tot;
   }
+  if (threadIdx.x == 0) rowtotal[blockIdx.x] = carry;
 }
 
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *__restrict__ keys_in,
@@ -91,18 +92,36 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
                                                                 uint32_t *__restrict__ keys_out,
                                                                 uint32_t *__restrict__ vals_out, uint32_t n,
                                                                 uint32_t per_block, uint32_t nb, int shift, int nbits,
-                                                                const uint32_t *__restrict__ hist) {
-  __shared__ uint32_t wcnt[4][256];
-  __shared__ uint32_t goff[256];
+                                                                const uint32_t *__restrict__ hist,
+                                                                const uint32_t *__restrict__ rowtotal) {
+  __shared__ uint32_t wcnt[4][RS_MAXBINS];
+  __shared__ uint32_t goff[RS_MAXBINS];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-  const uint32_t mask = (1u << nbits) - 1u;
-  if (tid <= mask) goff[tid] = hist[(size_t)tid * nb + blockIdx.x];
+  const uint32_t nbins = 1u << nbits, mask = nbins - 1u;
+  // digit bases: exclusive scan of the row totals (<= 1024 entries, 4 per thread), plus this block's row offset
+  {
+    uint32_t v[RS_MAXBINS / RS_THREADS], sum = 0;
+#pragma unroll
+    for (int q = 0; q < RS_MAXBINS / RS_THREADS; ++q) {
+      const uint32_t d = tid * (RS_MAXBINS / RS_THREADS) + q;
+      v[q] = d < nbins ? rowtotal[d] : 0u;
+      sum += v[q];
+    }
+    uint32_t tot;
+    uint32_t run = block_excl_scan_sum<RS_THREADS>(sum, &tot);
+#pragma unroll
+    for (int q = 0; q < RS_MAXBINS / RS_THREADS; ++q) {
+      const uint32_t d = tid * (RS_MAXBINS / RS_THREADS) + q;
+      if (d < nbins) goff[d] = run + hist[(size_t)d * nb + blockIdx.x];
+      run += v[q];
+    }
+  }
   const uint64_t beg = (uint64_t)blockIdx.x * per_block;
   uint64_t end = beg + per_block;
   if (end > n) end = n;
   const uint64_t lt = (1ull << lane) - 1ull;
   for (uint64_t base = beg; base < end; base += RS_CHUNK) {
-    wcnt[0][tid] = 0; wcnt[1][tid] = 0; wcnt[2][tid] = 0; wcnt[3][tid] = 0;
+    for (uint32_t d = tid; d < nbins; d += RS_THREADS) { wcnt[0][d] = 0; wcnt[1][d] = 0; wcnt[2][d] = 0; wcnt[3][d] = 0; }
     __syncthreads();
     uint32_t key[RS_ITEMS], val[RS_ITEMS], lr[RS_ITEMS];
     // wave w owns the contiguous quarter [base + w*512, base + (w+1)*512): order = (wave, step, lane)
@@ -126,11 +145,11 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
       lr[it] = pre + (uint32_t)__popcll(peers & lt);
     }
     __syncthreads();
-    if (tid <= mask) {
-      const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
-      const uint32_t b = goff[tid];
-      wcnt[0][tid] = b; wcnt[1][tid] = b + c0; wcnt[2][tid] = b + c0 + c1; wcnt[3][tid] = b + c0 + c1 + c2;
-      goff[tid] = b + c0 + c1 + c2 + c3;
+    for (uint32_t d = tid; d < nbins; d += RS_THREADS) {
+      const uint32_t c0 = wcnt[0][d], c1 = wcnt[1][d], c2 = wcnt[2][d], c3 = wcnt[3][d];
+      const uint32_t b = goff[d];
+      wcnt[0][d] = b; wcnt[1][d] = b + c0; wcnt[2][d] = b + c0 + c1; wcnt[3][d] = b + c0 + c1 + c2;
+      goff[d] = b + c0 + c1 + c2 + c3;
     }
     __syncthreads();
 #pragma unroll
@@ -147,23 +166,31 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
   }
 }
 
-int radix_sort_pairs(bce_hip_ctx *c, uint32_t *key[2], uint32_t *val[2], uint32_t n, uint32_t first_bit, uint32_t bits, int *res) {
+int radix_sort_pairs(bce_hip_ctx *c, uint32_t *key[2], uint32_t *val[2], uint32_t n, uint32_t first_bit, uint32_t bits,
+                     int *res, uint32_t max_digit_bits) {
   *res = 0;
   if (n <= 1 || bits == 0) return BCE_HIP_OK;
+  if (max_digit_bits < 1 || max_digit_bits > (uint32_t)RS_MAXBITS) max_digit_bits = 8;
   const RsPlan pl = rs_plan(n);
-  BCE_TRY(ensure(c, c->rs_hist, (size_t)256 * pl.nb * sizeof(uint32_t)));
+  BCE_TRY(ensure(c, c->rs_hist, ((size_t)RS_MAXBINS * pl.nb + RS_MAXBINS) * sizeof(uint32_t)));
   uint32_t *hist = c->rs_hist.as<uint32_t>();
+  uint32_t *rowtotal = hist + (size_t)RS_MAXBINS * pl.nb;
+  // balanced digits: as few passes as the digit width allows, all of (almost) equal width
+  const uint32_t npass = (bits + max_digit_bits - 1) / max_digit_bits;
   int cur = 0;
-  for (uint32_t done = 0; done < bits; done += 8) {
+  uint32_t done = 0;
+  for (uint32_t pass = 0; pass < npass; ++pass) {
+    const uint32_t left = bits - done, pleft = npass - pass;
+    const int nbits = (int)((left + pleft - 1) / pleft);
     const uint32_t shift = first_bit + done;
-    const int nbits = (int)((bits - done) < 8 ? (bits - done) : 8);
     const uint32_t nbins = 1u << nbits;
     hipLaunchKernelGGL(rs_hist_kernel, dim3(pl.nb), dim3(RS_THREADS), 0, c->stream, key[cur], n, pl.per_block, pl.nb,
                        (int)shift, nbits, hist);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, c->stream, hist, nbins * pl.nb);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(nbins), dim3(RS_THREADS), 0, c->stream, hist, pl.nb, rowtotal);
     hipLaunchKernelGGL(rs_scatter_kernel, dim3(pl.nb), dim3(RS_THREADS), 0, c->stream, key[cur], val[cur],
-                       key[cur ^ 1], val[cur ^ 1], n, pl.per_block, pl.nb, (int)shift, nbits, hist);
+                       key[cur ^ 1], val[cur ^ 1], n, pl.per_block, pl.nb, (int)shift, nbits, hist, rowtotal);
     cur ^= 1;
+    done += (uint32_t)nbits;
   }
   BCE_HIP_TRY(c, hipGetLastError());
   *res = cur;

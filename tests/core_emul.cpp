@@ -106,3 +106,20 @@ extern "C" int emul_encode_from_bwt(const uint8_t *bwt, uint32_t n, uint32_t off
   return 0;
 }
 extern "C" void emul_free(void *p) { free(p); }
+
+// exhaustive-ish check of the reciprocal division used by the host coder: returns the number of mismatches
+extern "C" uint64_t emul_check_recip(uint64_t seed, uint64_t samples_per_divisor) {
+  uint64_t bad = 0, st = seed ? seed : 1;
+  auto next = [&]() { st ^= st >> 12; st ^= st << 25; st ^= st >> 27; return st * 0x2545F4914F6CDD1DULL; };
+  for (uint32_t d = 2; d < 8192; ++d) {
+    const uint64_t edge[] = {0, 1, d - 1ull, d, d + 1ull, ~0ull, ~0ull - 1, ~0ull - d, (~0ull / d) * d, (~0ull / d) * d - 1,
+                             1ull << 63, (1ull << 63) - 1, (1ull << 48), (1ull << 48) - 1};
+    for (uint64_t x : edge) bad += bce::bce_test_div_recip(x, d) != x / d;
+    for (uint64_t i = 0; i < samples_per_divisor; ++i) {
+      uint64_t x = next();
+      if (i & 1) x >>= (next() & 63);
+      bad += bce::bce_test_div_recip(x, d) != x / d;
+    }
+  }
+  return bad;
+}

@@ -22,6 +22,8 @@ def emul():
                                        C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.emul_rank1.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
     L.emul_free.argtypes = [C.c_void_p]
+    L.emul_check_recip.argtypes = [C.c_uint64, C.c_uint64]
+    L.emul_check_recip.restype = C.c_uint64
     return L
 
 
@@ -75,3 +77,8 @@ def test_granule_rank_matches_reference_rank(emul):
         emul.emul_rank1(a.ctypes.data, len(a), plane, idx.ctypes.data, len(idx), out.ctypes.data)
         cum = np.concatenate([[0], np.cumsum(bits[plane])])
         assert (out == cum[idx]).all()
+
+
+def test_host_coder_reciprocal_division_is_exact(emul):
+    """step = (h - l) / total (bce.cpp:527) is done by multiplication in the host coder: must be the exact quotient."""
+    assert emul.emul_check_recip(12345, 2000) == 0
