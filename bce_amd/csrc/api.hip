@@ -89,11 +89,12 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf *bufs[] = {&c->text, &c->bwt, &c->sa[0], &c->sa[1], &c->key[0], &c->key[1], &c->rank, &c->k2, &c->nrk,
                     &c->rs_hist, &c->blk, &c->ptmp[0], &c->ptmp[1], &c->gran, &c->nodes, &c->ctl, &c->tilecnt,
-                    &c->tileoff, &c->runs, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
+                    &c->tileoff, &c->runs, &c->desc, &c->truns, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
                     &c->sesc, &c->stat, &c->dcfg, &c->k4w};
   for (DevBuf *b : bufs) release(*b);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   if (c->h_runs) (void)hipHostFree(c->h_runs);
+  if (c->h_truns) (void)hipHostFree(c->h_truns);
   if (c->coder) c->coder->drain();
   for (FlushSlot &sl : c->slot) {
     if (sl.h_out) (void)hipHostFree(sl.h_out);
@@ -221,9 +222,10 @@ int bce_hip_enum_round(bce_hip_ctx *c, uint64_t *next_nodes) {
   if (!c || !c->enum_active) return BCE_HIP_E_STATE;
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t first = c->round;
-  BCE_TRY(k3_rounds(c, 1));
+  BCE_TRY(k3_rounds(c, 1, (uint64_t)c->n * 4));
   EnumCtl ctl;
   BCE_TRY(k3_sync_ctl(c, &ctl));
+  if (ctl.lookback_fail) return BCE_HIP_E_INTERNAL;
   if (ctl.overflow) return BCE_HIP_E_OVERFLOW;
   if (ctl.need_flush) return BCE_HIP_E_OVERFLOW;   // the stepping interface never flushes
   BCE_TRY(k3_fetch_runs(c, first, 1));
@@ -285,17 +287,29 @@ int bce_hip_encode(bce_hip_ctx *c) {
   for (int i = 0; i < 8; ++i) cur_nodes += (C[i] && n - C[i]) ? 1 : 0;
   EnumCtl ctl;
   for (;;) {
-    // wide rounds: sync often (the round dominates); narrow rounds: queue many per sync
-    uint32_t batch = cur_nodes > (1u << 20) ? 4u : (cur_nodes > (1u << 14) ? 16u : 64u);
     const uint32_t first = c->round;
+    uint32_t executed = 0;
+    static const bool use_tail = getenv("BCE_HIP_NO_TAIL") == nullptr;
     BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    BCE_TRY(k3_rounds(c, batch));
-    BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    BCE_TRY(k3_sync_ctl(c, &ctl));
+    if (use_tail && cur_nodes <= K3_TAIL_ENTER) {
+      // narrow phase: the persistent single-workgroup kernel loops over rounds on the device
+      BCE_TRY(k3_tail(c));
+      BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+      BCE_TRY(k3_sync_ctl(c, &ctl));
+      executed = ctl.tail_rounds;
+      BCE_TRY(k3_fetch_tail_runs(c, executed));
+    } else {
+      // wide rounds: sync often (the round dominates); medium rounds: queue many per sync
+      const uint32_t batch = cur_nodes > (1u << 20) ? 4u : (cur_nodes > (1u << 14) ? 16u : 64u);
+      BCE_TRY(k3_rounds(c, batch, cur_nodes));
+      BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+      BCE_TRY(k3_sync_ctl(c, &ctl));
+      executed = ctl.need_flush ? ctl.skip_round - first : batch;
+      BCE_TRY(k3_fetch_runs(c, first, executed));
+    }
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms; }
+    if (ctl.lookback_fail) { snprintf(c->err, sizeof c->err, "K3 look-back gave up (round %u)", first); return BCE_HIP_E_INTERNAL; }
     if (ctl.overflow) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
-    const uint32_t executed = ctl.need_flush ? ctl.skip_round - first : batch;
-    BCE_TRY(k3_fetch_runs(c, first, executed));
     c->round = first + executed;
     cur_nodes = ctl.next_nodes;
     const bool done = ctl.done_round != 0xFFFFFFFFu;

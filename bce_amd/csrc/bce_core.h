@@ -73,39 +73,75 @@ struct StepOut {
   uint32_t sym, k, ctx1, ctx2, ctxs;   // coder_.set(sym, k, c1, c2, cs) arguments (bce.cpp:1302)
 };
 
-// rank1(pos) is supplied by the caller (a global-memory gather on the device).
+// One node of BCE::code (bce.cpp:1261-1351) in two halves, so a kernel can issue the rank gathers of many
+// nodes together: node_pre needs rank1(s) and rank1(s+x); node_post needs rank1(s+x0) only when kind == 3.
+struct NodePre {
+  uint32_t s1, n1x, n0x, mn, mx;
+  uint32_t kind;   // 0: all-0 pass-through, 1: all-1 pass-through, 2: mixed with forced split, 3: mixed, coded
+};
+
+BCE_HD void node_pre(const Node &nd, uint32_t r_s, uint32_t r_e, NodePre &pr) {
+  const uint32_t x = nd.x0 + nd.x1;
+  pr.s1 = r_s;                                        // :1265
+  pr.n1x = r_e - r_s;                                 // _1x, :1271
+  pr.n0x = x - pr.n1x;                                // _0x, :1281
+  pr.mn = pr.mx = 0;
+  if (pr.n1x == 0) { pr.kind = 0; return; }           // :1274
+  if (pr.n0x == 0) { pr.kind = 1; return; }           // :1282
+  uint32_t mn = nd.x0 - pr.n1x, mx = pr.n1x - nd.x1;  // :1290-1294
+  mn = ((int32_t)mn < 0) ? 0u : mn;
+  mx = ((int32_t)mx < 0) ? 0u : mx;
+  mx = nd.x0 - mx;
+  pr.mn = mn; pr.mx = mx;
+  pr.kind = (mx != mn) ? 3u : 2u;                     // :1299
+}
+
 // zeros_p = rank0_p(n): child1 lists are indexed from C[p+1] = zeros(plane p) (bce.cpp:1128,1259).
-template <class Rank1>
-BCE_HD void node_step(const Node &nd, uint32_t zeros_p, Rank1 rank1, StepOut &o) {
+BCE_HD void node_post(const Node &nd, uint32_t zeros_p, const NodePre &pr, uint32_t r_m, StepOut &o) {
   const uint32_t s = nd.s, x0 = nd.x0, x1 = nd.x1;
-  const uint32_t x = x0 + x1;
-  const uint32_t s1 = rank1(s);                       // :1265
-  const uint32_t n1x = rank1(s + x) - s1;             // _1x, :1271
-  const uint32_t s0 = s - s1;                         // :1272
+  const uint32_t s1 = pr.s1, s0 = s - s1;             // :1272
   o.has0 = o.has1 = o.hassym = 0;
-  if (n1x == 0) {                                     // :1274-1279
+  if (pr.kind == 0) {                                 // :1274-1279
     o.has0 = 1; o.c0.s = s0; o.c0.x0 = x0; o.c0.x1 = x1;
     return;
   }
-  const uint32_t n0x = x - n1x;                       // _0x, :1281
-  if (n0x == 0) {                                     // :1282-1287
+  if (pr.kind == 1) {                                 // :1282-1287
     o.has1 = 1; o.c1.s = zeros_p + s1; o.c1.x0 = x0; o.c1.x1 = x1;
     return;
   }
-  uint32_t mn = x0 - n1x, mx = n1x - x1;              // :1290-1294
-  mn = ((int32_t)mn < 0) ? 0u : mn;
-  mx = ((int32_t)mx < 0) ? 0u : mx;
-  mx = x0 - mx;
-  uint32_t n0x0 = mn;                                 // :1297
-  if (mx != mn) {                                     // :1299-1302
-    n0x0 = (s + x0 - rank1(s + x0)) - s0;             // rank0(s + x0) - s0
-    o.hassym = 1; o.sym = n0x0 - mn; o.k = mx - mn + 1; o.ctx1 = n0x; o.ctx2 = x1; o.ctxs = x;
+  uint32_t n0x0 = pr.mn;                              // :1297
+  if (pr.kind == 3) {                                 // :1299-1302
+    n0x0 = (s + x0 - r_m) - s0;                       // rank0(s + x0) - s0
+    o.hassym = 1; o.sym = n0x0 - pr.mn; o.k = pr.mx - pr.mn + 1; o.ctx1 = pr.n0x; o.ctx2 = x1; o.ctxs = x0 + x1;
   }
-  const uint32_t n0x1 = n0x - n0x0;                   // :1337
+  const uint32_t n0x1 = pr.n0x - n0x0;                // :1337
   if (n0x0 && n0x1) { o.has0 = 1; o.c0.s = s0; o.c0.x0 = n0x0; o.c0.x1 = n0x1; }
   const uint32_t n1x1 = x1 - n0x1;                    // :1343-1344
-  const uint32_t n1x0 = n1x - n1x1;
+  const uint32_t n1x0 = pr.n1x - n1x1;
   if (n1x0 && n1x1) { o.has1 = 1; o.c1.s = zeros_p + s1; o.c1.x0 = n1x0; o.c1.x1 = n1x1; }
+}
+
+// rank1(pos) is supplied by the caller.  The sequential form used by the CPU unit tests.
+template <class Rank1>
+BCE_HD void node_step(const Node &nd, uint32_t zeros_p, Rank1 rank1, StepOut &o) {
+  NodePre pr;
+  node_pre(nd, rank1(nd.s), rank1(nd.s + nd.x0 + nd.x1), pr);
+  node_post(nd, zeros_p, pr, pr.kind == 3 ? rank1(nd.s + nd.x0) : 0u, o);
+}
+
+// floor(a / b) for quotients known to be < 2^24 (here < 32): one float reciprocal and an exact integer
+// correction instead of the generic ~30-instruction u32 division.  Exact: the float estimate is within +-1.
+BCE_HD uint32_t small_quotient(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t q = (uint32_t)((float)a * __frcp_rn((float)b));
+  // q may be off by one either way (and a*rcp can round up to 2^k): fix with exact arithmetic
+  uint64_t prod = (uint64_t)q * b;
+  if (prod > a) { --q; prod -= b; }
+  if ((uint64_t)a - prod >= b) ++q;
+  return q;
+#else
+  return a / b;
+#endif
 }
 
 // Symbol record = two u32 words kept in two arrays (SoA):
@@ -127,7 +163,8 @@ BCE_HD void pack_symbol(const PlaneCfg &cfg, uint32_t plane, uint32_t sym, uint3
     sym >>= 1;
   }
   const uint32_t bits = cfg.bits[k];
-  const uint32_t ctx = (((uint32_t)(c1 << bits) / cs) << bits) | ((uint32_t)(c2 << bits) / cs);
+  // both quotients are < 2^bits <= 32 (c1, c2 < cs; also after the uint32 wrap of c1 << bits)
+  const uint32_t ctx = (small_quotient((uint32_t)(c1 << bits), cs) << bits) | small_quotient((uint32_t)(c2 << bits), cs);
   const uint32_t slot = cfg.ctxoff[k] + ctx;
   key_word = sym | (k << 5) | (slot << 10) | (plane << 26);
   esc_word = esc | (nesc << 27);

@@ -35,6 +35,12 @@ struct EnumCtl {
   uint32_t next_nodes;       // node total of the next round (after the last executed round)
   uint32_t pad;
   uint64_t want_syms;        // symbol records of the skipped round (to grow the buffer when one round exceeds it)
+  // single-pass rounds (k3_round_kernel): work-queue ticket and per-plane inclusive totals of the round
+  uint32_t ticket;
+  uint32_t lookback_fail;    // a look-back spin gave up (internal error; never expected)
+  uint32_t ptot[8][3];       // written by each plane's last tile: child0 total, child1 total, symbols up to the end of the plane
+  uint32_t tail_rounds;      // rounds executed by the last k3_tail_kernel launch
+  uint32_t pad2;
 };
 
 // Pinned host staging of one model flush + the batch descriptor handed to the coder threads.
@@ -72,7 +78,9 @@ struct bce_hip_ctx {
   uint32_t ngran = 0;                            // granules per plane
   bce::DevBuf nodes;                             // 2 parities x 8 planes x capP nodes
   uint32_t capP = 0;
-  bce::DevBuf ctl, tilecnt, tileoff, runs;       // K3 control
+  bce::DevBuf ctl, tilecnt, tileoff, runs, desc; // K3 control; desc = look-back descriptors [tiles][3]
+  bce::DevBuf truns;                             // run table of the persistent tail kernel [K3_TAIL_MAXROUNDS][8]
+  void *h_truns = nullptr;
   bce::DevBuf skey[2], sval[2], sout, sesc;       // K3->K4: symbol keys (skey[0]) + escape words (sesc); sort ping-pong; outputs
   uint64_t sym_cap = 0;
   bce::DevBuf stat, dcfg, k4w;                   // K4 counters, device copy of PlaneCfg[8], per-window work arrays
@@ -128,6 +136,10 @@ inline double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+constexpr uint32_t K3_TAIL_CAP = 4096;        // nodes the tail kernel holds in LDS (all 8 planes together)
+constexpr uint32_t K3_TAIL_ENTER = 2048;      // the host switches to the tail kernel at or below this many nodes
+constexpr uint32_t K3_TAIL_MAXROUNDS = 65536; // rounds per tail launch (bounded by its run table)
+
 inline uint32_t ceil_log2(uint32_t v) { uint32_t b = 0; while ((1ull << b) < v) ++b; return b; }
 
 // ---- stage implementations (one .hip file each) ----
@@ -136,7 +148,9 @@ int k2_build_planes(bce_hip_ctx *c);                // k2_planes.hip
 int k2_get_plane_bits(bce_hip_ctx *c, int plane, uint8_t *out);
 int k2_rank1(bce_hip_ctx *c, int plane, const uint32_t *idx, uint32_t count, uint32_t *out);
 int k3_begin(bce_hip_ctx *c);                       // k3_enumerate.hip
-int k3_rounds(bce_hip_ctx *c, uint32_t count);      // queue `count` rounds starting at c->round (no sync)
+int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint);   // queue `count` rounds from c->round (no sync)
+int k3_tail(bce_hip_ctx *c);                        // queue the persistent narrow-round kernel from c->round (no sync)
+int k3_fetch_tail_runs(bce_hip_ctx *c, uint32_t rounds);
 int k3_sync_ctl(bce_hip_ctx *c, EnumCtl *out);      // copy the control block back (syncs the stream)
 int k3_fetch_runs(bce_hip_ctx *c, uint32_t first_round, uint32_t count);  // append run-table rows to run_log
 int k3_get_nodes(bce_hip_ctx *c, int plane, uint32_t *out, uint32_t cap, uint32_t *count);

@@ -38,6 +38,7 @@ struct K3Args {
   uint32_t *tilecnt;      // [tiles][4]
   uint32_t *tileoff;      // [tiles][4]
   RunEntry *runs;         // [K3_MAXBATCH][8]
+  unsigned long long *desc;   // look-back descriptors [tiles][3]
   uint32_t capP, ngran, n;
   uint32_t zeros[8];
   uint32_t par, round, run_slot;
@@ -59,34 +60,80 @@ __device__ __forceinline__ void tile_prefix(const K3Args &a, uint32_t tp[9]) {
   tp[8] = acc;
 }
 
-// Process one tile.  WRITE=false: count children/symbols.  WRITE=true: place them.
-template <bool WRITE>
-__device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t tile_in_plane, uint32_t tile_global,
-                                        uint32_t (*lds_cnt)[4][3]) {
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+// Classify the K3_NPT nodes of one thread in PHASES so that the loads of all its nodes are in flight
+// together: (1) the node triples, (2) the two rank granules of every node, (3) the third granule only for
+// the nodes that code a symbol and whose split point falls in neither of the two granules already loaded.
+// (Measured: the kernel is VALU-issue bound, ~250 instructions per node; staging the tile's granule range
+// through LDS was tried and is slower.)
+struct TileOut {
+  uint32_t has0[K3_NPT], has1[K3_NPT], hassym[K3_NPT];
+  Node c0[K3_NPT], c1[K3_NPT];
+  uint32_t kw[K3_NPT], ew[K3_NPT];
+};
+
+__device__ __forceinline__ void k3_classify(const K3Args &a, uint32_t p, uint32_t tile_in_plane, TileOut &t) {
+  const uint32_t tid = threadIdx.x;
   const uint32_t c0n = a.ctl->cnt[a.par][p][0], c1n = a.ctl->cnt[a.par][p][1];
   const uint32_t M = c0n + c1n;
   const Node *src = plane_nodes(a, a.par, p);
   const Granule *G = a.gran + (size_t)p * a.ngran;
   const uint32_t zp = a.zeros[p];
-  auto rank1 = [&](uint32_t s) -> uint32_t {
-    const uint32_t g = div96(s);
-    const Granule q = G[g];
-    return granule_rank1(q, s - g * 96u);
-  };
-  StepOut so[K3_NPT];
+  const PlaneCfg &cfg = a.cfg[p];
+  Node nd[K3_NPT];
+  bool valid[K3_NPT];
+#pragma unroll
+  for (int it = 0; it < K3_NPT; ++it) {
+    const uint32_t q = tile_in_plane * K3_TILE + (uint32_t)it * K3_T + tid;
+    valid[it] = q < M;
+    nd[it] = Node{0u, 1u, 1u};
+    if (valid[it]) nd[it] = src[q < c0n ? q : (a.capP - 1u - (q - c0n))];
+  }
+  uint32_t ga[K3_NPT], gb[K3_NPT], gm[K3_NPT];
+  Granule qa[K3_NPT], qb[K3_NPT], qm[K3_NPT];
+#pragma unroll
+  for (int it = 0; it < K3_NPT; ++it) {          // invalid lanes read granule 0 (always present): harmless
+    ga[it] = div96(nd[it].s);
+    gb[it] = div96(nd[it].s + nd[it].x0 + nd[it].x1);
+    gm[it] = div96(nd[it].s + nd[it].x0);
+    qa[it] = G[valid[it] ? ga[it] : 0u];
+    qb[it] = G[valid[it] ? gb[it] : 0u];
+  }
+  NodePre pr[K3_NPT];
+#pragma unroll
+  for (int it = 0; it < K3_NPT; ++it) {
+    const uint32_t rs = granule_rank1(qa[it], nd[it].s - ga[it] * 96u);
+    const uint32_t re = granule_rank1(qb[it], nd[it].s + nd[it].x0 + nd[it].x1 - gb[it] * 96u);
+    node_pre(nd[it], rs, re, pr[it]);
+    qm[it] = gm[it] == ga[it] ? qa[it] : qb[it];
+    if (valid[it] && pr[it].kind == 3u && gm[it] != ga[it] && gm[it] != gb[it]) qm[it] = G[gm[it]];
+  }
+#pragma unroll
+  for (int it = 0; it < K3_NPT; ++it) {
+    StepOut so;
+    so.has0 = so.has1 = so.hassym = 0;
+    if (valid[it]) {
+      const uint32_t rm = granule_rank1(qm[it], nd[it].s + nd[it].x0 - gm[it] * 96u);
+      node_post(nd[it], zp, pr[it], rm, so);
+    }
+    t.has0[it] = so.has0; t.has1[it] = so.has1; t.hassym[it] = so.hassym;
+    t.c0[it] = so.c0; t.c1[it] = so.c1;
+    t.kw[it] = t.ew[it] = 0;
+    if (so.hassym) pack_symbol(cfg, p, so.sym, so.k, so.ctx1, so.ctx2, so.ctxs, t.kw[it], t.ew[it]);
+  }
+}
+
+// Process one tile.  WRITE=false: count children/symbols.  WRITE=true: place them.
+template <bool WRITE>
+__device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t tile_in_plane, uint32_t tile_global,
+                                        uint32_t (*lds_cnt)[4][3]) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+  TileOut t;
+  k3_classify(a, p, tile_in_plane, t);
   uint32_t pre0[K3_NPT], pre1[K3_NPT], pres[K3_NPT];
   const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int it = 0; it < K3_NPT; ++it) {
-    const uint32_t q = tile_in_plane * K3_TILE + (uint32_t)it * K3_T + tid;
-    const bool valid = q < M;
-    so[it].has0 = so[it].has1 = so[it].hassym = 0;
-    if (valid) {
-      const Node nd = src[q < c0n ? q : (a.capP - 1u - (q - c0n))];
-      node_step(nd, zp, rank1, so[it]);
-    }
-    const uint64_t b0 = __ballot(so[it].has0), b1 = __ballot(so[it].has1), bs = __ballot(so[it].hassym);
+    const uint64_t b0 = __ballot(t.has0[it]), b1 = __ballot(t.has1[it]), bs = __ballot(t.hassym[it]);
     pre0[it] = (uint32_t)__popcll(b0 & lt);
     pre1[it] = (uint32_t)__popcll(b1 & lt);
     pres[it] = (uint32_t)__popcll(bs & lt);
@@ -99,10 +146,10 @@ __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t ti
   __syncthreads();
   if (!WRITE) {
     if (tid < 3) {
-      uint32_t t = 0;
+      uint32_t tt = 0;
       for (int it = 0; it < K3_NPT; ++it)
-        for (int ww = 0; ww < 4; ++ww) t += lds_cnt[it][ww][tid];
-      a.tilecnt[(size_t)tile_global * 4 + tid] = t;
+        for (int ww = 0; ww < 4; ++ww) tt += lds_cnt[it][ww][tid];
+      a.tilecnt[(size_t)tile_global * 4 + tid] = tt;
     }
   } else {
     const uint32_t o0 = a.tileoff[(size_t)tile_global * 4 + 0];
@@ -111,7 +158,6 @@ __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t ti
                         ((uint64_t)a.tileoff[(size_t)tile_global * 4 + 3] << 32);
     const uint32_t pn = (p + 1u) & 7u;
     Node *dst = plane_nodes(a, a.par ^ 1u, pn);
-    const PlaneCfg &cfg = a.cfg[p];
     uint32_t run0 = 0, run1 = 0, runs_ = 0;   // counts of earlier (it, wave) groups
 #pragma unroll
     for (int it = 0; it < K3_NPT; ++it) {
@@ -122,13 +168,11 @@ __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t ti
         if ((uint32_t)ww < w) { b0 += x0; b1 += x1; bs += xs; }
         run0 += x0; run1 += x1; runs_ += xs;
       }
-      if (so[it].has0) dst[o0 + b0 + pre0[it]] = so[it].c0;
-      if (so[it].has1) dst[a.capP - 1u - (o1 + b1 + pre1[it])] = so[it].c1;
-      if (so[it].hassym) {
-        uint32_t kw, ew;
-        pack_symbol(cfg, p, so[it].sym, so[it].k, so[it].ctx1, so[it].ctx2, so[it].ctxs, kw, ew);
-        a.symkey[os + bs + pres[it]] = kw;
-        a.symesc[os + bs + pres[it]] = ew;
+      if (t.has0[it]) dst[o0 + b0 + pre0[it]] = t.c0[it];
+      if (t.has1[it]) dst[a.capP - 1u - (o1 + b1 + pre1[it])] = t.c1[it];
+      if (t.hassym[it]) {
+        a.symkey[os + bs + pres[it]] = t.kw[it];
+        a.symesc[os + bs + pres[it]] = t.ew[it];
       }
     }
   }
@@ -219,6 +263,396 @@ __global__ __launch_bounds__(1024) void k3_scan_kernel(K3Args a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Single-pass round: tiles are taken from a ticket counter (so every predecessor of a tile has started),
+// each tile classifies its nodes once, publishes its three counts and obtains its exclusive prefixes by
+// decoupled look-back, then writes children and symbol records.  Descriptors are 8-byte granules
+//   [63:33] epoch (= round + 1)   [32:31] status (1 = tile aggregate, 2 = inclusive prefix)   [30:0] value
+// stored/loaded with agent-scope relaxed atomics (write-through / L1-bypassing: the data is its own flag, no
+// fences).  The control block is READ-ONLY during the round; k3_finalize_kernel folds the round's totals in.
+// ------------------------------------------------------------------------------------------------------
+constexpr uint32_t K3_SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ unsigned long long k3_pack(uint32_t epoch, uint32_t status, uint32_t value) {
+  return ((unsigned long long)epoch << 33) | ((unsigned long long)status << 31) | (unsigned long long)value;
+}
+
+// executed by ONE wave: chains 0,1 (child lists) restart at the plane's first tile `lo_plane`, chain 2 (symbols) at 0
+__device__ __forceinline__ void k3_lookback(const K3Args &a, uint32_t tile, uint32_t lo_plane, uint32_t epoch,
+                                            const uint32_t agg[3], uint32_t excl[3]) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t lo[3] = {lo_plane, lo_plane, 0u};
+  if (lane < 3) {
+    const uint32_t mylo = lane < 2 ? lo_plane : 0u;
+    const uint32_t myagg = lane == 0 ? agg[0] : (lane == 1 ? agg[1] : agg[2]);
+    __hip_atomic_store(&a.desc[(size_t)tile * 3 + lane], k3_pack(epoch, tile == mylo ? 2u : 1u, myagg),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  bool done[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { excl[c] = 0; done[c] = tile == lo[c]; }
+  long long cur = (long long)tile - 1;
+  while (!(done[0] && done[1] && done[2])) {
+    const long long idx = cur - (long long)lane;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (done[c]) continue;                       // wave-uniform
+      const bool valid = idx >= (long long)lo[c];
+      unsigned long long v = 0;
+      if (valid) {
+        uint32_t spins = 0;
+        for (;;) {
+          v = __hip_atomic_load(&a.desc[(size_t)idx * 3 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((uint32_t)(v >> 33) == epoch && ((v >> 31) & 3ull) != 0) break;
+          if (++spins > K3_SPIN_LIMIT) { a.ctl->lookback_fail = 1; v = k3_pack(epoch, 2u, 0u); break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      const uint32_t st = (uint32_t)((v >> 31) & 3ull), val = (uint32_t)(v & 0x7FFFFFFFull);
+      const uint64_t vmask = __ballot(valid);
+      const uint64_t inclm = __ballot(valid && st == 2u);
+      // sum the aggregates of the nearest tiles up to (and including) the nearest inclusive prefix
+      const uint64_t use = inclm ? ((2ull << (__ffsll((long long)inclm) - 1)) - 1ull) & vmask : vmask;
+      uint32_t x = ((use >> lane) & 1ull) ? val : 0u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+      excl[c] += x;
+      if (inclm) done[c] = true;
+    }
+    cur -= 64;
+  }
+  if (lane < 3) {
+    const uint32_t inc = lane == 0 ? excl[0] + agg[0] : (lane == 1 ? excl[1] + agg[1] : excl[2] + agg[2]);
+    __hip_atomic_store(&a.desc[(size_t)tile * 3 + lane], k3_pack(epoch, 2u, inc), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(K3_T) void k3_round_kernel(K3Args a) {
+  __shared__ uint32_t tp[9];
+  __shared__ uint32_t lds_cnt[K3_NPT][4][3];
+  __shared__ uint32_t s_tile;
+  __shared__ uint32_t s_excl[3];
+  const EnumCtl *ctl = a.ctl;
+  if (ctl->need_flush || ctl->overflow || ctl->lookback_fail) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+  if (tid == 0) tile_prefix(a, tp);
+  __syncthreads();
+  const uint32_t T = tp[8];
+  // flush decision, identical in every block: a round emits at most one symbol per node
+  uint64_t round_nodes = 0;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) round_nodes += (uint64_t)ctl->cnt[a.par][p][0] + ctl->cnt[a.par][p][1];
+  const uint64_t symbase = ctl->sym_total;
+  if (symbase + round_nodes > ctl->sym_cap) {
+    if (blockIdx.x == 0 && tid == 0) { a.ctl->skip_round = a.round; a.ctl->want_syms = round_nodes; a.ctl->need_flush = 1; }
+    return;
+  }
+  const uint32_t epoch = a.round + 1u;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  for (;;) {
+    if (tid == 0) s_tile = atomicAdd(&a.ctl->ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if (tile >= T) break;
+    uint32_t p = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) p += (tile >= tp[k]) ? 1u : 0u;
+    const uint32_t tile_in_plane = tile - tp[p];
+    TileOut t;
+    k3_classify(a, p, tile_in_plane, t);
+    uint32_t pre0[K3_NPT], pre1[K3_NPT], pres[K3_NPT];
+#pragma unroll
+    for (int it = 0; it < K3_NPT; ++it) {
+      const uint64_t b0 = __ballot(t.has0[it]), b1 = __ballot(t.has1[it]), bs = __ballot(t.hassym[it]);
+      pre0[it] = (uint32_t)__popcll(b0 & lt);
+      pre1[it] = (uint32_t)__popcll(b1 & lt);
+      pres[it] = (uint32_t)__popcll(bs & lt);
+      if (lane == 0) {
+        lds_cnt[it][w][0] = (uint32_t)__popcll(b0);
+        lds_cnt[it][w][1] = (uint32_t)__popcll(b1);
+        lds_cnt[it][w][2] = (uint32_t)__popcll(bs);
+      }
+    }
+    __syncthreads();
+    if (w == 0) {
+      uint32_t agg[3] = {0, 0, 0}, excl[3];
+#pragma unroll
+      for (int it = 0; it < K3_NPT; ++it)
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { agg[0] += lds_cnt[it][ww][0]; agg[1] += lds_cnt[it][ww][1]; agg[2] += lds_cnt[it][ww][2]; }
+      k3_lookback(a, tile, tp[p], epoch, agg, excl);
+      if (lane == 0) {
+        s_excl[0] = excl[0]; s_excl[1] = excl[1]; s_excl[2] = excl[2];
+        if (tile + 1 == tp[p + 1]) {     // last tile of its plane: the plane's totals for k3_finalize_kernel
+          a.ctl->ptot[p][0] = excl[0] + agg[0];
+          a.ctl->ptot[p][1] = excl[1] + agg[1];
+          a.ctl->ptot[p][2] = excl[2] + agg[2];
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const uint32_t o0 = s_excl[0], o1 = s_excl[1];
+      const uint64_t os = symbase + s_excl[2];
+      const uint32_t pn = (p + 1u) & 7u;
+      Node *dst = plane_nodes(a, a.par ^ 1u, pn);
+      uint32_t run0 = 0, run1 = 0, runs_ = 0;
+#pragma unroll
+      for (int it = 0; it < K3_NPT; ++it) {
+        uint32_t b0 = run0, b1 = run1, bs = runs_;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+          const uint32_t x0 = lds_cnt[it][ww][0], x1 = lds_cnt[it][ww][1], xs = lds_cnt[it][ww][2];
+          if ((uint32_t)ww < w) { b0 += x0; b1 += x1; bs += xs; }
+          run0 += x0; run1 += x1; runs_ += xs;
+        }
+        if (t.has0[it]) { const uint32_t i0 = o0 + b0 + pre0[it]; if (i0 < a.capP) dst[i0] = t.c0[it]; }
+        if (t.has1[it]) { const uint32_t i1 = o1 + b1 + pre1[it]; if (i1 < a.capP) dst[a.capP - 1u - i1] = t.c1[it]; }
+        if (t.hassym[it]) {
+          a.symkey[os + bs + pres[it]] = t.kw[it];
+          a.symesc[os + bs + pres[it]] = t.ew[it];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// one small block after every round: fold the round's totals into the control block
+__global__ void k3_finalize_kernel(K3Args a) {
+  if (threadIdx.x != 0) return;
+  EnumCtl *ctl = a.ctl;
+  if (ctl->need_flush || ctl->overflow || ctl->lookback_fail) return;
+  uint32_t tp[9];
+  tile_prefix(a, tp);
+  uint64_t curn = 0, nextn = 0, prev_sym = 0;
+  bool ovf = false;
+  for (uint32_t p = 0; p < 8; ++p) {
+    const uint32_t pn = (p + 1u) & 7u;
+    curn += (uint64_t)ctl->cnt[a.par][p][0] + ctl->cnt[a.par][p][1];
+    RunEntry e; e.round = a.round;
+    if (tp[p + 1] > tp[p]) {
+      const uint32_t t0 = ctl->ptot[p][0], t1 = ctl->ptot[p][1], ts = ctl->ptot[p][2];
+      ctl->cnt[a.par ^ 1u][pn][0] = t0;
+      ctl->cnt[a.par ^ 1u][pn][1] = t1;
+      nextn += (uint64_t)t0 + t1;
+      if ((uint64_t)t0 + t1 > a.capP) ovf = true;
+      e.start = ctl->sym_total + prev_sym; e.count = (uint32_t)(ts - prev_sym);
+      prev_sym = ts;
+    } else {
+      ctl->cnt[a.par ^ 1u][pn][0] = 0;
+      ctl->cnt[a.par ^ 1u][pn][1] = 0;
+      e.start = ctl->sym_total + prev_sym; e.count = 0;
+    }
+    a.runs[(size_t)a.run_slot * 8 + p] = e;
+  }
+  ctl->ticket = 0;
+  if (ovf) { ctl->overflow = 1; return; }
+  ctl->sym_total += prev_sym;
+  ctl->nodes_total += curn;
+  ctl->next_nodes = (uint32_t)nextn;
+  if (nextn == 0 && ctl->done_round == 0xFFFFFFFFu) ctl->done_round = a.round + 1u;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Persistent tail: ONE workgroup keeps every live node (<= K3_TAIL_CAP over all 8 planes) in LDS and loops
+// over rounds on the device -- no launches, no host round trips.  Rounds = longest repeated bit string, so
+// inputs with long repeats have 10^4..10^6 rounds that each hold a handful of nodes (SURVEY section 7,
+// "round tail"); a launch per round would dominate everything.  Per round: classify (global rank gathers),
+// one packed block scan (child0 | child1 | symbol counts in 16-bit fields of a u64), scatter children into
+// the other LDS buffer, symbols and the per-(round, plane) run table to HBM.  The kernel leaves when nothing
+// is left, when the node count grows past the LDS capacity, when the symbol buffer cannot take another
+// round, or after max_rounds; state is handed back through the same control block the wide rounds use.
+// ------------------------------------------------------------------------------------------------------
+constexpr int KT_T = 1024;
+constexpr int KT_NPT = K3_TAIL_CAP / KT_T;   // 4 consecutive nodes per thread
+
+__device__ __forceinline__ uint64_t kt_block_excl_scan(uint64_t v, uint64_t *ws, uint64_t *total) {
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  const uint64_t inc = wave_incl_sum64(v);
+  if (lane == 63) ws[wid] = inc;
+  __syncthreads();
+  uint64_t wbase = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < KT_T / 64; ++i) {
+    const uint64_t t = ws[i];
+    if ((uint32_t)i < wid) wbase += t;
+    tot += t;
+  }
+  __syncthreads();
+  *total = tot;
+  return wbase + inc - v;
+}
+
+__global__ __launch_bounds__(KT_T) void k3_tail_kernel(K3Args a, RunEntry *truns, uint32_t max_rounds) {
+  __shared__ Node buf[2][K3_TAIL_CAP];
+  __shared__ uint32_t cnt[2][8][2];
+  __shared__ uint32_t off[9], noff[9];
+  __shared__ uint64_t ws[KT_T / 64];
+  __shared__ uint64_t pstart[9];
+  EnumCtl *ctl = a.ctl;
+  if (ctl->need_flush || ctl->overflow || ctl->lookback_fail) return;
+  const uint32_t tid = threadIdx.x;
+  uint32_t par = a.par, round = a.round, cur = 0, executed = 0;
+  if (tid < 16) cnt[par][tid >> 1][tid & 1] = ctl->cnt[par][tid >> 1][tid & 1];
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t acc = 0;
+    for (int p = 0; p < 8; ++p) { off[p] = acc; acc += cnt[par][p][0] + cnt[par][p][1]; }
+    off[8] = acc;
+  }
+  __syncthreads();
+  uint32_t total = off[8];
+  if (total > K3_TAIL_CAP) { if (tid == 0) ctl->tail_rounds = 0; return; }
+  for (uint32_t q = tid; q < total; q += KT_T) {
+    uint32_t p = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) p += (q >= off[k]) ? 1u : 0u;
+    const uint32_t i = q - off[p], c0 = cnt[par][p][0];
+    buf[0][q] = plane_nodes(a, par, p)[i < c0 ? i : (a.capP - 1u - (i - c0))];
+  }
+  uint64_t sym_total = ctl->sym_total, nodes_total = ctl->nodes_total;
+  const uint64_t sym_cap = ctl->sym_cap;
+  uint32_t flush = 0, done_round = ctl->done_round;
+  __syncthreads();
+  for (;;) {
+    if (total == 0) { if (done_round == 0xFFFFFFFFu) done_round = round ? round : 1u; break; }
+    if (executed >= max_rounds) break;
+    if (sym_total + total > sym_cap) { flush = 1; break; }
+    // ---- classify my KT_NPT consecutive nodes ----
+    Node nd[KT_NPT];
+    uint32_t pl[KT_NPT];
+    bool valid[KT_NPT];
+    uint32_t ga[KT_NPT], gb[KT_NPT], gm[KT_NPT];
+    Granule qa[KT_NPT], qb[KT_NPT], qm[KT_NPT];
+#pragma unroll
+    for (int it = 0; it < KT_NPT; ++it) {
+      const uint32_t q = tid * KT_NPT + (uint32_t)it;
+      valid[it] = q < total;
+      nd[it] = valid[it] ? buf[cur][q] : Node{0u, 1u, 1u};
+      uint32_t p = 0;
+#pragma unroll
+      for (int k = 1; k < 8; ++k) p += (q >= off[k]) ? 1u : 0u;
+      pl[it] = valid[it] ? p : 0u;
+      const Granule *G = a.gran + (size_t)pl[it] * a.ngran;
+      ga[it] = div96(nd[it].s);
+      gb[it] = div96(nd[it].s + nd[it].x0 + nd[it].x1);
+      gm[it] = div96(nd[it].s + nd[it].x0);
+      qa[it] = G[valid[it] ? ga[it] : 0u];
+      qb[it] = G[valid[it] ? gb[it] : 0u];
+    }
+    NodePre pr[KT_NPT];
+#pragma unroll
+    for (int it = 0; it < KT_NPT; ++it) {
+      const uint32_t rs = granule_rank1(qa[it], nd[it].s - ga[it] * 96u);
+      const uint32_t re = granule_rank1(qb[it], nd[it].s + nd[it].x0 + nd[it].x1 - gb[it] * 96u);
+      node_pre(nd[it], rs, re, pr[it]);
+      qm[it] = gm[it] == ga[it] ? qa[it] : qb[it];
+      if (valid[it] && pr[it].kind == 3u && gm[it] != ga[it] && gm[it] != gb[it])
+        qm[it] = (a.gran + (size_t)pl[it] * a.ngran)[gm[it]];
+    }
+    StepOut so[KT_NPT];
+    uint64_t mine = 0;
+#pragma unroll
+    for (int it = 0; it < KT_NPT; ++it) {
+      so[it].has0 = so[it].has1 = so[it].hassym = 0;
+      if (valid[it]) {
+        const uint32_t rm = granule_rank1(qm[it], nd[it].s + nd[it].x0 - gm[it] * 96u);
+        node_post(nd[it], a.zeros[pl[it]], pr[it], rm, so[it]);
+      }
+      mine += (uint64_t)so[it].has0 | ((uint64_t)so[it].has1 << 16) | ((uint64_t)so[it].hassym << 32);
+    }
+    // ---- one packed scan: [15:0] child0, [31:16] child1, [47:32] symbols ----
+    uint64_t tot;
+    uint64_t ex = kt_block_excl_scan(mine, ws, &tot);
+    if (tid < 9) pstart[tid] = tot;                       // default for planes with no nodes: fixed up below
+    __syncthreads();
+    {
+      uint64_t run = ex;
+#pragma unroll
+      for (int it = 0; it < KT_NPT; ++it) {
+        const uint32_t q = tid * KT_NPT + (uint32_t)it;
+        if (valid[it] && q == off[pl[it]]) pstart[pl[it]] = run;     // exclusive prefix at the plane's first node
+        run += (uint64_t)so[it].has0 | ((uint64_t)so[it].has1 << 16) | ((uint64_t)so[it].hassym << 32);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int p = 7; p >= 0; --p) if (off[p] == off[p + 1]) pstart[p] = pstart[p + 1];
+      // next-round geometry: plane pn receives the children of plane (pn + 7) % 8
+      uint32_t acc = 0;
+      for (int pn = 0; pn < 8; ++pn) {
+        const int p = (pn + 7) & 7;
+        const uint64_t d = pstart[p + 1] - pstart[p];
+        const uint32_t t0 = (uint32_t)(d & 0xFFFFu), t1 = (uint32_t)((d >> 16) & 0xFFFFu);
+        cnt[par ^ 1u][pn][0] = t0;
+        cnt[par ^ 1u][pn][1] = t1;
+        noff[pn] = acc;
+        acc += t0 + t1;
+      }
+      noff[8] = acc;
+    }
+    __syncthreads();
+    if (noff[8] > K3_TAIL_CAP) break;                      // the children would not fit in LDS: hand this round to the wide kernels
+    if (tid < 8) {                                         // run table row of this round
+      RunEntry e;
+      e.start = sym_total + ((pstart[tid] >> 32) & 0xFFFFu);
+      e.count = (uint32_t)(((pstart[tid + 1] - pstart[tid]) >> 32) & 0xFFFFu);
+      e.round = round;
+      truns[(size_t)executed * 8 + tid] = e;
+    }
+    // ---- scatter children (LDS) and symbols (HBM) ----
+    {
+      uint64_t run = ex;
+      const PlaneCfg *cfgs = a.cfg;
+#pragma unroll
+      for (int it = 0; it < KT_NPT; ++it) {
+        if (valid[it]) {
+          const uint32_t p = pl[it], pn = (p + 1u) & 7u;
+          const uint64_t rel = run - pstart[p];
+          const uint32_t t0 = cnt[par ^ 1u][pn][0];
+          if (so[it].has0) buf[cur ^ 1u][noff[pn] + (uint32_t)(rel & 0xFFFFu)] = so[it].c0;
+          if (so[it].has1) buf[cur ^ 1u][noff[pn] + t0 + (uint32_t)((rel >> 16) & 0xFFFFu)] = so[it].c1;
+          if (so[it].hassym) {
+            uint32_t kw, ew;
+            pack_symbol(cfgs[p], p, so[it].sym, so[it].k, so[it].ctx1, so[it].ctx2, so[it].ctxs, kw, ew);
+            const uint64_t si = sym_total + ((run >> 32) & 0xFFFFu);
+            a.symkey[si] = kw;
+            a.symesc[si] = ew;
+          }
+        }
+        run += (uint64_t)so[it].has0 | ((uint64_t)so[it].has1 << 16) | ((uint64_t)so[it].hassym << 32);
+      }
+    }
+    sym_total += (tot >> 32) & 0xFFFFu;
+    nodes_total += total;
+    __syncthreads();
+    if (tid < 9) off[tid] = noff[tid];
+    __syncthreads();
+    total = off[8];
+    par ^= 1u; cur ^= 1u; ++round; ++executed;
+  }
+  // ---- hand the state back ----
+  __syncthreads();
+  for (uint32_t q = tid; q < total && total <= K3_TAIL_CAP; q += KT_T) {
+    uint32_t p = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) p += (q >= off[k]) ? 1u : 0u;
+    const uint32_t i = q - off[p], c0 = cnt[par][p][0];
+    plane_nodes(a, par, p)[i < c0 ? i : (a.capP - 1u - (i - c0))] = buf[cur][q];
+  }
+  if (tid < 16) ctl->cnt[par][tid >> 1][tid & 1] = cnt[par][tid >> 1][tid & 1];
+  if (tid == 0) {
+    ctl->sym_total = sym_total;
+    ctl->nodes_total = nodes_total;
+    ctl->next_nodes = total;
+    ctl->done_round = done_round;
+    ctl->tail_rounds = executed;
+    if (flush) { ctl->need_flush = 1; ctl->skip_round = round; ctl->want_syms = total; }
+  }
+}
+
 static K3Args make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot) {
   K3Args a;
   a.ctl = c->ctl.as<EnumCtl>();
@@ -230,6 +664,7 @@ static K3Args make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot) {
   a.tilecnt = c->tilecnt.as<uint32_t>();
   a.tileoff = c->tileoff.as<uint32_t>();
   a.runs = c->runs.as<RunEntry>();
+  a.desc = c->desc.as<unsigned long long>();
   a.capP = c->capP; a.ngran = c->ngran; a.n = c->n;
   for (int i = 0; i < 8; ++i) a.zeros[i] = c->zeros[i];
   a.par = round & 1u; a.round = round; a.run_slot = run_slot;
@@ -250,6 +685,8 @@ int k3_begin(bce_hip_ctx *c) {
   const size_t tiles = (size_t)8 * ((c->capP + K3_TILE - 1) / K3_TILE) + 8;
   BCE_TRY(ensure(c, c->tilecnt, tiles * 16));
   BCE_TRY(ensure(c, c->tileoff, tiles * 16));
+  BCE_TRY(ensure(c, c->desc, tiles * 24));
+  BCE_HIP_TRY(c, hipMemsetAsync(c->desc.p, 0, tiles * 24, c->stream));   // epoch 0 = never published
   BCE_TRY(ensure(c, c->ctl, sizeof(EnumCtl)));
   BCE_TRY(ensure(c, c->runs, (size_t)K3_MAXBATCH * 8 * sizeof(RunEntry)));
   if (!c->h_ctl) BCE_HIP_TRY(c, hipHostMalloc(&c->h_ctl, sizeof(EnumCtl), hipHostMallocDefault));
@@ -290,17 +727,45 @@ int k3_begin(bce_hip_ctx *c) {
   return BCE_HIP_OK;
 }
 
-int k3_rounds(bce_hip_ctx *c, uint32_t count) {
+int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint) {
   if (count > K3_MAXBATCH) count = K3_MAXBATCH;
+  static const int mode = [] { const char *e = getenv("BCE_HIP_K3_MODE"); return e ? atoi(e) : 1; }();
+  (void)nodes_hint;   // a per-batch hint is useless while the node count doubles every round; narrow rounds go to k3_tail
   const uint32_t grid = 2048;
   for (uint32_t i = 0; i < count; ++i) {
     const K3Args a = make_args(c, c->round + i, i);
-    hipLaunchKernelGGL(k3_tiles_kernel<false>, dim3(grid), dim3(K3_T), 0, c->stream, a);
-    hipLaunchKernelGGL(k3_scan_kernel, dim3(1), dim3(1024), 0, c->stream, a);
-    hipLaunchKernelGGL(k3_tiles_kernel<true>, dim3(grid), dim3(K3_T), 0, c->stream, a);
+    if (mode == 3) {          // v1: count -> scan -> write (kept for A/B measurements)
+      hipLaunchKernelGGL(k3_tiles_kernel<false>, dim3(grid), dim3(K3_T), 0, c->stream, a);
+      hipLaunchKernelGGL(k3_scan_kernel, dim3(1), dim3(1024), 0, c->stream, a);
+      hipLaunchKernelGGL(k3_tiles_kernel<true>, dim3(grid), dim3(K3_T), 0, c->stream, a);
+    } else {                  // single pass with decoupled look-back + finalize
+      hipLaunchKernelGGL(k3_round_kernel, dim3(grid), dim3(K3_T), 0, c->stream, a);
+      hipLaunchKernelGGL(k3_finalize_kernel, dim3(1), dim3(64), 0, c->stream, a);
+    }
   }
   BCE_HIP_TRY(c, hipGetLastError());
-  c->stats.k3_launches += 3.0 * count;
+  c->stats.k3_launches += (mode == 3 ? 3.0 : 2.0) * count;
+  return BCE_HIP_OK;
+}
+
+int k3_tail(bce_hip_ctx *c) {
+  BCE_TRY(ensure(c, c->truns, (size_t)K3_TAIL_MAXROUNDS * 8 * sizeof(RunEntry)));
+  if (!c->h_truns) BCE_HIP_TRY(c, hipHostMalloc(&c->h_truns, (size_t)K3_TAIL_MAXROUNDS * 8 * sizeof(RunEntry), hipHostMallocDefault));
+  const K3Args a = make_args(c, c->round, 0);
+  hipLaunchKernelGGL(k3_tail_kernel, dim3(1), dim3(KT_T), 0, c->stream, a, c->truns.as<RunEntry>(), K3_TAIL_MAXROUNDS);
+  BCE_HIP_TRY(c, hipGetLastError());
+  c->stats.k3_launches += 1.0;
+  return BCE_HIP_OK;
+}
+
+int k3_fetch_tail_runs(bce_hip_ctx *c, uint32_t rounds) {
+  if (!rounds) return BCE_HIP_OK;
+  BCE_HIP_TRY(c, hipMemcpyAsync(c->h_truns, c->truns.p, (size_t)rounds * 8 * sizeof(RunEntry), hipMemcpyDeviceToHost, c->stream));
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const RunEntry *r = reinterpret_cast<const RunEntry *>(c->h_truns);
+  for (uint32_t i = 0; i < rounds; ++i)
+    for (int p = 0; p < 8; ++p)
+      if (r[(size_t)i * 8 + p].count) c->run_log[p].push_back(r[(size_t)i * 8 + p]);
   return BCE_HIP_OK;
 }
 

@@ -190,55 +190,93 @@ __global__ __launch_bounds__(K4_T) void k4_window_kernel(K4Args a) {
   }
 }
 
-// B: one wave per long run
+// B: one wave per long run.  The walk is serial in the counter state but its inputs (window info, window
+// histogram, window keys) do not depend on that state, so they are streamed in groups of K4_GW windows:
+// the next group's global loads are issued before the current group is processed out of LDS, which keeps
+// HBM/L2 latency off the serial chain.
+constexpr uint32_t K4_GW = 16;                      // windows per staged group
+struct K4Stage {                                    // per wave
+  uint32_t keys[K4_GW][64];
+  uint32_t hist[K4_GW][8];                          // 32 bytes per window
+  uint32_t info[K4_GW];
+};
+
 __global__ __launch_bounds__(K4_T) void k4_long_kernel(K4Args a) {
   __shared__ uint32_t cntbuf[K4_T / 64][32];
+  __shared__ K4Stage stage[K4_T / 64];
   const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
   volatile uint32_t *cb = cntbuf[w];
+  volatile K4Stage *st = &stage[w];
   const uint64_t ltm = (1ull << lane) - 1ull;
   const uint32_t nq = *a.qcount;
   const uint32_t nwaves = gridDim.x * (K4_T / 64);
   const uint64_t nwin = ((uint64_t)a.nsym + 63) / 64;
+  const uint32_t *hist32 = reinterpret_cast<const uint32_t *>(a.histT);
   for (uint32_t q = blockIdx.x * (K4_T / 64) + w; q < nq; q += nwaves) {
     const uint2 e = a.queue[q];
     const uint32_t hkey = e.y, runid = hkey >> kSymRunShift, k = key_k(hkey);
     uint8_t *ctr = k4_counters(a, hkey);
     uint32_t C = lane < k ? (uint32_t)ctr[lane] : 0u;
     // head fragment: from the run start to the end of its window, replayed directly
-    uint64_t win = (uint64_t)e.x / 64 + 1;
-    (void)k4_replay(a, e.x, win * 64, runid, k, C, cb, lane, ltm);
-    // following windows: histogram walk, one window ahead prefetched
-    uint32_t info = win < nwin ? a.winfo[win] : 0xFFFFFFFFu;
-    uint32_t h = (win < nwin && lane < 32) ? a.histT[win * 32 + lane] : 0u;
-    uint32_t kk = (win < nwin && win * 64 + lane < a.nsym) ? a.keys[win * 64 + lane] : 0xFFFFFFFFu;
-    while (win < nwin && (info >> 7) == runid) {
-      const uint64_t wn = win + 1;
-      const uint32_t info_n = wn < nwin ? a.winfo[wn] : 0xFFFFFFFFu;
-      const uint32_t h_n = (wn < nwin && lane < 32) ? a.histT[wn * 32 + lane] : 0u;
-      const uint32_t kk_n = (wn < nwin && wn * 64 + lane < a.nsym) ? a.keys[wn * 64 + lane] : 0xFFFFFFFFu;
-      const uint32_t f = info & 127u;
-      if (lane < 32) a.stateW[win * 32 + lane] = (uint8_t)C;
-      const uint64_t hm = __ballot(lane < k && C + h >= 0xFFu);
-      if (!hm) {
-        C += h;
-        if (lane == 0) a.haltW[win] = K4_NO_HALVE;
-      } else {
-        // some counter reaches 0xFF inside this window: find the first event that does
-        const bool valid = lane < f;
-        const uint32_t s = kk & 31u;
-        const uint64_t vm = __ballot(valid);
-        uint64_t eq, lt;
-        k4_eq_lt(s, vm, eq, lt);
-        const uint32_t before = __shfl(C, (int)s) + (uint32_t)__popcll(eq & ltm);
-        const uint64_t hit = __ballot(valid && before + 1u == 0xFFu);
-        const uint32_t t = (uint32_t)__ffsll((long long)hit) - 1u;     // hit != 0 by construction
-        const uint64_t cm = (2ull << t) - 1ull;                         // lanes <= t
-        const uint32_t cle = k4_symbol_counts(s, eq, cm, valid && lane <= t, cb, lane);
-        C = ((C + cle) >> 1) + (h - cle);                               // halve (bce.cpp:531-533), then the rest
-        if (lane == 0) a.haltW[win] = (uint8_t)t;
+    uint64_t gbase = (uint64_t)e.x / 64 + 1;
+    (void)k4_replay(a, e.x, gbase * 64, runid, k, C, cb, lane, ltm);
+    // group loads into registers: 16 keys, 2 histogram dwords, 1 info dword per lane
+    uint32_t rk[K4_GW], rh[2], ri;
+    auto load_group = [&](uint64_t g0) {
+#pragma unroll
+      for (uint32_t i = 0; i < K4_GW; ++i) {
+        const uint64_t j = (g0 + i) * 64 + lane;
+        rk[i] = j < a.nsym ? a.keys[j] : 0xFFFFFFFFu;
       }
-      if (f < 64) break;                                                // the run ends inside this window
-      win = wn; info = info_n; h = h_n; kk = kk_n;
+#pragma unroll
+      for (uint32_t r = 0; r < 2; ++r) {                 // K4_GW * 8 dwords = 128 dwords, two per lane
+        const uint64_t d = g0 * 8 + r * 64 + lane;
+        rh[r] = d < nwin * 8 ? hist32[d] : 0u;
+      }
+      ri = (lane < K4_GW && g0 + lane < nwin) ? a.winfo[g0 + lane] : 0xFFFFFFFFu;
+    };
+    load_group(gbase);
+    bool running = true;
+    while (running) {
+      // registers -> LDS (the previous group has been fully consumed)
+#pragma unroll
+      for (uint32_t i = 0; i < K4_GW; ++i) st->keys[i][lane] = rk[i];
+#pragma unroll
+      for (uint32_t r = 0; r < 2; ++r) st->hist[(r * 64 + lane) >> 3][(r * 64 + lane) & 7u] = rh[r];
+      if (lane < K4_GW) st->info[lane] = ri;
+      __builtin_amdgcn_wave_barrier();
+      load_group(gbase + K4_GW);                        // in flight while this group is processed
+      for (uint32_t i = 0; i < K4_GW; ++i) {
+        const uint64_t win = gbase + i;
+        const uint32_t info = st->info[i];
+        if (win >= nwin || (info >> 7) != runid) { running = false; break; }
+        const uint32_t f = info & 127u;
+        // byte `lane` of the window's 32-byte histogram
+        const uint32_t h = lane < 32 ? (st->hist[i][lane >> 2] >> (8u * (lane & 3u))) & 0xFFu : 0u;
+        if (lane < 32) a.stateW[win * 32 + lane] = (uint8_t)C;
+        const uint64_t hm = __ballot(lane < k && C + h >= 0xFFu);
+        if (!hm) {
+          C += h;
+          if (lane == 0) a.haltW[win] = K4_NO_HALVE;
+        } else {
+          // some counter reaches 0xFF inside this window: find the first event that does
+          const bool valid = lane < f;
+          const uint32_t s = st->keys[i][lane] & 31u;
+          const uint64_t vm = __ballot(valid);
+          uint64_t eq, lt;
+          k4_eq_lt(s, vm, eq, lt);
+          const uint32_t before = __shfl(C, (int)s) + (uint32_t)__popcll(eq & ltm);
+          const uint64_t hit = __ballot(valid && before + 1u == 0xFFu);
+          const uint32_t t = (uint32_t)__ffsll((long long)hit) - 1u;     // hit != 0 by construction
+          const uint64_t cm = (2ull << t) - 1ull;                         // lanes <= t
+          const uint32_t cle = k4_symbol_counts(s, eq, cm, valid && lane <= t, cb, lane);
+          C = ((C + cle) >> 1) + (h - cle);                               // halve (bce.cpp:531-533), then the rest
+          if (lane == 0) a.haltW[win] = (uint8_t)t;
+        }
+        if (f < 64) { running = false; break; }                           // the run ends inside this window
+      }
+      __builtin_amdgcn_wave_barrier();
+      gbase += K4_GW;
     }
     if (lane < k) ctr[lane] = (uint8_t)C;
   }
