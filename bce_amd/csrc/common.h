@@ -71,7 +71,7 @@ struct bce_hip_ctx {
 
   // device buffers (grow-only)
   bce::DevBuf text, bwt;                         // n bytes each
-  bce::DevBuf sa[2], key[2], rank, k2, nrk;      // K1: 7 x 4n
+  bce::DevBuf sa[2], key[2], rank, k2, nrk, act[2];   // K1: 9 x 4n (act = active-set lists)
   bce::DevBuf rs_hist, blk;                      // radix histograms [256][nb]; per-block scratch
   bce::DevBuf ptmp[2];                           // K2 byte ping-pong
   bce::DevBuf gran;                              // 8 planes x ngran x 16 B

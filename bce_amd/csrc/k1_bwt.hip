@@ -15,6 +15,10 @@
 //   ranks are "index of the group head", so they only ever refine; stop when every group is a
 //   singleton or h >= n.
 // All passes are coalesced streams over u32 arrays plus two random gathers and one scatter per round.
+#include <stdlib.h>
+
+#include <utility>
+
 #include "common.h"
 #include "scan_util.h"
 
@@ -141,6 +145,113 @@ __global__ __launch_bounds__(K1_T) void k1_offset_kernel(const uint32_t *__restr
   if ((threadIdx.x & 63u) == 0 && best != 0xFFFFFFFFu) atomicMin(out, best);
 }
 
+// ---- active-set rounds -----------------------------------------------------------------------------
+// Once most suffixes sit in singleton groups, only the rest (the ACTIVE list A of SA indices, ascending) is
+// worked on: sort the active suffixes by rank[p+h], then stably by their group (rank[p]), write them back into
+// their SA slots (groups are contiguous in A as in SA), re-rank inside the groups, drop new singletons.
+
+// count (pass 0) / write (pass 1) the elements that stay active.  head(i) = i == 0 || nrk[i] != 0;
+// an element is a singleton iff it is a head and its successor is a head (or it is the last one).
+template <int PASS>
+__global__ __launch_bounds__(K1_T) void k1_active_kernel(const uint32_t *__restrict__ nrk,
+                                                         const uint32_t *__restrict__ src, uint32_t m,
+                                                         uint32_t per_block, uint32_t nb, uint32_t *__restrict__ blockcnt,
+                                                         uint32_t *__restrict__ out, uint32_t *__restrict__ total) {
+  const uint64_t beg = (uint64_t)blockIdx.x * per_block;
+  uint64_t end = beg + per_block;
+  if (end > m) end = m;
+  auto keep = [&](uint64_t i) -> bool {
+    const bool h0 = i == 0 || nrk[i] != 0;
+    const bool h1 = i + 1 >= m || nrk[i + 1] != 0;
+    return !(h0 && h1);
+  };
+  if (PASS == 0) {
+    uint32_t c = 0;
+    for (uint64_t i = beg + threadIdx.x; i < end; i += K1_T) c += keep(i) ? 1u : 0u;
+    c = block_reduce_sum<K1_T>(c);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = c;
+  } else {
+    uint32_t b = 0, a = 0;
+    for (uint32_t k = threadIdx.x; k < nb; k += K1_T) { const uint32_t v = blockcnt[k]; a += v; if (k < blockIdx.x) b += v; }
+    uint32_t base = block_reduce_sum<K1_T>(b);
+    const uint32_t all = block_reduce_sum<K1_T>(a);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *total = all;
+    for (uint64_t c0 = beg; c0 < end; c0 += K1_T) {
+      const uint64_t i = c0 + threadIdx.x;
+      const bool k = i < end && keep(i);
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan_sum<K1_T>(k ? 1u : 0u, &tot);
+      if (k) out[base + ex] = src ? src[i] : (uint32_t)i;
+      base += tot;
+    }
+  }
+}
+
+// keys[i] = rank[SA[A[i]] + h], vals[i] = SA[A[i]]
+__global__ __launch_bounds__(K1_T) void k1_act_gather_kernel(const uint32_t *__restrict__ A, const uint32_t *__restrict__ sa,
+                                                             const uint32_t *__restrict__ rank, uint32_t n, uint32_t m,
+                                                             uint32_t h, uint32_t *__restrict__ keys,
+                                                             uint32_t *__restrict__ vals) {
+  for (uint64_t i = (uint64_t)blockIdx.x * K1_T + threadIdx.x; i < m; i += (uint64_t)gridDim.x * K1_T) {
+    const uint32_t p = sa[A[i]];
+    const uint64_t q = (uint64_t)p + h;
+    vals[i] = p;
+    keys[i] = rank[q >= n ? q - n : q];
+  }
+}
+// keys[i] = rank[vals[i]]  (the group of each active suffix)
+__global__ __launch_bounds__(K1_T) void k1_act_group_kernel(const uint32_t *__restrict__ vals,
+                                                            const uint32_t *__restrict__ rank, uint32_t m,
+                                                            uint32_t *__restrict__ keys) {
+  for (uint64_t i = (uint64_t)blockIdx.x * K1_T + threadIdx.x; i < m; i += (uint64_t)gridDim.x * K1_T)
+    keys[i] = rank[vals[i]];
+}
+// write the sorted suffixes back to their SA slots; nrk[i] = A[i] where a new group starts (else 0);
+// k2 = rank[p+h] is gathered again here (the second sort carried only the group key)
+__global__ __launch_bounds__(K1_T) void k1_act_heads_kernel(const uint32_t *__restrict__ A, const uint32_t *__restrict__ vals,
+                                                            const uint32_t *__restrict__ k1s,
+                                                            const uint32_t *__restrict__ rank, uint32_t n, uint32_t m,
+                                                            uint32_t h, uint32_t per_block, uint32_t *__restrict__ sa,
+                                                            uint32_t *__restrict__ nrk, uint32_t *__restrict__ blockmax) {
+  const uint64_t beg = (uint64_t)blockIdx.x * per_block;
+  uint64_t end = beg + per_block;
+  if (end > m) end = m;
+  uint32_t mx = 0;
+  auto key2 = [&](uint64_t i) -> uint32_t { const uint64_t q = (uint64_t)vals[i] + h; return rank[q >= n ? q - n : q]; };
+  for (uint64_t i = beg + threadIdx.x; i < end; i += K1_T) {
+    const uint32_t slot = A[i];
+    sa[slot] = vals[i];
+    bool head = i == 0 || k1s[i] != k1s[i - 1];
+    if (!head) head = key2(i) != key2(i - 1);
+    nrk[i] = head ? slot : 0u;
+    if (head) mx = slot;
+  }
+  mx = block_reduce_max<K1_T>(mx);
+  if (threadIdx.x == 0) blockmax[blockIdx.x] = mx;
+}
+// rank[vals[i]] = running max of nrk (= SA index of the group head)
+__global__ __launch_bounds__(K1_T) void k1_act_apply_kernel(const uint32_t *__restrict__ nrk,
+                                                            const uint32_t *__restrict__ blockmax, uint32_t m,
+                                                            uint32_t per_block, const uint32_t *__restrict__ vals,
+                                                            uint32_t *__restrict__ rank) {
+  uint32_t c = 0;
+  for (uint32_t b = threadIdx.x; b < blockIdx.x; b += K1_T) { const uint32_t v = blockmax[b]; c = c > v ? c : v; }
+  uint32_t carry = block_reduce_max<K1_T>(c);
+  const uint64_t beg = (uint64_t)blockIdx.x * per_block;
+  uint64_t end = beg + per_block;
+  if (end > m) end = m;
+  for (uint64_t base = beg; base < end; base += K1_T) {
+    const uint64_t i = base + threadIdx.x;
+    const bool valid = i < end;
+    const uint32_t v = valid ? nrk[i] : 0u;
+    uint32_t tot;
+    uint32_t inc = block_incl_scan_max<K1_T>(v, &tot);
+    inc = inc > carry ? inc : carry;
+    if (valid) rank[vals[i]] = inc;
+    carry = carry > tot ? carry : tot;
+  }
+}
+
 static uint32_t grid_for(uint32_t n) {
   uint64_t b = ((uint64_t)n + K1_T - 1) / K1_T;
   return (uint32_t)(b < 4096 ? (b ? b : 1) : 4096);
@@ -163,6 +274,7 @@ int k1_bwt(bce_hip_ctx *c) {
   BCE_TRY(ensure(c, c->rank, b4));
   BCE_TRY(ensure(c, c->k2, b4));
   BCE_TRY(ensure(c, c->nrk, b4));
+  for (int i = 0; i < 2; ++i) BCE_TRY(ensure(c, c->act[i], b4));
   const K1Plan pl = k1_plan(n);
   BCE_TRY(ensure(c, c->blk, (size_t)(pl.nb + 16) * 4));
   uint32_t *blockmax = c->blk.as<uint32_t>();
@@ -189,7 +301,58 @@ int k1_bwt(bce_hip_ctx *c) {
   BCE_TRY(rerank(key[res], nullptr, val[res]));
   const uint32_t bits = ceil_log2(n);
   uint64_t h = 4;
+  uint32_t *act[2] = {c->act[0].as<uint32_t>(), c->act[1].as<uint32_t>()};
+  uint32_t m = n;                 // active elements; the list is implicit (identity) while every element is active
+  bool have_list = false;
+  // active elements after a re-rank: not (head && next is head)
+  auto build_active = [&](const uint32_t *nrk_in, const uint32_t *src, uint32_t cnt, uint32_t *out) -> int {
+    const K1Plan ap = k1_plan(cnt);
+    hipLaunchKernelGGL(k1_active_kernel<0>, dim3(ap.nb), dim3(K1_T), 0, c->stream, nrk_in, src, cnt, ap.per_block, ap.nb,
+                       blockmax, out, scalars + 2);
+    hipLaunchKernelGGL(k1_active_kernel<1>, dim3(ap.nb), dim3(K1_T), 0, c->stream, nrk_in, src, cnt, ap.per_block, ap.nb,
+                       blockmax, out, scalars + 2);
+    BCE_HIP_TRY(c, hipMemcpyAsync(&m, scalars + 2, 4, hipMemcpyDeviceToHost, c->stream));
+    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return BCE_HIP_OK;
+  };
+  static const bool use_active = getenv("BCE_HIP_K1_FULL") == nullptr;
   while (groups < n && h < n) {
+    if (use_active && !have_list && (uint64_t)(n - groups) * 5 < (uint64_t)n * 2 + 5) {
+      // few elements can still be in non-singleton groups (at most 2 per missing group... bound: n - groups < 0.4 n
+      // means at most 0.8 n active): build the explicit list and check its real size
+      BCE_TRY(build_active(nrk, nullptr, n, act[0]));
+      have_list = true;
+      if (m == 0) break;
+    }
+    if (have_list && (uint64_t)m * 5 < (uint64_t)n * 2) {
+      // ---- active round on m elements ----
+      const uint32_t *A = act[0];
+      uint32_t *ki[2] = {key[0], key[1]};
+      uint32_t *vi[2] = {val[res ^ 1], k2};
+      const uint32_t ga = grid_for(m);
+      hipLaunchKernelGGL(k1_act_gather_kernel, dim3(ga), dim3(K1_T), 0, c->stream, A, val[res], rank, n, m, (uint32_t)h,
+                         ki[0], vi[0]);
+      int r1 = 0;
+      BCE_TRY(radix_sort_pairs(c, ki, vi, m, 0, bits, &r1, 9));
+      // second sort: by group, input = output of the first
+      uint32_t *kj[2] = {ki[r1 ^ 1], ki[r1]};
+      uint32_t *vj[2] = {vi[r1], vi[r1 ^ 1]};
+      hipLaunchKernelGGL(k1_act_group_kernel, dim3(ga), dim3(K1_T), 0, c->stream, vj[0], rank, m, kj[0]);
+      int r2 = 0;
+      BCE_TRY(radix_sort_pairs(c, kj, vj, m, 0, bits, &r2, 9));
+      const K1Plan ap = k1_plan(m);
+      hipLaunchKernelGGL(k1_act_heads_kernel, dim3(ap.nb), dim3(K1_T), 0, c->stream, A, vj[r2], kj[r2], rank, n, m,
+                         (uint32_t)h, ap.per_block, val[res], nrk, blockmax);
+      hipLaunchKernelGGL(k1_act_apply_kernel, dim3(ap.nb), dim3(K1_T), 0, c->stream, nrk, blockmax, m, ap.per_block,
+                         vj[r2], rank);
+      BCE_TRY(build_active(nrk, A, m, act[1]));
+      std::swap(act[0], act[1]);
+      h <<= 1;
+      c->stats.sort_rounds++;
+      if (m == 0) break;
+      continue;
+    }
+    // ---- full round on all n elements ----
     // input of the sort goes to slot 0 of a local ping-pong so the result index is well defined
     uint32_t *ki[2] = {key[res ^ 1], key[res]};
     uint32_t *vi[2] = {val[res ^ 1], val[res]};
@@ -204,6 +367,7 @@ int k1_bwt(bce_hip_ctx *c) {
     res = (ssa == val[0]) ? 0 : 1;
     h <<= 1;
     c->stats.sort_rounds++;
+    have_list = false;
   }
   BCE_HIP_TRY(c, hipMemsetAsync(scalars + 1, 0xFF, 4, c->stream));
   hipLaunchKernelGGL(k1_bwt_kernel, dim3(g), dim3(K1_T), 0, c->stream, T, val[res], n, bwt);
