@@ -58,53 +58,63 @@ void HostCoder::begin(const uint8_t config[9][32], const uint32_t C[8], uint32_t
   }
 }
 
-// Exact floor(x / d) for 64-bit x by multiplication (Granlund-Montgomery round-up method, N = 64):
-//   l = ceil(log2 d), m = floor(2^64 (2^l - d) / d) + 1, t = mulhi(m, x), q = (t + ((x - t) >> 1)) >> (l - 1)
-// valid for every x and 2 <= d < 2^63.  The model totals are < 8192 (k <= 31 counters <= 254, + k), so a
-// table indexed by the divisor replaces the 64-bit divide that sits on the coder's dependency chain
-// (step = (h - l) / total, bce.cpp:527); the quotient is bit-identical.
+// Exact floor(x / d) for 64-bit x by ONE multiplication (divisor-invariant division, N = 64).
+// With L = floor(log2 d), s = 64 + L, m_dn = floor(2^s / d), e' = 2^s - m_dn d, e = d - e':
+//   * e  <= 2^L : q = mulhi(m_dn + 1, x)     >> L   is exact for every x < 2^64            (round-up magic)
+//   * e' <= 2^L : q = mulhi(m_dn,     x + 1) >> L   is exact for every x < 2^64 - 1        (round-down magic)
+// e + e' = d <= 2^(L+1), so one of the two always applies.  (Error terms: m (x+a) / 2^s = (x+a)/d (1 +- e/2^s);
+// at x = kd + d - 1 resp. x = kd the deviation stays below 1/d.)  Powers of two use m = 2^(64-L), shift 0.
+// The model totals are < 8192 (k <= 31 counters <= 254, + k), so a table indexed by the divisor replaces the
+// 64-bit divide on the coder's dependency chain (step = (h - l) / total, bce.cpp:527); the quotient is
+// bit-identical.  x = 2^64 - 1 (right after a range reset) and larger divisors take the real divide.
 namespace {
-struct Recip { uint64_t m; uint32_t sh; };
+struct Recip { uint64_t m; uint32_t add; uint32_t sh; };
 constexpr uint32_t kRecipMax = 8192;
 const Recip *recip_table() {
   static const std::vector<Recip> tab = [] {
     std::vector<Recip> t(kRecipMax);
-    t[0] = t[1] = Recip{0, 0};
+    t[0] = t[1] = Recip{0, 0, 0};
     for (uint32_t d = 2; d < kRecipMax; ++d) {
-      uint32_t l = 0;
-      while ((1ull << l) < d) ++l;
-      const unsigned __int128 num = (unsigned __int128)((1ull << l) - d) << 64;
-      t[d] = Recip{(uint64_t)(num / d) + 1, l - 1};
+      uint32_t L = 0;
+      while ((2ull << L) <= d) ++L;                       // floor(log2 d)
+      if ((d & (d - 1)) == 0) { t[d] = Recip{1ull << (64 - L), 0, 0}; continue; }
+      const unsigned __int128 two_s = (unsigned __int128)1 << (64 + L);
+      const uint64_t m_dn = (uint64_t)(two_s / d);
+      const uint64_t e_dn = (uint64_t)(two_s - (unsigned __int128)m_dn * d);   // e'
+      const uint64_t e_up = d - e_dn;                                           // e
+      if (e_up <= (1ull << L)) t[d] = Recip{m_dn + 1, 0, L};
+      else t[d] = Recip{m_dn, 1, L};
     }
     return t;
   }();
   return tab.data();
 }
-inline uint64_t div_recip(uint64_t x, const Recip &r) {
-  const uint64_t t = (uint64_t)(((unsigned __int128)r.m * x) >> 64);
-  return (t + ((x - t) >> 1)) >> r.sh;
+inline uint64_t div_recip(uint64_t x, const Recip &r) {   // requires x != 2^64 - 1
+  return (uint64_t)(((unsigned __int128)r.m * (x + r.add)) >> 64) >> r.sh;
 }
 }  // namespace
 
-uint64_t bce_test_div_recip(uint64_t x, uint32_t d) { return div_recip(x, recip_table()[d]); }
+uint64_t bce_test_div_recip(uint64_t x, uint32_t d) {
+  return x == ~0ull ? x / d : div_recip(x, recip_table()[d]);
+}
 
-// Same arithmetic as encode() (bce.cpp:520-529 + shift_out :655-661), with l/h in locals and the
-// divide done by reciprocal multiplication.
+// Same arithmetic as encode() (bce.cpp:520-529 + shift_out :655-661) on the pair (l, r = h - l): the next
+// range r' = step * freq - 1 then depends on r alone, and l accumulates off the critical chain.
 void RangeCoder::encode_run(const uint64_t *out, const uint32_t *esc, uint64_t begin, uint64_t end) {
   const Recip *rt = recip_table();
-  uint64_t l = l_, h = h_;
+  uint64_t l = l_, r = h_ - l_;
   auto step1 = [&](uint32_t cum, uint32_t freq, uint32_t total) {
-    if (__builtin_expect(h - l < total, 0)) {
+    if (__builtin_expect(r < total, 0)) {               // :520-525
       for (int i = 0; i < 4; ++i) data_.push_back((uint16_t)(l >> (48 - 16 * i)));
-      l = 0; h = ~0ull;
+      l = 0; r = ~0ull;
     }
-    const uint64_t step = total < kRecipMax ? div_recip(h - l, rt[total]) : (h - l) / total;
-    l += step * cum;
-    h = l + step * freq - 1;
-    while (__builtin_expect(!((h ^ l) >> 48), 0)) {
-      data_.push_back((uint16_t)(h >> 48));
-      l = (l << 16) + 0x0000;
-      h = (h << 16) + 0xFFFF;
+    const uint64_t step = (__builtin_expect(r == ~0ull, 0) || total >= kRecipMax) ? r / total : div_recip(r, rt[total]);
+    l += step * cum;                                    // :528
+    r = step * freq - 1;                                // h = l + step*freq - 1  (:529)
+    while (__builtin_expect(!(((l + r) ^ l) >> 48), 0)) {   // shift_out :655-661
+      data_.push_back((uint16_t)((l + r) >> 48));
+      l <<= 16;
+      r = (r << 16) | 0xFFFF;
     }
   };
   for (uint64_t i = begin; i < end; ++i) {
@@ -114,7 +124,7 @@ void RangeCoder::encode_run(const uint64_t *out, const uint32_t *esc, uint64_t b
       for (uint32_t nesc = bits >> 27; nesc; --nesc, bits >>= 1) step1(bits & 1, 1, 2);
     step1((uint32_t)(o & 0xFFFF), (uint32_t)((o >> 16) & 0xFFFF), (uint32_t)((o >> 32) & 0xFFFF));
   }
-  l_ = l; h_ = h;
+  l_ = l; h_ = l + r;
 }
 
 void HostCoder::consume(int p, const SymRun *runs, size_t nruns, const uint64_t *out, const uint32_t *esc) {
