@@ -32,6 +32,9 @@
 // Counter state persists in HBM between flushes, so flushes can be arbitrarily small.
 #include <stdlib.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 
 namespace bce {
@@ -50,6 +53,7 @@ struct K4Args {
   uint8_t *stateW;               // [nwin][32] counters at the window start (long runs)
   uint32_t *winfo;               // [nwin] runid<<7 | length of the leading fragment
   uint8_t *haltW;                // [nwin]
+  unsigned long long *bitsW;     // [nwin] bit i = low symbol bit of record i of the leading fragment (k = 2 runs)
   uint2 *queue;                  // long runs: {start, key word of the first record}
   uint32_t *qcount;
   uint32_t stat_off[8];
@@ -163,9 +167,11 @@ __global__ __launch_bounds__(K4_T) void k4_window_kernel(K4Args a) {
     k4_eq_lt(s, leadm, eq, lt);
     const uint32_t h = k4_symbol_counts(s, eq, leadm, lead, cb, lane);
     if (lane < 32) a.histT[win * 32 + lane] = (uint8_t)h;
+    const uint64_t b1 = __ballot(lead && (key & 1u));
     if (lane == 0) {
       a.winfo[win] = (r0 << 7) | (uint32_t)__popcll(leadm);
       a.haltW[win] = K4_NOT_LONG;
+      a.bitsW[win] = b1;
     }
     while (heads) {                                         // runs that START in this window
       const int hl = __ffsll((long long)heads) - 1;
@@ -220,6 +226,58 @@ __global__ __launch_bounds__(K4_T) void k4_long_kernel(K4Args a) {
     // head fragment: from the run start to the end of its window, replayed directly
     uint64_t gbase = (uint64_t)e.x / 64 + 1;
     (void)k4_replay(a, e.x, gbase * 64, runid, k, C, cb, lane, ltm);
+    if (k == 2) {
+      // ---- binary slots (every really long run is one): the window's symbols are a 64-bit mask, so the walk
+      // is wave-uniform mask arithmetic -- counts are popcounts, the halving position is "the n-th zero or the
+      // n-th one", found with mbcnt + one ballot.  64 windows' masks/infos are fetched per coalesced load.
+      uint32_t c0 = __shfl(C, 0), c1 = __shfl(C, 1);
+      uint64_t gb = gbase;
+      unsigned long long nbits = gb + lane < nwin ? a.bitsW[gb + lane] : 0ull;
+      uint32_t ninfo = gb + lane < nwin ? a.winfo[gb + lane] : 0xFFFFFFFFu;
+      bool running = true;
+      while (running) {
+        const unsigned long long cbits = nbits;
+        const uint32_t cinfo = ninfo;
+        const uint64_t g2 = gb + 64;
+        nbits = g2 + lane < nwin ? a.bitsW[g2 + lane] : 0ull;        // next group in flight
+        ninfo = g2 + lane < nwin ? a.winfo[g2 + lane] : 0xFFFFFFFFu;
+        uint32_t my_state = 0, my_halt = K4_NOT_LONG;
+        bool mine = false;
+        for (int i = 0; i < 64; ++i) {
+          const uint32_t info = __shfl(cinfo, i);
+          if ((info >> 7) != runid) { running = false; break; }      // also ends at nwin (info = ~0)
+          const uint32_t f = info & 127u;
+          const unsigned long long fm = f >= 64 ? ~0ull : ((1ull << f) - 1ull);
+          const unsigned long long B = (unsigned long long)__shfl((long long)cbits, i) & fm;
+          const uint32_t h1 = (uint32_t)__popcll(B), h0 = f - h1;
+          const uint32_t s0 = c0, s1 = c1;
+          uint32_t halt = K4_NO_HALVE;
+          if (c0 + h0 >= 0xFFu || c1 + h1 >= 0xFFu) {
+            const uint32_t pb = __builtin_amdgcn_mbcnt_hi((uint32_t)(B >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B, 0u));
+            const bool bit = (B >> lane) & 1ull;
+            const bool hit = lane < f && (bit ? (c1 + pb + 1u == 0xFFu) : (c0 + (lane - pb) + 1u == 0xFFu));
+            const uint64_t hm = __ballot(hit);
+            const uint32_t t = (uint32_t)__ffsll((long long)hm) - 1u;
+            const unsigned long long le = (2ull << t) - 1ull;
+            const uint32_t cle1 = (uint32_t)__popcll(B & le), cle0 = t + 1u - cle1;
+            c0 = ((c0 + cle0) >> 1) + (h0 - cle0);                    // halve (bce.cpp:531-533), then the rest
+            c1 = ((c1 + cle1) >> 1) + (h1 - cle1);
+            halt = t;
+          } else {
+            c0 += h0; c1 += h1;
+          }
+          if (lane == (uint32_t)i) { my_state = s0 | (s1 << 8); my_halt = halt; mine = true; }
+          if (f < 64) { running = false; break; }                     // the run ends inside this window
+        }
+        if (mine) {
+          *reinterpret_cast<uint16_t *>(a.stateW + (gb + lane) * 32) = (uint16_t)my_state;
+          a.haltW[gb + lane] = (uint8_t)my_halt;
+        }
+        gb += 64;
+      }
+      if (lane == 0) { ctr[0] = (uint8_t)c0; ctr[1] = (uint8_t)c1; }
+      continue;
+    }
     // group loads into registers: 16 keys, 2 histogram dwords, 1 info dword per lane
     uint32_t rk[K4_GW], rh[2], ri;
     auto load_group = [&](uint64_t g0) {
@@ -293,8 +351,9 @@ __global__ __launch_bounds__(K4_T) void k4_emit_kernel(K4Args a) {
     if (a.haltW[win] == K4_NOT_LONG) continue;
     const uint32_t info = a.winfo[win];
     const uint32_t hkey = a.keys[win * 64];
-    uint32_t C = lane < 32 ? (uint32_t)a.stateW[win * 32 + lane] : 0u;
-    (void)k4_replay(a, win * 64, win * 64 + (info & 127u), info >> 7, key_k(hkey), C, cb, lane, ltm);
+    const uint32_t k = key_k(hkey);
+    uint32_t C = lane < k ? (uint32_t)a.stateW[win * 32 + lane] : 0u;    // (the k = 2 walk records two bytes only)
+    (void)k4_replay(a, win * 64, win * 64 + (info & 127u), info >> 7, k, C, cb, lane, ltm);
   }
 }
 
@@ -348,9 +407,28 @@ int k4_flush(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   const size_t nwin = ((size_t)nsym + 63) / 64;
   auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
   const size_t o_hist = 0, o_state = o_hist + nwin * 32, o_info = o_state + nwin * 32,
-               o_queue = up16(o_info + nwin * 4), o_halt = o_queue + (nwin / 4 + 2) * 8, o_qc = up16(o_halt + nwin);
+               o_queue = up16(o_info + nwin * 4), o_halt = o_queue + (nwin / 4 + 2) * 8, o_bits = up16(o_halt + nwin),
+               o_qc = up16(o_bits + nwin * 8);
   BCE_TRY(ensure(c, c->k4w, o_qc + 16));
   uint8_t *wbuf = c->k4w.as<uint8_t>();
+  if (getenv("BCE_HIP_DEBUG_RUNS")) {      // diagnostic: longest slot runs of this flush
+    std::vector<uint32_t> hk(nsym);
+    BCE_HIP_TRY(c, hipMemcpy(hk.data(), key[res], b4, hipMemcpyDeviceToHost));
+    std::vector<std::pair<uint32_t, uint32_t>> runs;   // (length, key)
+    uint64_t longsum = 0;
+    for (uint32_t i = 0; i < nsym;) {
+      uint32_t j = i;
+      while (j < nsym && (hk[j] >> kSymRunShift) == (hk[i] >> kSymRunShift)) ++j;
+      runs.push_back({j - i, hk[i]});
+      if (j - i >= K4_LONG) longsum += j - i;
+      i = j;
+    }
+    std::sort(runs.begin(), runs.end(), [](auto &x, auto &y) { return x.first > y.first; });
+    fprintf(stderr, "[bce] flush %u syms, %zu runs, %llu syms in long runs; top:", nsym, runs.size(), (unsigned long long)longsum);
+    for (size_t r = 0; r < runs.size() && r < 8; ++r)
+      fprintf(stderr, " %u(k=%u,p=%u)", runs[r].first, key_k(runs[r].second), key_plane(runs[r].second));
+    fprintf(stderr, "\n");
+  }
   K4Args a;
   a.keys = key[res]; a.vals = val[res];
   a.stat = c->stat.as<uint8_t>();
@@ -360,6 +438,7 @@ int k4_flush(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   a.winfo = reinterpret_cast<uint32_t *>(wbuf + o_info);
   a.queue = reinterpret_cast<uint2 *>(wbuf + o_queue);
   a.haltW = wbuf + o_halt;
+  a.bitsW = reinterpret_cast<unsigned long long *>(wbuf + o_bits);
   a.qcount = reinterpret_cast<uint32_t *>(wbuf + o_qc);
   for (int p = 0; p < 8; ++p) a.stat_off[p] = c->stat_off[p];
   a.nsym = nsym;
