@@ -123,10 +123,17 @@ def main():
         st = sts[-1]
         k3_s = sum(s["k3_ms"] for s in sts) / len(sts) / 1e3
         alg_bytes = 384.0 * n + 16.0 * st["symbols"]     # 48 B/node x 8n nodes + 16 B/symbol
-        roof = {"bound": "hbm", "kernel": "K3 interval-count (k3_tiles_kernel<count> + k3_scan_kernel + k3_tiles_kernel<write>, all rounds of one compression)",
+        traffic = None    # HBM bytes from PMC counters: measured offline (rocprofv3 --pmc passes), see profiles/
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_k3_traffic.json")))
+            if tj["bytes_per_gpu"] == n and not args.file and args.workload == "synth-text":
+                traffic = tj["traffic_bytes_corrected"]
+        except Exception:
+            pass
+        roof = {"bound": "hbm", "kernel": "K3 interval-count (k3_round_kernel + k3_finalize_kernel + k3_tail_kernel, all rounds of one compression = one launch unit)",
                 "achieved": round(alg_bytes / k3_s / 1e9, 2) if k3_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(alg_bytes / k3_s / 1e9 / HBM_PEAK_GBS, 5) if k3_s > 0 else None,
-                "traffic": None, "algorithmic_bytes": alg_bytes, "k3_ms_per_step": round(k3_s * 1e3, 3),
+                "traffic": traffic, "algorithmic_bytes": alg_bytes, "k3_ms_per_step": round(k3_s * 1e3, 3),
                 "k3_launches_per_step": st["k3_launches"]}
         out = {
             "metric": "MB/s compressed", "value": round(n_gpus * n * steps / dt / 1e6, 3), "unit": "MB/s",
