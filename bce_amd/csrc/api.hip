@@ -89,7 +89,7 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   DevBuf *bufs[] = {&c->text, &c->bwt, &c->sa[0], &c->sa[1], &c->key[0], &c->key[1], &c->rank, &c->k2, &c->nrk, &c->act[0], &c->act[1],
                     &c->rs_hist, &c->blk, &c->ptmp[0], &c->ptmp[1], &c->gran, &c->nodes, &c->ctl, &c->tilecnt,
-                    &c->tileoff, &c->runs, &c->desc, &c->truns, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
+                    &c->tileoff, &c->runs, &c->truns, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
                     &c->sesc, &c->stat, &c->dcfg, &c->k4w};
   for (DevBuf *b : bufs) release(*b);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);

@@ -121,6 +121,37 @@ BCE_HD void node_post(const Node &nd, uint32_t zeros_p, const NodePre &pr, uint3
   if (n1x0 && n1x1) { o.has1 = 1; o.c1.s = zeros_p + s1; o.c1.x0 = n1x0; o.c1.x1 = n1x1; }
 }
 
+// Branch-free form of the same node body for the kernels.  The two pass-through cases of the reference
+// (bce.cpp:1274-1287) are special cases of the general formulas: with _1x == 0, min = max = x0 forces
+// _0x0 = x0 and the "1" child vanishes; with _0x == 0, min = max = 0 forces _0x0 = 0 and the "0" child
+// vanishes.  So: need_mid = (max != min) says whether rank1(s + x0) is needed at all, and node_flat
+// produces children and the coder arguments with one select.
+struct NodeFlat {
+  uint32_t s1, s0, n1x, n0x, mn, mx;
+  uint32_t need_mid;
+};
+BCE_HD void node_flat_pre(const Node &nd, uint32_t r_s, uint32_t r_e, NodeFlat &f) {
+  const uint32_t x = nd.x0 + nd.x1;
+  f.s1 = r_s; f.s0 = nd.s - r_s;
+  f.n1x = r_e - r_s; f.n0x = x - f.n1x;
+  const int32_t a = (int32_t)(nd.x0 - f.n1x), b = (int32_t)(f.n1x - nd.x1);
+  f.mn = a < 0 ? 0u : (uint32_t)a;
+  f.mx = nd.x0 - (b < 0 ? 0u : (uint32_t)b);
+  f.need_mid = f.mx != f.mn;
+}
+// r_m = rank1(s + x0) (ignored unless need_mid).  Children: has0/has1 + (s, x0, x1); symbol args when need_mid.
+BCE_HD void node_flat_post(const Node &nd, uint32_t zeros_p, const NodeFlat &f, uint32_t r_m, uint32_t &has0,
+                           Node &c0, uint32_t &has1, Node &c1, uint32_t &sym, uint32_t &k) {
+  const uint32_t n0x0 = f.need_mid ? (nd.s + nd.x0 - r_m) - f.s0 : f.mn;   // rank0(s + x0) - s0   (:1301)
+  const uint32_t n0x1 = f.n0x - n0x0;                                       // :1337
+  const uint32_t n1x1 = nd.x1 - n0x1, n1x0 = f.n1x - n1x1;                  // :1343-1344
+  has0 = (n0x0 != 0u) & (n0x1 != 0u);
+  has1 = (n1x0 != 0u) & (n1x1 != 0u);
+  c0.s = f.s0; c0.x0 = n0x0; c0.x1 = n0x1;
+  c1.s = zeros_p + f.s1; c1.x0 = n1x0; c1.x1 = n1x1;
+  sym = n0x0 - f.mn; k = f.mx - f.mn + 1u;                                  // :1302
+}
+
 // rank1(pos) is supplied by the caller.  The sequential form used by the CPU unit tests.
 template <class Rank1>
 BCE_HD void node_step(const Node &nd, uint32_t zeros_p, Rank1 rank1, StepOut &o) {

@@ -35,10 +35,10 @@ struct EnumCtl {
   uint32_t next_nodes;       // node total of the next round (after the last executed round)
   uint32_t pad;
   uint64_t want_syms;        // symbol records of the skipped round (to grow the buffer when one round exceeds it)
-  // single-pass rounds (k3_round_kernel): work-queue ticket and per-plane inclusive totals of the round
-  uint32_t ticket;
-  uint32_t lookback_fail;    // a look-back spin gave up (internal error; never expected)
-  uint32_t ptot[8][3];       // written by each plane's last tile: child0 total, child1 total, symbols up to the end of the plane
+  uint32_t ticket;           // k3_scan_kernel: arrival counter of its 8 plane blocks (last one runs the epilogue)
+  uint32_t lookback_fail;    // (unused; kept for layout stability)
+  uint32_t ptot[8][3];       // per plane totals of the round: child0, child1, symbols
+  uint64_t symbase[8];       // symbol-buffer base of each plane's records in this round
   uint32_t tail_rounds;      // rounds executed by the last k3_tail_kernel launch
   uint32_t pad2;
 };
@@ -78,7 +78,7 @@ struct bce_hip_ctx {
   uint32_t ngran = 0;                            // granules per plane
   bce::DevBuf nodes;                             // 2 parities x 8 planes x capP nodes
   uint32_t capP = 0;
-  bce::DevBuf ctl, tilecnt, tileoff, runs, desc; // K3 control; desc = look-back descriptors [tiles][3]
+  bce::DevBuf ctl, tilecnt, tileoff, runs;       // K3 control
   bce::DevBuf truns;                             // run table of the persistent tail kernel [K3_TAIL_MAXROUNDS][8]
   void *h_truns = nullptr;
   bce::DevBuf skey[2], sval[2], sout, sesc;       // K3->K4: symbol keys (skey[0]) + escape words (sesc); sort ping-pong; outputs

@@ -38,7 +38,6 @@ struct K3Args {
   uint32_t *tilecnt;      // [tiles][4]
   uint32_t *tileoff;      // [tiles][4]
   RunEntry *runs;         // [K3_MAXBATCH][8]
-  unsigned long long *desc;   // look-back descriptors [tiles][3]
   uint32_t capP, ngran, n;
   uint32_t zeros[8];
   uint32_t par, round, run_slot;
@@ -71,6 +70,7 @@ struct TileOut {
   uint32_t kw[K3_NPT], ew[K3_NPT];
 };
 
+template <bool PACK>
 __device__ __forceinline__ void k3_classify(const K3Args &a, uint32_t p, uint32_t tile_in_plane, TileOut &t) {
   const uint32_t tid = threadIdx.x;
   const uint32_t c0n = a.ctl->cnt[a.par][p][0], c1n = a.ctl->cnt[a.par][p][1];
@@ -80,45 +80,44 @@ __device__ __forceinline__ void k3_classify(const K3Args &a, uint32_t p, uint32_
   const uint32_t zp = a.zeros[p];
   const PlaneCfg &cfg = a.cfg[p];
   Node nd[K3_NPT];
-  bool valid[K3_NPT];
+  uint32_t valid[K3_NPT];
 #pragma unroll
   for (int it = 0; it < K3_NPT; ++it) {
     const uint32_t q = tile_in_plane * K3_TILE + (uint32_t)it * K3_T + tid;
-    valid[it] = q < M;
-    nd[it] = Node{0u, 1u, 1u};
-    if (valid[it]) nd[it] = src[q < c0n ? q : (a.capP - 1u - (q - c0n))];
+    valid[it] = q < M ? 1u : 0u;
+    // out-of-range lanes re-read the tile's first node (always valid when the tile exists); their results are masked
+    const uint32_t qq = valid[it] ? q : tile_in_plane * K3_TILE;
+    nd[it] = src[qq < c0n ? qq : (a.capP - 1u - (qq - c0n))];
   }
   uint32_t ga[K3_NPT], gb[K3_NPT], gm[K3_NPT];
   Granule qa[K3_NPT], qb[K3_NPT], qm[K3_NPT];
 #pragma unroll
-  for (int it = 0; it < K3_NPT; ++it) {          // invalid lanes read granule 0 (always present): harmless
+  for (int it = 0; it < K3_NPT; ++it) {
     ga[it] = div96(nd[it].s);
     gb[it] = div96(nd[it].s + nd[it].x0 + nd[it].x1);
     gm[it] = div96(nd[it].s + nd[it].x0);
-    qa[it] = G[valid[it] ? ga[it] : 0u];
-    qb[it] = G[valid[it] ? gb[it] : 0u];
+    qa[it] = G[ga[it]];
+    qb[it] = G[gb[it]];
   }
-  NodePre pr[K3_NPT];
+  NodeFlat nf[K3_NPT];
 #pragma unroll
   for (int it = 0; it < K3_NPT; ++it) {
     const uint32_t rs = granule_rank1(qa[it], nd[it].s - ga[it] * 96u);
     const uint32_t re = granule_rank1(qb[it], nd[it].s + nd[it].x0 + nd[it].x1 - gb[it] * 96u);
-    node_pre(nd[it], rs, re, pr[it]);
+    node_flat_pre(nd[it], rs, re, nf[it]);
     qm[it] = gm[it] == ga[it] ? qa[it] : qb[it];
-    if (valid[it] && pr[it].kind == 3u && gm[it] != ga[it] && gm[it] != gb[it]) qm[it] = G[gm[it]];
+    if (nf[it].need_mid && gm[it] != ga[it] && gm[it] != gb[it]) qm[it] = G[gm[it]];
   }
 #pragma unroll
   for (int it = 0; it < K3_NPT; ++it) {
-    StepOut so;
-    so.has0 = so.has1 = so.hassym = 0;
-    if (valid[it]) {
-      const uint32_t rm = granule_rank1(qm[it], nd[it].s + nd[it].x0 - gm[it] * 96u);
-      node_post(nd[it], zp, pr[it], rm, so);
-    }
-    t.has0[it] = so.has0; t.has1[it] = so.has1; t.hassym[it] = so.hassym;
-    t.c0[it] = so.c0; t.c1[it] = so.c1;
+    const uint32_t rm = granule_rank1(qm[it], nd[it].s + nd[it].x0 - gm[it] * 96u);
+    uint32_t sym, k;
+    node_flat_post(nd[it], zp, nf[it], rm, t.has0[it], t.c0[it], t.has1[it], t.c1[it], sym, k);
+    t.has0[it] &= valid[it];
+    t.has1[it] &= valid[it];
+    t.hassym[it] = nf[it].need_mid & valid[it];
     t.kw[it] = t.ew[it] = 0;
-    if (so.hassym) pack_symbol(cfg, p, so.sym, so.k, so.ctx1, so.ctx2, so.ctxs, t.kw[it], t.ew[it]);
+    if (PACK && t.hassym[it]) pack_symbol(cfg, p, sym, k, nf[it].n0x, nd[it].x1, nd[it].x0 + nd[it].x1, t.kw[it], t.ew[it]);
   }
 }
 
@@ -128,7 +127,7 @@ __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t ti
                                         uint32_t (*lds_cnt)[4][3]) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
   TileOut t;
-  k3_classify(a, p, tile_in_plane, t);
+  k3_classify<WRITE>(a, p, tile_in_plane, t);
   uint32_t pre0[K3_NPT], pre1[K3_NPT], pres[K3_NPT];
   const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
@@ -154,8 +153,7 @@ __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t ti
   } else {
     const uint32_t o0 = a.tileoff[(size_t)tile_global * 4 + 0];
     const uint32_t o1 = a.tileoff[(size_t)tile_global * 4 + 1];
-    const uint64_t os = (uint64_t)a.tileoff[(size_t)tile_global * 4 + 2] |
-                        ((uint64_t)a.tileoff[(size_t)tile_global * 4 + 3] << 32);
+    const uint64_t os = a.ctl->symbase[p] + a.tileoff[(size_t)tile_global * 4 + 2];
     const uint32_t pn = (p + 1u) & 7u;
     Node *dst = plane_nodes(a, a.par ^ 1u, pn);
     uint32_t run0 = 0, run1 = 0, runs_ = 0;   // counts of earlier (it, wave) groups
@@ -195,261 +193,65 @@ __global__ __launch_bounds__(K3_T) void k3_tiles_kernel(K3Args a) {
   }
 }
 
-// Single block: exclusive scan of the tile counts per plane, symbol bases, next-round counts, run table.
+// Scan: block p scans the tile counts of plane p (tile offsets are plane-local); the block that finishes
+// last folds the 8 plane totals into the control block: symbol bases, flush / overflow decisions, next-round
+// counts, run table.  (threadfence + atomic ticket: the classic last-block pattern.)
 __global__ __launch_bounds__(1024) void k3_scan_kernel(K3Args a) {
   __shared__ uint32_t tp[9];
-  __shared__ uint32_t tot[8][3];
+  __shared__ uint32_t s_last;
   EnumCtl *ctl = a.ctl;
   if (ctl->need_flush || ctl->overflow) return;
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, p = blockIdx.x;
   if (tid == 0) tile_prefix(a, tp);
   __syncthreads();
-  for (uint32_t p = 0; p < 8; ++p) {
-    uint32_t r0 = 0, r1 = 0, rs = 0;
-    for (uint32_t base = tp[p]; base < tp[p + 1]; base += 1024) {
-      const uint32_t t = base + tid;
-      const bool valid = t < tp[p + 1];
-      const uint32_t v0 = valid ? a.tilecnt[(size_t)t * 4 + 0] : 0u;
-      const uint32_t v1 = valid ? a.tilecnt[(size_t)t * 4 + 1] : 0u;
-      const uint32_t vs = valid ? a.tilecnt[(size_t)t * 4 + 2] : 0u;
-      uint32_t t0, t1, ts;
-      const uint32_t e0 = block_excl_scan_sum<1024>(v0, &t0);
-      const uint32_t e1 = block_excl_scan_sum<1024>(v1, &t1);
-      const uint32_t es = block_excl_scan_sum<1024>(vs, &ts);
-      if (valid) {
-        a.tileoff[(size_t)t * 4 + 0] = r0 + e0;
-        a.tileoff[(size_t)t * 4 + 1] = r1 + e1;
-        a.tileoff[(size_t)t * 4 + 2] = rs + es;   // plane-local for now; the symbol base is added below
-      }
-      r0 += t0; r1 += t1; rs += ts;
+  uint32_t r0 = 0, r1 = 0, rs = 0;
+  for (uint32_t base = tp[p]; base < tp[p + 1]; base += 1024) {
+    const uint32_t t = base + tid;
+    const bool valid = t < tp[p + 1];
+    const uint32_t v0 = valid ? a.tilecnt[(size_t)t * 4 + 0] : 0u;
+    const uint32_t v1 = valid ? a.tilecnt[(size_t)t * 4 + 1] : 0u;
+    const uint32_t vs = valid ? a.tilecnt[(size_t)t * 4 + 2] : 0u;
+    // child counts <= 1024 per tile: pack both in one u64 scan with the symbol count
+    uint64_t tot;
+    const uint64_t ex = block_excl_scan_sum64<1024>((uint64_t)v0 | ((uint64_t)v1 << 21) | ((uint64_t)vs << 42), &tot);
+    if (valid) {
+      a.tileoff[(size_t)t * 4 + 0] = r0 + (uint32_t)(ex & 0x1FFFFFu);
+      a.tileoff[(size_t)t * 4 + 1] = r1 + (uint32_t)((ex >> 21) & 0x1FFFFFu);
+      a.tileoff[(size_t)t * 4 + 2] = rs + (uint32_t)(ex >> 42);
     }
-    if (tid == 0) { tot[p][0] = r0; tot[p][1] = r1; tot[p][2] = rs; }
-  }
-  __syncthreads();
-  // symbol bases and the flush / overflow decisions (uniform: every thread computes the same values)
-  uint64_t symsum = 0, sb[8];
-  uint32_t nextn = 0, curn = 0;
-  bool ovf = false;
-  for (int p = 0; p < 8; ++p) {
-    sb[p] = ctl->sym_total + symsum;
-    symsum += tot[p][2];
-    nextn += tot[p][0] + tot[p][1];
-    curn += ctl->cnt[a.par][p][0] + ctl->cnt[a.par][p][1];
-    if ((uint64_t)tot[p][0] + tot[p][1] > a.capP) ovf = true;
-  }
-  const bool flush = ctl->sym_total + symsum > ctl->sym_cap;
-  __syncthreads();   // everyone has read ctl before thread 0 changes it
-  if (ovf) { if (tid == 0) ctl->overflow = 1; return; }
-  if (flush) { if (tid == 0) { ctl->need_flush = 1; ctl->skip_round = a.round; ctl->want_syms = symsum; } return; }
-  // fold the symbol bases into the tile offsets (64-bit: low in [2], high in [3])
-  for (uint32_t p = 0; p < 8; ++p)
-    for (uint32_t t = tp[p] + tid; t < tp[p + 1]; t += 1024) {
-      const uint64_t v = sb[p] + a.tileoff[(size_t)t * 4 + 2];
-      a.tileoff[(size_t)t * 4 + 2] = (uint32_t)v;
-      a.tileoff[(size_t)t * 4 + 3] = (uint32_t)(v >> 32);
-    }
-  if (tid < 8) {
-    const uint32_t p = tid, pn = (p + 1u) & 7u;
-    ctl->cnt[a.par ^ 1u][pn][0] = tot[p][0];
-    ctl->cnt[a.par ^ 1u][pn][1] = tot[p][1];
-    RunEntry e; e.start = sb[p]; e.count = tot[p][2]; e.round = a.round;
-    a.runs[(size_t)a.run_slot * 8 + p] = e;
+    r0 += (uint32_t)(tot & 0x1FFFFFu); r1 += (uint32_t)((tot >> 21) & 0x1FFFFFu); rs += (uint32_t)(tot >> 42);
   }
   if (tid == 0) {
-    ctl->sym_total += symsum;
-    ctl->nodes_total += curn;
-    ctl->next_nodes = nextn;
-    if (nextn == 0 && ctl->done_round == 0xFFFFFFFFu) ctl->done_round = a.round + 1u;
+    ctl->ptot[p][0] = r0; ctl->ptot[p][1] = r1; ctl->ptot[p][2] = rs;
+    __threadfence();
+    s_last = atomicAdd(&ctl->ticket, 1u) == 7u ? 1u : 0u;
   }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Single-pass round: tiles are taken from a ticket counter (so every predecessor of a tile has started),
-// each tile classifies its nodes once, publishes its three counts and obtains its exclusive prefixes by
-// decoupled look-back, then writes children and symbol records.  Descriptors are 8-byte granules
-//   [63:33] epoch (= round + 1)   [32:31] status (1 = tile aggregate, 2 = inclusive prefix)   [30:0] value
-// stored/loaded with agent-scope relaxed atomics (write-through / L1-bypassing: the data is its own flag, no
-// fences).  The control block is READ-ONLY during the round; k3_finalize_kernel folds the round's totals in.
-// ------------------------------------------------------------------------------------------------------
-constexpr uint32_t K3_SPIN_LIMIT = 1u << 22;
-
-__device__ __forceinline__ unsigned long long k3_pack(uint32_t epoch, uint32_t status, uint32_t value) {
-  return ((unsigned long long)epoch << 33) | ((unsigned long long)status << 31) | (unsigned long long)value;
-}
-
-// executed by ONE wave: chains 0,1 (child lists) restart at the plane's first tile `lo_plane`, chain 2 (symbols) at 0
-__device__ __forceinline__ void k3_lookback(const K3Args &a, uint32_t tile, uint32_t lo_plane, uint32_t epoch,
-                                            const uint32_t agg[3], uint32_t excl[3]) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t lo[3] = {lo_plane, lo_plane, 0u};
-  if (lane < 3) {
-    const uint32_t mylo = lane < 2 ? lo_plane : 0u;
-    const uint32_t myagg = lane == 0 ? agg[0] : (lane == 1 ? agg[1] : agg[2]);
-    __hip_atomic_store(&a.desc[(size_t)tile * 3 + lane], k3_pack(epoch, tile == mylo ? 2u : 1u, myagg),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  bool done[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) { excl[c] = 0; done[c] = tile == lo[c]; }
-  long long cur = (long long)tile - 1;
-  while (!(done[0] && done[1] && done[2])) {
-    const long long idx = cur - (long long)lane;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      if (done[c]) continue;                       // wave-uniform
-      const bool valid = idx >= (long long)lo[c];
-      unsigned long long v = 0;
-      if (valid) {
-        uint32_t spins = 0;
-        for (;;) {
-          v = __hip_atomic_load(&a.desc[(size_t)idx * 3 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((uint32_t)(v >> 33) == epoch && ((v >> 31) & 3ull) != 0) break;
-          if (++spins > K3_SPIN_LIMIT) { a.ctl->lookback_fail = 1; v = k3_pack(epoch, 2u, 0u); break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      const uint32_t st = (uint32_t)((v >> 31) & 3ull), val = (uint32_t)(v & 0x7FFFFFFFull);
-      const uint64_t vmask = __ballot(valid);
-      const uint64_t inclm = __ballot(valid && st == 2u);
-      // sum the aggregates of the nearest tiles up to (and including) the nearest inclusive prefix
-      const uint64_t use = inclm ? ((2ull << (__ffsll((long long)inclm) - 1)) - 1ull) & vmask : vmask;
-      uint32_t x = ((use >> lane) & 1ull) ? val : 0u;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-      excl[c] += x;
-      if (inclm) done[c] = true;
-    }
-    cur -= 64;
-  }
-  if (lane < 3) {
-    const uint32_t inc = lane == 0 ? excl[0] + agg[0] : (lane == 1 ? excl[1] + agg[1] : excl[2] + agg[2]);
-    __hip_atomic_store(&a.desc[(size_t)tile * 3 + lane], k3_pack(epoch, 2u, inc), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-__global__ __launch_bounds__(K3_T) void k3_round_kernel(K3Args a) {
-  __shared__ uint32_t tp[9];
-  __shared__ uint32_t lds_cnt[K3_NPT][4][3];
-  __shared__ uint32_t s_tile;
-  __shared__ uint32_t s_excl[3];
-  const EnumCtl *ctl = a.ctl;
-  if (ctl->need_flush || ctl->overflow || ctl->lookback_fail) return;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-  if (tid == 0) tile_prefix(a, tp);
   __syncthreads();
-  const uint32_t T = tp[8];
-  // flush decision, identical in every block: a round emits at most one symbol per node
-  uint64_t round_nodes = 0;
-#pragma unroll
-  for (int p = 0; p < 8; ++p) round_nodes += (uint64_t)ctl->cnt[a.par][p][0] + ctl->cnt[a.par][p][1];
-  const uint64_t symbase = ctl->sym_total;
-  if (symbase + round_nodes > ctl->sym_cap) {
-    if (blockIdx.x == 0 && tid == 0) { a.ctl->skip_round = a.round; a.ctl->want_syms = round_nodes; a.ctl->need_flush = 1; }
-    return;
-  }
-  const uint32_t epoch = a.round + 1u;
-  const uint64_t lt = (1ull << lane) - 1ull;
-  for (;;) {
-    if (tid == 0) s_tile = atomicAdd(&a.ctl->ticket, 1u);
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    if (tile >= T) break;
-    uint32_t p = 0;
-#pragma unroll
-    for (int k = 1; k < 8; ++k) p += (tile >= tp[k]) ? 1u : 0u;
-    const uint32_t tile_in_plane = tile - tp[p];
-    TileOut t;
-    k3_classify(a, p, tile_in_plane, t);
-    uint32_t pre0[K3_NPT], pre1[K3_NPT], pres[K3_NPT];
-#pragma unroll
-    for (int it = 0; it < K3_NPT; ++it) {
-      const uint64_t b0 = __ballot(t.has0[it]), b1 = __ballot(t.has1[it]), bs = __ballot(t.hassym[it]);
-      pre0[it] = (uint32_t)__popcll(b0 & lt);
-      pre1[it] = (uint32_t)__popcll(b1 & lt);
-      pres[it] = (uint32_t)__popcll(bs & lt);
-      if (lane == 0) {
-        lds_cnt[it][w][0] = (uint32_t)__popcll(b0);
-        lds_cnt[it][w][1] = (uint32_t)__popcll(b1);
-        lds_cnt[it][w][2] = (uint32_t)__popcll(bs);
-      }
-    }
-    __syncthreads();
-    if (w == 0) {
-      uint32_t agg[3] = {0, 0, 0}, excl[3];
-#pragma unroll
-      for (int it = 0; it < K3_NPT; ++it)
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) { agg[0] += lds_cnt[it][ww][0]; agg[1] += lds_cnt[it][ww][1]; agg[2] += lds_cnt[it][ww][2]; }
-      k3_lookback(a, tile, tp[p], epoch, agg, excl);
-      if (lane == 0) {
-        s_excl[0] = excl[0]; s_excl[1] = excl[1]; s_excl[2] = excl[2];
-        if (tile + 1 == tp[p + 1]) {     // last tile of its plane: the plane's totals for k3_finalize_kernel
-          a.ctl->ptot[p][0] = excl[0] + agg[0];
-          a.ctl->ptot[p][1] = excl[1] + agg[1];
-          a.ctl->ptot[p][2] = excl[2] + agg[2];
-        }
-      }
-    }
-    __syncthreads();
-    {
-      const uint32_t o0 = s_excl[0], o1 = s_excl[1];
-      const uint64_t os = symbase + s_excl[2];
-      const uint32_t pn = (p + 1u) & 7u;
-      Node *dst = plane_nodes(a, a.par ^ 1u, pn);
-      uint32_t run0 = 0, run1 = 0, runs_ = 0;
-#pragma unroll
-      for (int it = 0; it < K3_NPT; ++it) {
-        uint32_t b0 = run0, b1 = run1, bs = runs_;
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-          const uint32_t x0 = lds_cnt[it][ww][0], x1 = lds_cnt[it][ww][1], xs = lds_cnt[it][ww][2];
-          if ((uint32_t)ww < w) { b0 += x0; b1 += x1; bs += xs; }
-          run0 += x0; run1 += x1; runs_ += xs;
-        }
-        if (t.has0[it]) { const uint32_t i0 = o0 + b0 + pre0[it]; if (i0 < a.capP) dst[i0] = t.c0[it]; }
-        if (t.has1[it]) { const uint32_t i1 = o1 + b1 + pre1[it]; if (i1 < a.capP) dst[a.capP - 1u - i1] = t.c1[it]; }
-        if (t.hassym[it]) {
-          a.symkey[os + bs + pres[it]] = t.kw[it];
-          a.symesc[os + bs + pres[it]] = t.ew[it];
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// one small block after every round: fold the round's totals into the control block
-__global__ void k3_finalize_kernel(K3Args a) {
-  if (threadIdx.x != 0) return;
-  EnumCtl *ctl = a.ctl;
-  if (ctl->need_flush || ctl->overflow || ctl->lookback_fail) return;
-  uint32_t tp[9];
-  tile_prefix(a, tp);
-  uint64_t curn = 0, nextn = 0, prev_sym = 0;
-  bool ovf = false;
-  for (uint32_t p = 0; p < 8; ++p) {
-    const uint32_t pn = (p + 1u) & 7u;
-    curn += (uint64_t)ctl->cnt[a.par][p][0] + ctl->cnt[a.par][p][1];
-    RunEntry e; e.round = a.round;
-    if (tp[p + 1] > tp[p]) {
-      const uint32_t t0 = ctl->ptot[p][0], t1 = ctl->ptot[p][1], ts = ctl->ptot[p][2];
-      ctl->cnt[a.par ^ 1u][pn][0] = t0;
-      ctl->cnt[a.par ^ 1u][pn][1] = t1;
-      nextn += (uint64_t)t0 + t1;
-      if ((uint64_t)t0 + t1 > a.capP) ovf = true;
-      e.start = ctl->sym_total + prev_sym; e.count = (uint32_t)(ts - prev_sym);
-      prev_sym = ts;
-    } else {
-      ctl->cnt[a.par ^ 1u][pn][0] = 0;
-      ctl->cnt[a.par ^ 1u][pn][1] = 0;
-      e.start = ctl->sym_total + prev_sym; e.count = 0;
-    }
-    a.runs[(size_t)a.run_slot * 8 + p] = e;
-  }
+  if (!s_last || tid != 0) return;
+  __threadfence();
   ctl->ticket = 0;
+  uint64_t symsum = 0, nextn = 0, curn = 0;
+  bool ovf = false;
+  const volatile uint32_t (*pt)[3] = ctl->ptot;
+  for (int q = 0; q < 8; ++q) {
+    symsum += pt[q][2];
+    nextn += (uint64_t)pt[q][0] + pt[q][1];
+    curn += (uint64_t)ctl->cnt[a.par][q][0] + ctl->cnt[a.par][q][1];
+    if ((uint64_t)pt[q][0] + pt[q][1] > a.capP) ovf = true;
+  }
   if (ovf) { ctl->overflow = 1; return; }
-  ctl->sym_total += prev_sym;
+  if (ctl->sym_total + symsum > ctl->sym_cap) { ctl->need_flush = 1; ctl->skip_round = a.round; ctl->want_syms = symsum; return; }
+  uint64_t acc = ctl->sym_total;
+  for (uint32_t q = 0; q < 8; ++q) {
+    const uint32_t qn = (q + 1u) & 7u;
+    ctl->symbase[q] = acc;
+    ctl->cnt[a.par ^ 1u][qn][0] = pt[q][0];
+    ctl->cnt[a.par ^ 1u][qn][1] = pt[q][1];
+    RunEntry e; e.start = acc; e.count = pt[q][2]; e.round = a.round;
+    a.runs[(size_t)a.run_slot * 8 + q] = e;
+    acc += pt[q][2];
+  }
+  ctl->sym_total = acc;
   ctl->nodes_total += curn;
   ctl->next_nodes = (uint32_t)nextn;
   if (nextn == 0 && ctl->done_round == 0xFFFFFFFFu) ctl->done_round = a.round + 1u;
@@ -664,7 +466,6 @@ static K3Args make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot) {
   a.tilecnt = c->tilecnt.as<uint32_t>();
   a.tileoff = c->tileoff.as<uint32_t>();
   a.runs = c->runs.as<RunEntry>();
-  a.desc = c->desc.as<unsigned long long>();
   a.capP = c->capP; a.ngran = c->ngran; a.n = c->n;
   for (int i = 0; i < 8; ++i) a.zeros[i] = c->zeros[i];
   a.par = round & 1u; a.round = round; a.run_slot = run_slot;
@@ -685,8 +486,6 @@ int k3_begin(bce_hip_ctx *c) {
   const size_t tiles = (size_t)8 * ((c->capP + K3_TILE - 1) / K3_TILE) + 8;
   BCE_TRY(ensure(c, c->tilecnt, tiles * 16));
   BCE_TRY(ensure(c, c->tileoff, tiles * 16));
-  BCE_TRY(ensure(c, c->desc, tiles * 24));
-  BCE_HIP_TRY(c, hipMemsetAsync(c->desc.p, 0, tiles * 24, c->stream));   // epoch 0 = never published
   BCE_TRY(ensure(c, c->ctl, sizeof(EnumCtl)));
   BCE_TRY(ensure(c, c->runs, (size_t)K3_MAXBATCH * 8 * sizeof(RunEntry)));
   if (!c->h_ctl) BCE_HIP_TRY(c, hipHostMalloc(&c->h_ctl, sizeof(EnumCtl), hipHostMallocDefault));
@@ -729,22 +528,16 @@ int k3_begin(bce_hip_ctx *c) {
 
 int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint) {
   if (count > K3_MAXBATCH) count = K3_MAXBATCH;
-  static const int mode = [] { const char *e = getenv("BCE_HIP_K3_MODE"); return e ? atoi(e) : 1; }();
-  (void)nodes_hint;   // a per-batch hint is useless while the node count doubles every round; narrow rounds go to k3_tail
+  (void)nodes_hint;
   const uint32_t grid = 2048;
   for (uint32_t i = 0; i < count; ++i) {
     const K3Args a = make_args(c, c->round + i, i);
-    if (mode == 3) {          // v1: count -> scan -> write (kept for A/B measurements)
-      hipLaunchKernelGGL(k3_tiles_kernel<false>, dim3(grid), dim3(K3_T), 0, c->stream, a);
-      hipLaunchKernelGGL(k3_scan_kernel, dim3(1), dim3(1024), 0, c->stream, a);
-      hipLaunchKernelGGL(k3_tiles_kernel<true>, dim3(grid), dim3(K3_T), 0, c->stream, a);
-    } else {                  // single pass with decoupled look-back + finalize
-      hipLaunchKernelGGL(k3_round_kernel, dim3(grid), dim3(K3_T), 0, c->stream, a);
-      hipLaunchKernelGGL(k3_finalize_kernel, dim3(1), dim3(64), 0, c->stream, a);
-    }
+    hipLaunchKernelGGL(k3_tiles_kernel<false>, dim3(grid), dim3(K3_T), 0, c->stream, a);
+    hipLaunchKernelGGL(k3_scan_kernel, dim3(8), dim3(1024), 0, c->stream, a);
+    hipLaunchKernelGGL(k3_tiles_kernel<true>, dim3(grid), dim3(K3_T), 0, c->stream, a);
   }
   BCE_HIP_TRY(c, hipGetLastError());
-  c->stats.k3_launches += (mode == 3 ? 3.0 : 2.0) * count;
+  c->stats.k3_launches += 3.0 * count;
   return BCE_HIP_OK;
 }
 

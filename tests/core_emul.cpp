@@ -76,6 +76,16 @@ extern "C" int emul_encode_from_bwt(const uint8_t *bwt, uint32_t n, uint32_t off
         for (const Node &nd : cur[p][j]) {
           StepOut so;
           node_step(nd, zeros[p], rank1, so);
+          {   // the branch-free form used by the kernels must agree with the reference-shaped one
+            NodeFlat nf; uint32_t h0, h1, sy, kk; Node a0, a1;
+            node_flat_pre(nd, rank1(nd.s), rank1(nd.s + nd.x0 + nd.x1), nf);
+            node_flat_post(nd, zeros[p], nf, nf.need_mid ? rank1(nd.s + nd.x0) : 0u, h0, a0, h1, a1, sy, kk);
+            bool ok = h0 == so.has0 && h1 == so.has1 && nf.need_mid == so.hassym;
+            if (h0) ok = ok && a0.s == so.c0.s && a0.x0 == so.c0.x0 && a0.x1 == so.c0.x1;
+            if (h1) ok = ok && a1.s == so.c1.s && a1.x0 == so.c1.x0 && a1.x1 == so.c1.x1;
+            if (nf.need_mid) ok = ok && sy == so.sym && kk == so.k;
+            if (!ok) return -7;
+          }
           ++nodes;
           if (so.has0) nxt[(p + 1) & 7][0].push_back(so.c0);
           if (so.has1) nxt[(p + 1) & 7][1].push_back(so.c1);
