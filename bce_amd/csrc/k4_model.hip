@@ -119,7 +119,7 @@ __device__ __forceinline__ uint64_t k4_replay(const K4Args &a, uint64_t pos, uin
       const uint32_t t = __shfl_up(inc, o);
       if (lane >= (uint32_t)o) inc += t;
     }
-    const uint32_t T = __shfl(inc, 31);
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)inc, 31);
     const uint32_t Ps = __shfl(inc - C, (int)s);
     const uint32_t Cs = __shfl(C, (int)s);
     uint64_t eq, lt;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(K4_T) void k4_window_kernel(K4Args a) {
     const bool head = inb && (j0 == 0 || rid != (prev >> kSymRunShift));
     uint64_t heads = __ballot(head);
     // histogram of the leading fragment (the lanes that continue the run of lane 0)
-    const uint32_t r0 = __shfl(rid, 0);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rid);
     const bool lead = inb && rid == r0;
     const uint64_t leadm = __ballot(lead);
     const uint32_t s = key & 31u;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(K4_T) void k4_window_kernel(K4Args a) {
     while (heads) {                                         // runs that START in this window
       const int hl = __ffsll((long long)heads) - 1;
       heads &= heads - 1;
-      const uint32_t hkey = __shfl(key, hl);
+      const uint32_t hkey = (uint32_t)__builtin_amdgcn_readlane((int)key, hl);
       const uint64_t start = win * 64 + (uint64_t)hl;
       const uint64_t probe = start + K4_LONG - 1;
       const bool is_long = probe < a.nsym && (a.keys[probe] >> kSymRunShift) == (hkey >> kSymRunShift);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(K4_T) void k4_long_kernel(K4Args a) {
       // ---- binary slots (every really long run is one): the window's symbols are a 64-bit mask, so the walk
       // is wave-uniform mask arithmetic -- counts are popcounts, the halving position is "the n-th zero or the
       // n-th one", found with mbcnt + one ballot.  64 windows' masks/infos are fetched per coalesced load.
-      uint32_t c0 = __shfl(C, 0), c1 = __shfl(C, 1);
+      uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)C, 0), c1 = (uint32_t)__builtin_amdgcn_readlane((int)C, 1);
       uint64_t gb = gbase;
       unsigned long long nbits = gb + lane < nwin ? a.bitsW[gb + lane] : 0ull;
       uint32_t ninfo = gb + lane < nwin ? a.winfo[gb + lane] : 0xFFFFFFFFu;
@@ -244,11 +244,12 @@ __global__ __launch_bounds__(K4_T) void k4_long_kernel(K4Args a) {
         uint32_t my_state = 0, my_halt = K4_NOT_LONG;
         bool mine = false;
         for (int i = 0; i < 64; ++i) {
-          const uint32_t info = __shfl(cinfo, i);
+          const uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)cinfo, i);   // uniform index: v_readlane, not ds_bpermute
           if ((info >> 7) != runid) { running = false; break; }      // also ends at nwin (info = ~0)
           const uint32_t f = info & 127u;
           const unsigned long long fm = f >= 64 ? ~0ull : ((1ull << f) - 1ull);
-          const unsigned long long B = (unsigned long long)__shfl((long long)cbits, i) & fm;
+          const unsigned long long B = (((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(cbits >> 32), i) << 32) |
+                                        (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cbits, i)) & fm;
           const uint32_t h1 = (uint32_t)__popcll(B), h0 = f - h1;
           const uint32_t s0 = c0, s1 = c1;
           uint32_t halt = K4_NO_HALVE;

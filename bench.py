@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--file", default=os.environ.get("BCE_BENCH_FILE"))
     ap.add_argument("--cpu-sample", type=int, default=24 << 20, help="bytes of the workload the CPU baseline compresses")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real multi-GPU path); gloo = rehearsal of the N>1 control flow on one GPU")
     return ap.parse_args()
 
 
@@ -76,10 +78,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend="gloo")
+            local = local % max(1, torch.cuda.device_count())     # rehearsal: ranks may share a GPU
     n_gpus = world
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     data, workload = make_input(args, rank)
     n = len(data)
@@ -99,7 +106,7 @@ def main():
         arch, st = bce_amd.compress_device(t_in.data_ptr(), n, ctx=ctx)
         if dist is not None:
             # RCCL gather of the per-block coded streams to rank 0 (size exchange, then padded gather)
-            gathered[0] = sharding.gather_streams(arch, dist, dev)
+            gathered[0] = sharding.gather_streams(arch, dist, comm_dev)
         return arch, st
 
     for _ in range(args.warmup):
@@ -113,7 +120,7 @@ def main():
         sts.append(st)
     barrier()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev if dist is not None else dev)
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
@@ -135,6 +142,11 @@ def main():
                 "frac": round(alg_bytes / k3_s / 1e9 / HBM_PEAK_GBS, 5) if k3_s > 0 else None,
                 "traffic": traffic, "algorithmic_bytes": alg_bytes, "k3_ms_per_step": round(k3_s * 1e3, 3),
                 "k3_launches_per_step": st["k3_launches"]}
+        if dist is not None and gathered[0] is not None:
+            # the gathered per-block streams form the multi-block container (bce_amd/container.py)
+            from bce_amd import container
+            blob = container.pack_blocks(gathered[0], [n] * n_gpus)
+            assert container.unpack_blocks(blob)[0][0] == arch
         out = {
             "metric": "MB/s compressed", "value": round(n_gpus * n * steps / dt / 1e6, 3), "unit": "MB/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 2),

@@ -1,0 +1,45 @@
+"""GPU: the `bce` command line (bce_amd/bin/bce) -- `bce -c archive file [config]` as the reference's main() (bce.cpp:1403-1427)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "bce_amd", "bin", "bce")
+
+
+def test_cli_compress_matches_oracle(tmp_path):
+    data = oracle.synth_text(12, 300000)
+    src, dst = tmp_path / "in.txt", tmp_path / "out.bce"
+    src.write_bytes(data)
+    r = subprocess.run([EXE, "-c", str(dst), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("BCE v0.4 Release\n")
+    assert "Compressed from 300000 B -> %d B in " % dst.stat().st_size in r.stdout
+    assert dst.read_bytes() == oracle.compress(data)
+
+
+def test_cli_config_and_errors(tmp_path):
+    data = oracle.synth_text(13, 100000)
+    cfg = np.random.RandomState(5).randint(0, 6, 288).astype(np.uint8).tobytes()
+    src, dst, cf = tmp_path / "in.txt", tmp_path / "out.bce", tmp_path / "c.bcc"
+    src.write_bytes(data)
+    cf.write_bytes(cfg)
+    r = subprocess.run([EXE, "-c", str(dst), str(src), str(cf)], capture_output=True, text=True)
+    assert r.returncode == 0
+    assert dst.read_bytes() == oracle.compress(data, cfg)
+    # wrong-size config: message, defaults used (bce.cpp:629-631)
+    cf.write_bytes(b"x" * 10)
+    r = subprocess.run([EXE, "-c", str(dst), str(src), str(cf)], capture_output=True, text=True)
+    assert r.returncode == 0 and "Config not found or wrong size." in r.stdout
+    assert dst.read_bytes() == oracle.compress(data)
+    # missing / empty input: "Error loading file", exit -1 (bce.cpp:1412-1415; empty input crashes the reference, Q12)
+    r = subprocess.run([EXE, "-c", str(dst), str(tmp_path / "nope")], capture_output=True, text=True)
+    assert r.returncode == 255 and "Error loading file" in r.stdout
+    (tmp_path / "empty").write_bytes(b"")
+    r = subprocess.run([EXE, "-c", str(dst), str(tmp_path / "empty")], capture_output=True, text=True)
+    assert r.returncode == 255 and "Error loading file" in r.stdout
