@@ -65,6 +65,7 @@ SYMBOLS = [
     ("bce_hip_enum_round", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("bce_hip_enum_symbols", C.c_int, [C.c_void_p, _u32p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("bce_hip_enum_model", C.c_int, [C.c_void_p, _u32p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("bce_hip_decompress", C.c_int, [_u8p, C.c_size_t, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("bce_hip_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     ("bce_hip_synth_text", None, [C.c_uint64, _u8p, C.c_size_t]),
     ("bce_hip_synth_rand", None, [C.c_uint64, _u8p, C.c_size_t]),
@@ -282,6 +283,21 @@ def compress_device(device_ptr, n, config=None, device=0, ctx=None):
     finally:
         if own:
             c.close()
+
+
+def decompress(archive) -> bytes:
+    """`bce -d` on an in-memory archive (bce.cpp:1428-1472 minus file I/O).  Host C++ decoder; needs no GPU."""
+    lib = load_library()
+    a = _as_u8(archive)
+    n = C.c_size_t()
+    rc = lib.bce_hip_decompress(a.ctypes.data, len(a), None, 0, C.byref(n))
+    if rc != 0:
+        raise BceError(rc, "bce_hip_decompress")
+    out = np.empty(n.value, dtype=np.uint8)
+    rc = lib.bce_hip_decompress(a.ctypes.data, len(a), out.ctypes.data, n.value, C.byref(n))
+    if rc != 0:
+        raise BceError(rc, "bce_hip_decompress")
+    return out.tobytes()
 
 
 def synth_text(seed, n) -> np.ndarray:

@@ -1,8 +1,8 @@
 // main.cpp -- the `bce` command line, mirroring the reference's main() (bce.cpp:1376-1484):
 //   bce -c archive.bce file [config.bcc]    compress on the MI355X through libbcehip.so
 // Banner, usage text, summary line, argument detection and exit codes follow the reference
-// (banner :1377-1379, -c :1403-1427, usage :1473-1483).  -d / -s are outside this round's hot path
-//  and say so instead of silently doing something else.
+// (banner :1377-1379, -c :1403-1427, -d :1428-1472, usage :1473-1483).  -d uses the host decoder (decoder.cpp);
+// -s (ScanCoder) is outside this round's scope and says so.
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -82,8 +82,29 @@ int main(int argc, char **argv) {
     archive.write(reinterpret_cast<const char *>(arch.data()), (std::streamsize)arch.size());
     bce_hip_destroy(ctx);
     return 0;
-  } else if (argc == 4 && argv[1][0] == '-' && (argv[1][1] == 'd' || argv[1][1] == 's')) {
-    printf("bce %s is not part of the MI355X hot path yet (see DESIGN.md, out of scope this round).\n", argv[1]);
+  } else if (argc == 4 && argv[1][0] == '-' && argv[1][1] == 'd') {
+    // Decompress (bce.cpp:1428-1472).  `-ds` selected the low-memory bitwise unbwt in the reference (:1466); the
+    // host decoder here has one inverse transform, so both spellings give the same output.
+    auto start = std::chrono::high_resolution_clock::now();
+    std::ifstream archive(std::string(argv[3]), std::ios::binary | std::ios::ate);
+    std::streamoff size = archive ? (std::streamoff)archive.tellg() : -1;
+    if (size < 0) { printf("Archive not found.\n"); return -1; }
+    std::vector<uint8_t> adata((size_t)size);
+    archive.seekg(0, std::ios::beg);
+    if (size == 0 || !archive.read(reinterpret_cast<char *>(adata.data()), size)) { printf("Could not read Archive.\n"); return -2; }
+    size_t n = 0;
+    int rc = bce_hip_decompress(adata.data(), adata.size(), nullptr, 0, &n);
+    std::vector<uint8_t> out(n);
+    if (rc == 0) rc = bce_hip_decompress(adata.data(), adata.size(), out.data(), out.size(), &n);
+    if (rc != 0) { printf("Decompression failed: %s\n", bce_hip_strerror(rc)); return -4; }
+    auto end = std::chrono::high_resolution_clock::now();
+    std::chrono::duration<double> duration = end - start;
+    printf("Decompressed from %zu B -> %zu B in %.1f s\n", adata.size(), out.size(), duration.count());
+    std::ofstream file(std::string(argv[2]), std::ios::binary | std::ios::trunc);
+    file.write(reinterpret_cast<const char *>(out.data()), (std::streamsize)out.size());
+    return 0;
+  } else if (argc == 4 && argv[1][0] == '-' && argv[1][1] == 's') {
+    printf("bce -s (ScanCoder) is not part of the MI355X hot path yet (see DESIGN.md, out of scope this round).\n");
     return -5;
   }
   return usage();

@@ -99,6 +99,11 @@ int bce_hip_enum_symbols(bce_hip_ctx *ctx, uint32_t *out, uint64_t cap_records, 
 /* run K4 on the symbols emitted so far: out[3*i+0..2] = cum, freq, total per record (same order) */
 int bce_hip_enum_model(bce_hip_ctx *ctx, uint32_t *out, uint64_t cap_records, uint64_t *count);
 
+/* ---- decoder (SURVEY section 8f "next #1"; host C++ this round, not a GPU path) ------------------------------ */
+/* BCE::decode + unbwt::bytewise + inverse BWT + rotate (bce.cpp:1169-1233, 1043-1102): archive -> original bytes.
+ * out == NULL: only report the decoded size in *out_len.  Needs no context and no GPU. */
+int bce_hip_decompress(const uint8_t *archive, size_t len, uint8_t *out, size_t cap, size_t *out_len);
+
 /* ---- statistics of the last bce_hip_encode / bce_hip_compress ------------------------------------ */
 typedef struct bce_hip_stats {
   uint64_t n;            /* input bytes */
