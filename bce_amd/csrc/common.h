@@ -136,8 +136,8 @@ inline double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-constexpr uint32_t K3_TAIL_CAP = 4096;        // nodes the tail kernel holds in LDS (all 8 planes together)
-constexpr uint32_t K3_TAIL_ENTER = 2048;      // the host switches to the tail kernel at or below this many nodes
+constexpr uint32_t K3_TAIL_CAP = 1024;        // nodes the tail kernel holds in LDS (all 8 planes together)
+constexpr uint32_t K3_TAIL_ENTER = 512;       // the host switches to the tail kernel at or below this many nodes
 constexpr uint32_t K3_TAIL_MAXROUNDS = 65536; // rounds per tail launch (bounded by its run table)
 
 inline uint32_t ceil_log2(uint32_t v) { uint32_t b = 0; while ((1ull << b) < v) ++b; return b; }

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(1024) void k3_scan_kernel(K3Args a) {
 // is left, when the node count grows past the LDS capacity, when the symbol buffer cannot take another
 // round, or after max_rounds; state is handed back through the same control block the wide rounds use.
 // ------------------------------------------------------------------------------------------------------
-constexpr int KT_T = 1024;
+constexpr int KT_T = 256;                    // 4 waves: cheap barriers, no 128-VGPR cap (a 1024-thread version spilled)
 constexpr int KT_NPT = K3_TAIL_CAP / KT_T;   // 4 consecutive nodes per thread
 
 __device__ __forceinline__ uint64_t kt_block_excl_scan(uint64_t v, uint64_t *ws, uint64_t *total) {
