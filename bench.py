@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--size", type=int, default=100_000_000, help="input bytes per GPU (enwik8 = 10^8)")
     ap.add_argument("--workload", default="synth-text", choices=["synth-text", "synth-rand"])
     ap.add_argument("--file", default=os.environ.get("BCE_BENCH_FILE"))
-    ap.add_argument("--cpu-sample", type=int, default=24 << 20, help="bytes of the workload the CPU baseline compresses")
+    ap.add_argument("--cpu-sample", type=int, default=64 << 20, help="bytes of the workload the CPU baseline compresses")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU path); gloo = rehearsal of the N>1 control flow on one GPU")
@@ -137,7 +137,7 @@ def main():
                 traffic = tj["traffic_bytes_corrected"]
         except Exception:
             pass
-        roof = {"bound": "hbm", "kernel": "K3 interval-count (k3_round_kernel + k3_finalize_kernel + k3_tail_kernel, all rounds of one compression = one launch unit)",
+        roof = {"bound": "hbm", "kernel": "K3 interval-count (k3_tiles_kernel<count> + k3_scan_kernel + k3_tiles_kernel<write> + k3_tail_kernel, all rounds of one compression = one launch unit)",
                 "achieved": round(alg_bytes / k3_s / 1e9, 2) if k3_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(alg_bytes / k3_s / 1e9 / HBM_PEAK_GBS, 5) if k3_s > 0 else None,
                 "traffic": traffic, "algorithmic_bytes": alg_bytes, "k3_ms_per_step": round(k3_s * 1e3, 3),
