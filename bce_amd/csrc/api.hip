@@ -222,7 +222,7 @@ int bce_hip_enum_round(bce_hip_ctx *c, uint64_t *next_nodes) {
   if (!c || !c->enum_active) return BCE_HIP_E_STATE;
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t first = c->round;
-  BCE_TRY(k3_rounds(c, 1, (uint64_t)c->n * 4));
+  BCE_TRY(k3_rounds(c, 1, 0));
   EnumCtl ctl;
   BCE_TRY(k3_sync_ctl(c, &ctl));
   if (ctl.lookback_fail) return BCE_HIP_E_INTERNAL;
@@ -286,6 +286,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
   uint64_t cur_nodes = 0;
   for (int i = 0; i < 8; ++i) cur_nodes += (C[i] && n - C[i]) ? 1 : 0;
   EnumCtl ctl;
+  bool decaying = false;
   for (;;) {
     const uint32_t first = c->round;
     uint32_t executed = 0;
@@ -301,7 +302,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
     } else {
       // wide rounds: sync often (the round dominates); medium rounds: queue many per sync
       const uint32_t batch = cur_nodes > (1u << 20) ? 4u : (cur_nodes > (1u << 14) ? 16u : 64u);
-      BCE_TRY(k3_rounds(c, batch, cur_nodes));
+      BCE_TRY(k3_rounds(c, batch, decaying ? cur_nodes : 0));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
       BCE_TRY(k3_sync_ctl(c, &ctl));
       executed = ctl.need_flush ? ctl.skip_round - first : batch;
@@ -311,6 +312,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
     if (ctl.lookback_fail) { snprintf(c->err, sizeof c->err, "K3 look-back gave up (round %u)", first); return BCE_HIP_E_INTERNAL; }
     if (ctl.overflow) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
     c->round = first + executed;
+    decaying = ctl.next_nodes <= cur_nodes && c->round > 16;   // past the ramp-up: the node count no longer doubles
     cur_nodes = ctl.next_nodes;
     const bool done = ctl.done_round != 0xFFFFFFFFu;
     if (ctl.need_flush) {

@@ -24,7 +24,10 @@
 namespace bce {
 
 constexpr int K3_T = 256;
-constexpr int K3_NPT = 4;                       // nodes per thread
+#ifndef K3_NPT_VALUE
+#define K3_NPT_VALUE 4
+#endif
+constexpr int K3_NPT = K3_NPT_VALUE;            // nodes per thread
 constexpr uint32_t K3_TILE = K3_T * K3_NPT;     // 1024 nodes per tile
 constexpr uint32_t K3_MAXBATCH = 256;           // rounds per run-table batch
 
@@ -528,8 +531,11 @@ int k3_begin(bce_hip_ctx *c) {
 
 int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint) {
   if (count > K3_MAXBATCH) count = K3_MAXBATCH;
-  (void)nodes_hint;
-  const uint32_t grid = 2048;
+  // nodes_hint = 0: unknown / growing (ramp-up: the count doubles every round) -> full grid.  Otherwise the caller
+  // has seen the count stop growing, so the hint bounds the coming rounds and narrow rounds do not pay for 2048
+  // idle blocks per launch (tiles are grid-strided: the size only affects speed).
+  uint64_t want = nodes_hint ? (nodes_hint * 2 + K3_TILE - 1) / K3_TILE + 16 : 2048;
+  const uint32_t grid = (uint32_t)(want < 2048 ? want : 2048);
   for (uint32_t i = 0; i < count; ++i) {
     const K3Args a = make_args(c, c->round + i, i);
     hipLaunchKernelGGL(k3_tiles_kernel<false>, dim3(grid), dim3(K3_T), 0, c->stream, a);
