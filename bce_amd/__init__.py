@@ -8,5 +8,5 @@ There is no CPU fallback: every compute call goes through the HIP library and fa
 when it is missing or when no GPU is present.
 """
 from .api import (BCE, BceError, RankFile, compress, compress_device, decompress, library_path,  # noqa: F401
-                  load_library, synth_rand, synth_text, stats)
+                  load_library, scan, synth_rand, synth_text, stats)
 from .build import build as build_native  # noqa: F401

@@ -65,6 +65,7 @@ SYMBOLS = [
     ("bce_hip_enum_round", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("bce_hip_enum_symbols", C.c_int, [C.c_void_p, _u32p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("bce_hip_enum_model", C.c_int, [C.c_void_p, _u32p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    ("bce_hip_scan", C.c_int, [C.c_void_p, _u8p, C.POINTER(C.c_double)]),
     ("bce_hip_decompress", C.c_int, [_u8p, C.c_size_t, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("bce_hip_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     ("bce_hip_synth_text", None, [C.c_uint64, _u8p, C.c_size_t]),
@@ -283,6 +284,18 @@ def compress_device(device_ptr, n, config=None, device=0, ctx=None):
     finally:
         if own:
             c.close()
+
+
+def scan(data, device=0):
+    """`bce -s` on an in-memory buffer (bce.cpp:1384-1402 minus file I/O) -> (288-byte config, nine result sizes)."""
+    rf = RankFile(data, device=device)
+    try:
+        cfg = np.zeros(CONFIG_BYTES, dtype=np.uint8)
+        res = (C.c_double * 9)()
+        rf._c.check(rf._c.lib.bce_hip_scan(rf._c.h, cfg.ctypes.data, res), "bce_hip_scan")
+        return cfg.tobytes(), list(res)
+    finally:
+        rf.close()
 
 
 def decompress(archive) -> bytes:

@@ -4,6 +4,7 @@
 
 #include "common.h"
 #include "host_coder.h"
+#include "scan_coder.h"
 
 using namespace bce;
 
@@ -90,7 +91,7 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   DevBuf *bufs[] = {&c->text, &c->bwt, &c->sa[0], &c->sa[1], &c->key[0], &c->key[1], &c->rank, &c->k2, &c->nrk, &c->act[0], &c->act[1],
                     &c->rs_hist, &c->blk, &c->ptmp[0], &c->ptmp[1], &c->gran, &c->nodes, &c->ctl, &c->tilecnt,
                     &c->tileoff, &c->runs, &c->truns, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
-                    &c->sesc, &c->stat, &c->dcfg, &c->k4w};
+                    &c->sesc, &c->stat, &c->dcfg, &c->k4w, &c->scanrec};
   for (DevBuf *b : bufs) release(*b);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   if (c->h_runs) (void)hipHostFree(c->h_runs);
@@ -343,6 +344,82 @@ int bce_hip_encode(bce_hip_ctx *c) {
   c->enum_active = false;
   c->stage = 4;
   c->stats.t_enum = now_s() - t0 - c->stats.t_model - c->stats.t_coder;
+  return BCE_HIP_OK;
+}
+
+// `bce -s`: BCE<ScanCoder<31>, unbwt::noop>::encode + save_config (bce.cpp:1384-1402, 726-834).  The enumeration
+// runs on the GPU in scan mode (raw symbol tuples instead of model records); the eight ScanCoders consume them on
+// the host in stream order, then pick the context bits.
+int bce_hip_scan(bce_hip_ctx *c, uint8_t config288[BCE_HIP_CONFIG_BYTES], double result_bytes[9]) {
+  BCE_TRY(check_stage(c, 3));
+  if (!config288) return BCE_HIP_E_ARG;
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  c->coder->drain();
+  c->scan_mode = true;
+  struct Reset { bce_hip_ctx *c; ~Reset() { c->scan_mode = false; } } reset{c};
+  const uint32_t n = c->n;
+  BCE_TRY(k4_prepare(c));
+  BCE_TRY(k3_begin(c));
+  std::vector<ScanCoder> coders;
+  for (int i = 0; i < 8; ++i) coders.emplace_back(i);
+  std::vector<uint32_t> host;
+  auto consume = [&](uint64_t nsym) -> int {
+    if (nsym) {
+      host.resize((size_t)nsym * 5);
+      BCE_HIP_TRY(c, hipMemcpy(host.data(), c->scanrec.p, (size_t)nsym * 20, hipMemcpyDeviceToHost));
+      for (int p = 0; p < 8; ++p)
+        for (const RunEntry &e : c->run_log[p])
+          for (uint64_t i = e.start; i < e.start + e.count; ++i) {
+            const uint32_t *r = &host[(size_t)i * 5];
+            coders[p].set(r[0], r[1], r[2], r[3], r[4]);
+          }
+    }
+    return k3_reset_symbols(c);
+  };
+  uint64_t cur_nodes = 0;
+  for (int i = 0; i < 8; ++i) { const uint32_t C = c->zeros[(i + 7) & 7]; cur_nodes += (C && n - C) ? 1 : 0; }
+  EnumCtl ctl;
+  for (;;) {
+    const uint32_t first = c->round;
+    uint32_t executed = 0;
+    if (cur_nodes <= K3_TAIL_ENTER) {
+      BCE_TRY(k3_tail(c));
+      BCE_TRY(k3_sync_ctl(c, &ctl));
+      executed = ctl.tail_rounds;
+      BCE_TRY(k3_fetch_tail_runs(c, executed));
+    } else {
+      const uint32_t batch = cur_nodes > (1u << 20) ? 4u : 16u;
+      BCE_TRY(k3_rounds(c, batch, 0));
+      BCE_TRY(k3_sync_ctl(c, &ctl));
+      executed = ctl.need_flush ? ctl.skip_round - first : batch;
+      BCE_TRY(k3_fetch_runs(c, first, executed));
+    }
+    if (ctl.overflow) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
+    c->round = first + executed;
+    cur_nodes = ctl.next_nodes;
+    if (ctl.need_flush) {
+      if (ctl.sym_total == 0) {
+        const uint64_t want = ctl.want_syms + (ctl.want_syms >> 3) + 1024;
+        if (want >= (1ull << 31)) return BCE_HIP_E_OVERFLOW;
+        BCE_TRY(k3_grow_symbols(c, want));
+        continue;
+      }
+      BCE_TRY(consume(ctl.sym_total));
+      continue;
+    }
+    if (ctl.done_round != 0xFFFFFFFFu) { BCE_TRY(consume(ctl.sym_total)); break; }
+  }
+  c->enum_active = false;
+  uint8_t init[9][32];
+  memset(init, 0, sizeof init);                            // ScanCoder::init_ is a zero-initialised static (:834)
+  for (int i = 0; i < 8; ++i) {                            // coder_[i].flush(), :1135-1138
+    const double r = coders[i].flush(init);
+    if (result_bytes) result_bytes[i] = r;
+  }
+  ScanCoder mainc(-1);                                     // coder_type main(-1), :1141-1149 (its set(s,k) are no-ops)
+  const double rm = mainc.flush(init);
+  if (result_bytes) result_bytes[8] = rm;
+  memcpy(config288, init, BCE_HIP_CONFIG_BYTES);
   return BCE_HIP_OK;
 }
 

@@ -83,6 +83,8 @@ struct bce_hip_ctx {
   void *h_truns = nullptr;
   bce::DevBuf skey[2], sval[2], sout, sesc;       // K3->K4: symbol keys (skey[0]) + escape words (sesc); sort ping-pong; outputs
   uint64_t sym_cap = 0;
+  bool scan_mode = false;                        // `bce -s`: K3 emits raw (sym,k,c1,c2,cs) tuples into scanrec
+  bce::DevBuf scanrec;
   bce::DevBuf stat, dcfg, k4w;                   // K4 counters, device copy of PlaneCfg[8], per-window work arrays
   uint32_t stat_off[8] = {0};
 

@@ -38,6 +38,7 @@ struct K3Args {
   const PlaneCfg *cfg;    // [8]
   uint32_t *symkey;       // symbol records: key words (K4 sort input)
   uint32_t *symesc;       // symbol records: escape words
+  uint32_t *scanrec;      // scan mode (`bce -s`): raw (sym, k, c1, c2, cs) per record instead of key/escape words
   uint32_t *tilecnt;      // [tiles][4]
   uint32_t *tileoff;      // [tiles][4]
   RunEntry *runs;         // [K3_MAXBATCH][8]
@@ -71,9 +72,10 @@ struct TileOut {
   uint32_t has0[K3_NPT], has1[K3_NPT], hassym[K3_NPT];
   Node c0[K3_NPT], c1[K3_NPT];
   uint32_t kw[K3_NPT], ew[K3_NPT];
+  uint32_t raw[K3_NPT][3];   // scan mode: kw = sym, ew = k, raw = c1, c2, cs
 };
 
-template <bool PACK>
+template <bool PACK, bool SCAN>
 __device__ __forceinline__ void k3_classify(const K3Args &a, uint32_t p, uint32_t tile_in_plane, TileOut &t) {
   const uint32_t tid = threadIdx.x;
   const uint32_t c0n = a.ctl->cnt[a.par][p][0], c1n = a.ctl->cnt[a.par][p][1];
@@ -120,17 +122,22 @@ __device__ __forceinline__ void k3_classify(const K3Args &a, uint32_t p, uint32_
     t.has1[it] &= valid[it];
     t.hassym[it] = nf[it].need_mid & valid[it];
     t.kw[it] = t.ew[it] = 0;
-    if (PACK && t.hassym[it]) pack_symbol(cfg, p, sym, k, nf[it].n0x, nd[it].x1, nd[it].x0 + nd[it].x1, t.kw[it], t.ew[it]);
+    if (SCAN) {
+      t.kw[it] = sym; t.ew[it] = k;
+      t.raw[it][0] = nf[it].n0x; t.raw[it][1] = nd[it].x1; t.raw[it][2] = nd[it].x0 + nd[it].x1;
+    } else if (PACK && t.hassym[it]) {
+      pack_symbol(cfg, p, sym, k, nf[it].n0x, nd[it].x1, nd[it].x0 + nd[it].x1, t.kw[it], t.ew[it]);
+    }
   }
 }
 
 // Process one tile.  WRITE=false: count children/symbols.  WRITE=true: place them.
-template <bool WRITE>
+template <bool WRITE, bool SCAN>
 __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t tile_in_plane, uint32_t tile_global,
                                         uint32_t (*lds_cnt)[4][3]) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
   TileOut t;
-  k3_classify<WRITE>(a, p, tile_in_plane, t);
+  k3_classify<WRITE, SCAN>(a, p, tile_in_plane, t);
   uint32_t pre0[K3_NPT], pre1[K3_NPT], pres[K3_NPT];
   const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
@@ -172,15 +179,20 @@ __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t ti
       if (t.has0[it]) dst[o0 + b0 + pre0[it]] = t.c0[it];
       if (t.has1[it]) dst[a.capP - 1u - (o1 + b1 + pre1[it])] = t.c1[it];
       if (t.hassym[it]) {
-        a.symkey[os + bs + pres[it]] = t.kw[it];
-        a.symesc[os + bs + pres[it]] = t.ew[it];
+        if (SCAN) {
+          uint32_t *r = a.scanrec + (os + bs + pres[it]) * 5;
+          r[0] = t.kw[it]; r[1] = t.ew[it]; r[2] = t.raw[it][0]; r[3] = t.raw[it][1]; r[4] = t.raw[it][2];
+        } else {
+          a.symkey[os + bs + pres[it]] = t.kw[it];
+          a.symesc[os + bs + pres[it]] = t.ew[it];
+        }
       }
     }
   }
   __syncthreads();
 }
 
-template <bool WRITE>
+template <bool WRITE, bool SCAN>
 __global__ __launch_bounds__(K3_T) void k3_tiles_kernel(K3Args a) {
   __shared__ uint32_t tp[9];
   __shared__ uint32_t lds_cnt[K3_NPT][4][3];
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(K3_T) void k3_tiles_kernel(K3Args a) {
     uint32_t p = 0;
 #pragma unroll
     for (int k = 1; k < 8; ++k) p += (tile >= tp[k]) ? 1u : 0u;
-    k3_tile<WRITE>(a, p, tile - tp[p], tile, lds_cnt);
+    k3_tile<WRITE, SCAN>(a, p, tile - tp[p], tile, lds_cnt);
   }
 }
 
@@ -290,6 +302,7 @@ __device__ __forceinline__ uint64_t kt_block_excl_scan(uint64_t v, uint64_t *ws,
   return wbase + inc - v;
 }
 
+template <bool SCAN>
 __global__ __launch_bounds__(KT_T) void k3_tail_kernel(K3Args a, RunEntry *truns, uint32_t max_rounds) {
   __shared__ Node buf[2][K3_TAIL_CAP];
   __shared__ uint32_t cnt[2][8][2];
@@ -420,11 +433,16 @@ __global__ __launch_bounds__(KT_T) void k3_tail_kernel(K3Args a, RunEntry *truns
           if (so[it].has0) buf[cur ^ 1u][noff[pn] + (uint32_t)(rel & 0xFFFFu)] = so[it].c0;
           if (so[it].has1) buf[cur ^ 1u][noff[pn] + t0 + (uint32_t)((rel >> 16) & 0xFFFFu)] = so[it].c1;
           if (so[it].hassym) {
-            uint32_t kw, ew;
-            pack_symbol(cfgs[p], p, so[it].sym, so[it].k, so[it].ctx1, so[it].ctx2, so[it].ctxs, kw, ew);
             const uint64_t si = sym_total + ((run >> 32) & 0xFFFFu);
-            a.symkey[si] = kw;
-            a.symesc[si] = ew;
+            if (SCAN) {
+              uint32_t *r = a.scanrec + si * 5;
+              r[0] = so[it].sym; r[1] = so[it].k; r[2] = so[it].ctx1; r[3] = so[it].ctx2; r[4] = so[it].ctxs;
+            } else {
+              uint32_t kw, ew;
+              pack_symbol(cfgs[p], p, so[it].sym, so[it].k, so[it].ctx1, so[it].ctx2, so[it].ctxs, kw, ew);
+              a.symkey[si] = kw;
+              a.symesc[si] = ew;
+            }
           }
         }
         run += (uint64_t)so[it].has0 | ((uint64_t)so[it].has1 << 16) | ((uint64_t)so[it].hassym << 32);
@@ -466,6 +484,7 @@ static K3Args make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot) {
   a.cfg = c->dcfg.as<PlaneCfg>();
   a.symkey = c->skey[0].as<uint32_t>();
   a.symesc = c->sesc.as<uint32_t>();
+  a.scanrec = c->scanrec.as<uint32_t>();
   a.tilecnt = c->tilecnt.as<uint32_t>();
   a.tileoff = c->tileoff.as<uint32_t>();
   a.runs = c->runs.as<RunEntry>();
@@ -505,6 +524,7 @@ int k3_begin(bce_hip_ctx *c) {
   c->sym_cap = cap;
   BCE_TRY(ensure(c, c->skey[0], (size_t)cap * 4));
   BCE_TRY(ensure(c, c->sesc, (size_t)cap * 4));
+  if (c->scan_mode) BCE_TRY(ensure(c, c->scanrec, (size_t)cap * 20));
   // roots: (0, C[i], n - C[i]) with C[i] = zeros(plane (i+7)%8), only where both are non-zero (bce.cpp:1237-1240)
   EnumCtl ctl;
   memset(&ctl, 0, sizeof ctl);
@@ -538,9 +558,10 @@ int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint) {
   const uint32_t grid = (uint32_t)(want < 2048 ? want : 2048);
   for (uint32_t i = 0; i < count; ++i) {
     const K3Args a = make_args(c, c->round + i, i);
-    hipLaunchKernelGGL(k3_tiles_kernel<false>, dim3(grid), dim3(K3_T), 0, c->stream, a);
+    hipLaunchKernelGGL((k3_tiles_kernel<false, false>), dim3(grid), dim3(K3_T), 0, c->stream, a);
     hipLaunchKernelGGL(k3_scan_kernel, dim3(8), dim3(1024), 0, c->stream, a);
-    hipLaunchKernelGGL(k3_tiles_kernel<true>, dim3(grid), dim3(K3_T), 0, c->stream, a);
+    if (c->scan_mode) hipLaunchKernelGGL((k3_tiles_kernel<true, true>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+    else hipLaunchKernelGGL((k3_tiles_kernel<true, false>), dim3(grid), dim3(K3_T), 0, c->stream, a);
   }
   BCE_HIP_TRY(c, hipGetLastError());
   c->stats.k3_launches += 3.0 * count;
@@ -551,7 +572,8 @@ int k3_tail(bce_hip_ctx *c) {
   BCE_TRY(ensure(c, c->truns, (size_t)K3_TAIL_MAXROUNDS * 8 * sizeof(RunEntry)));
   if (!c->h_truns) BCE_HIP_TRY(c, hipHostMalloc(&c->h_truns, (size_t)K3_TAIL_MAXROUNDS * 8 * sizeof(RunEntry), hipHostMallocDefault));
   const K3Args a = make_args(c, c->round, 0);
-  hipLaunchKernelGGL(k3_tail_kernel, dim3(1), dim3(KT_T), 0, c->stream, a, c->truns.as<RunEntry>(), K3_TAIL_MAXROUNDS);
+  if (c->scan_mode) hipLaunchKernelGGL(k3_tail_kernel<true>, dim3(1), dim3(KT_T), 0, c->stream, a, c->truns.as<RunEntry>(), K3_TAIL_MAXROUNDS);
+  else hipLaunchKernelGGL(k3_tail_kernel<false>, dim3(1), dim3(KT_T), 0, c->stream, a, c->truns.as<RunEntry>(), K3_TAIL_MAXROUNDS);
   BCE_HIP_TRY(c, hipGetLastError());
   c->stats.k3_launches += 1.0;
   return BCE_HIP_OK;
@@ -603,6 +625,7 @@ int k3_grow_symbols(bce_hip_ctx *c, uint64_t cap) {
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
   BCE_TRY(ensure(c, c->skey[0], (size_t)cap * 4));
   BCE_TRY(ensure(c, c->sesc, (size_t)cap * 4));
+  if (c->scan_mode) BCE_TRY(ensure(c, c->scanrec, (size_t)cap * 20));
   c->sym_cap = cap;
   EnumCtl *d = c->ctl.as<EnumCtl>();
   BCE_HIP_TRY(c, hipMemcpyAsync(&d->sym_cap, &c->sym_cap, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));

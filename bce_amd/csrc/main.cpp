@@ -2,7 +2,7 @@
 //   bce -c archive.bce file [config.bcc]    compress on the MI355X through libbcehip.so
 // Banner, usage text, summary line, argument detection and exit codes follow the reference
 // (banner :1377-1379, -c :1403-1427, -d :1428-1472, usage :1473-1483).  -d uses the host decoder (decoder.cpp);
-// -s (ScanCoder) is outside this round's scope and says so.
+// -s runs the enumeration on the GPU in scan mode and the ScanCoder optimisation on the host (scan_coder.cpp).
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -104,8 +104,36 @@ int main(int argc, char **argv) {
     file.write(reinterpret_cast<const char *>(out.data()), (std::streamsize)out.size());
     return 0;
   } else if (argc == 4 && argv[1][0] == '-' && argv[1][1] == 's') {
-    printf("bce -s (ScanCoder) is not part of the MI355X hot path yet (see DESIGN.md, out of scope this round).\n");
-    return -5;
+    // Scan (bce.cpp:1384-1402): enumeration on the GPU, ScanCoder optimisation on the host, 288-byte config out
+    auto start = std::chrono::high_resolution_clock::now();
+    bce_hip_ctx *ctx = nullptr;
+    int rc = bce_hip_create(&ctx, 0);
+    if (rc != 0) { printf("No usable HIP device: %s\n", bce_hip_strerror(rc)); return -3; }
+    std::ifstream file(argv[3], std::ios::binary | std::ios::ate);
+    std::streamoff fsize = file ? (std::streamoff)file.tellg() : -1;
+    std::vector<uint8_t> data;
+    bool ok = fsize > 0 && fsize < (std::streamoff)0x80000000ll;
+    if (ok) {
+      data.resize((size_t)fsize);
+      file.seekg(0, std::ios::beg);
+      ok = (bool)file.read(reinterpret_cast<char *>(data.data()), fsize);
+    }
+    if (!ok) { printf("Error loading file\n"); bce_hip_destroy(ctx); return -1; }
+    uint8_t cfg[BCE_HIP_CONFIG_BYTES];
+    double res[9];
+    rc = bce_hip_load_host(ctx, data.data(), (uint32_t)data.size());
+    if (rc == 0) rc = bce_hip_bwt(ctx, nullptr);
+    if (rc == 0) rc = bce_hip_build_planes(ctx, nullptr);
+    if (rc == 0) rc = bce_hip_scan(ctx, cfg, res);
+    if (rc != 0) { printf("Scan failed: %s (%s)\n", bce_hip_strerror(rc), bce_hip_last_error(ctx)); bce_hip_destroy(ctx); return -4; }
+    for (int i = 0; i < 9; ++i) printf("Result size: %.1f B\n", res[i]);            // ScanCoder::flush, :799
+    std::ofstream f(std::string(argv[2]), std::ios::binary | std::ios::trunc);     // save_config, :810-813
+    f.write(reinterpret_cast<const char *>(cfg), BCE_HIP_CONFIG_BYTES);
+    auto end = std::chrono::high_resolution_clock::now();
+    std::chrono::duration<double> duration = end - start;
+    printf("Scanned %zu B in %.1f s\n", data.size(), duration.count());
+    bce_hip_destroy(ctx);
+    return 0;
   }
   return usage();
 }

@@ -99,6 +99,13 @@ int bce_hip_enum_symbols(bce_hip_ctx *ctx, uint32_t *out, uint64_t cap_records, 
 /* run K4 on the symbols emitted so far: out[3*i+0..2] = cum, freq, total per record (same order) */
 int bce_hip_enum_model(bce_hip_ctx *ctx, uint32_t *out, uint64_t cap_records, uint64_t *count);
 
+/* ---- config scan (SURVEY section 8f "next #2") ---------------------------------------------------------------- */
+/* main() -s branch (bce.cpp:1384-1402): BCE<ScanCoder<31>, noop>::encode + ScanCoder::save_config
+ * (bce.cpp:726-834).  Call after bce_hip_build_planes: the enumeration runs on the GPU, the eight ScanCoders and
+ * their cost optimisation on the host.  config288 = the .bcc file content; result_bytes[9] (optional) = the values
+ * of the nine "Result size: %.1f B" lines (bce.cpp:799). */
+int bce_hip_scan(bce_hip_ctx *ctx, uint8_t config288[BCE_HIP_CONFIG_BYTES], double result_bytes[9]);
+
 /* ---- decoder (SURVEY section 8f "next #1"; host C++ this round, not a GPU path) ------------------------------ */
 /* BCE::decode + unbwt::bytewise + inverse BWT + rotate (bce.cpp:1169-1233, 1043-1102): archive -> original bytes.
  * out == NULL: only report the decoded size in *out_len.  Needs no context and no GPU. */

@@ -12,8 +12,8 @@ _lib = None
 
 def build(force=False):
     """Compile the oracle with gcc (no GPU toolchain involved)."""
-    src = os.path.join(_HERE, "bce_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("bce_oracle.c", "scan_oracle.cpp", "Makefile")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -39,6 +39,8 @@ def lib():
             f.argtypes = [C.POINTER(u32p)]
             f.restype = C.c_size_t
         L.bce_oracle_trace_rounds.restype = C.c_uint32
+        L.bce_oracle_scan.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_double)]
+        L.bce_oracle_scan.restype = C.c_int
         L.bce_oracle_synth_rand.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t]
         L.bce_oracle_synth_text.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t]
         _lib = L
@@ -129,6 +131,17 @@ def trace_encode_from_bwt(bwt, offset, config=None):
     finally:
         L.bce_oracle_trace_end()
         L.bce_oracle_trace_free()
+
+
+def scan(data):
+    """Reference `bce -s` on an in-memory buffer -> (288-byte config, the nine "Result size" values in bytes)."""
+    a, p = _buf(data)
+    cfg = np.zeros(288, dtype=np.uint8)
+    res = (C.c_double * 9)()
+    rc = lib().bce_oracle_scan(p, len(a), cfg.ctypes.data_as(C.c_void_p), res)
+    if rc != 0:
+        raise ValueError("oracle scan failed")
+    return cfg.tobytes(), list(res)
 
 
 def synth_rand(seed: int, n: int) -> bytes:

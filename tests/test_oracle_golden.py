@@ -46,3 +46,18 @@ def test_oracle_bwt_is_cyclic_rotation_bwt():
 def test_oracle_rejects_empty():
     with pytest.raises(ValueError):
         oracle.compress(b"")
+
+
+def test_oracle_scan_matches_reference_config():
+    """`bce -s` (ScanCoder, Q11): the .bcc and the archive compressed with it, against SURVEY 8c."""
+    import json, os
+    from conftest import ROOT
+    v = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["scan_vectors"][0]
+    d = oracle.synth_text(v["seed"], v["n"])
+    assert hashlib.sha256(d).hexdigest() == v["input_sha256"]
+    cfg, res = oracle.scan(d)
+    h = hashlib.sha256(cfg).hexdigest()
+    assert h.startswith(v["config_sha256_prefix"]) and h.endswith(v["config_sha256_suffix"])
+    a = oracle.compress(d, cfg)
+    assert len(a) == v["archive_bytes"] and hashlib.sha256(a).hexdigest() == v["archive_sha256"]
+    assert len(res) == 9 and res[8] == 0.0
