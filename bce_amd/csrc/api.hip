@@ -91,7 +91,7 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   DevBuf *bufs[] = {&c->text, &c->bwt, &c->sa[0], &c->sa[1], &c->key[0], &c->key[1], &c->rank, &c->k2, &c->nrk, &c->act[0], &c->act[1],
                     &c->rs_hist, &c->blk, &c->ptmp[0], &c->ptmp[1], &c->gran, &c->nodes, &c->ctl, &c->tilecnt,
                     &c->tileoff, &c->runs, &c->truns, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
-                    &c->sesc, &c->stat, &c->dcfg, &c->k4w, &c->scanrec};
+                    &c->sesc, &c->stat, &c->dcfg, &c->k4w, &c->scanrec, &c->dfs};
   for (DevBuf *b : bufs) release(*b);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   if (c->h_runs) (void)hipHostFree(c->h_runs);
@@ -164,6 +164,7 @@ int bce_hip_set_bwt(bce_hip_ctx *c, const uint8_t *bwt, uint32_t n, uint32_t off
   BCE_TRY(ensure(c, c->bwt, n));
   BCE_HIP_TRY(c, hipMemcpy(c->bwt.p, bwt, n, hipMemcpyHostToDevice));
   c->n = n; c->offset = offset; c->stage = 2; c->enum_active = false;
+  c->k1_unique = false;                          // no suffix array behind an injected BWT
   c->archive.clear();
   memset(&c->stats, 0, sizeof c->stats);
   c->stats.n = n;
@@ -288,7 +289,29 @@ int bce_hip_encode(bce_hip_ctx *c) {
   for (int i = 0; i < 8; ++i) cur_nodes += (C[i] && n - C[i]) ? 1 : 0;
   EnumCtl ctl;
   bool decaying = false;
+  bool have_ctl = false;
   for (;;) {
+    if (have_ctl && decaying && !ctl.need_flush && ctl.done_round == 0xFFFFFFFFu) {
+      // few live nodes and almost everything visited: finish depth-first (k3_dfs.hip).  The walkers' symbols
+      // come after everything emitted so far, so flush that first.
+      const uint64_t all = 8ull * (n - 1);
+      if (ctl.next_nodes && ctl.next_nodes <= 8192 && all >= ctl.nodes_total && all - ctl.nodes_total <= (8u << 20)) {
+        BCE_TRY(flush_symbols(c, ctl.sym_total));
+        ctl.sym_total = 0;
+        bool dfs_done = false;
+        BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        BCE_TRY(k3_dfs_tail(c, ctl, &dfs_done));
+        BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        BCE_HIP_TRY(c, hipEventSynchronize(c->ev1));
+        { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms; }
+        if (dfs_done) {
+          BCE_TRY(k3_sync_ctl(c, &ctl));
+          BCE_TRY(flush_symbols(c, ctl.sym_total));
+          break;
+        }
+        decaying = false;                         // walker gave up (stack / symbol capacity): carry on with rounds
+      }
+    }
     const uint32_t first = c->round;
     uint32_t executed = 0;
     static const bool use_tail = getenv("BCE_HIP_NO_TAIL") == nullptr;
@@ -314,6 +337,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
     if (ctl.overflow) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
     c->round = first + executed;
     decaying = ctl.next_nodes <= cur_nodes && c->round > 16;   // past the ramp-up: the node count no longer doubles
+    have_ctl = true;
     cur_nodes = ctl.next_nodes;
     const bool done = ctl.done_round != 0xFFFFFFFFu;
     if (ctl.need_flush) {

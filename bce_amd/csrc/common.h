@@ -67,6 +67,8 @@ struct bce_hip_ctx {
   uint8_t config[9][32];
   bce::PlaneCfg cfg[8];
   uint32_t zeros[8] = {0};
+  bool k1_unique = false;                        // K1 ended with all rotations distinct: sa[sa_res] / rank are SA / ISA
+  int sa_res = 0;
   uint64_t sym_cap_user = 0;
 
   // device buffers (grow-only)
@@ -79,6 +81,7 @@ struct bce_hip_ctx {
   bce::DevBuf nodes;                             // 2 parities x 8 planes x capP nodes
   uint32_t capP = 0;
   bce::DevBuf ctl, tilecnt, tileoff, runs;       // K3 control
+  bce::DevBuf dfs;                               // depth-first tail: tagged symbols, sort scratch, walker stacks
   bce::DevBuf truns;                             // run table of the persistent tail kernel [K3_TAIL_MAXROUNDS][8]
   void *h_truns = nullptr;
   bce::DevBuf skey[2], sval[2], sout, sesc;       // K3->K4: symbol keys (skey[0]) + escape words (sesc); sort ping-pong; outputs
@@ -151,6 +154,7 @@ int k2_get_plane_bits(bce_hip_ctx *c, int plane, uint8_t *out);
 int k2_rank1(bce_hip_ctx *c, int plane, const uint32_t *idx, uint32_t count, uint32_t *out);
 int k3_begin(bce_hip_ctx *c);                       // k3_enumerate.hip
 int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint);   // queue `count` rounds from c->round (no sync)
+int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, bool *done);   // k3_dfs.hip: finish the enumeration depth-first
 int k3_tail(bce_hip_ctx *c);                        // queue the persistent narrow-round kernel from c->round (no sync)
 int k3_fetch_tail_runs(bce_hip_ctx *c, uint32_t rounds);
 int k3_sync_ctl(bce_hip_ctx *c, EnumCtl *out);      // copy the control block back (syncs the stream)

@@ -263,6 +263,7 @@ int k1_bwt(bce_hip_ctx *c) {
   BCE_TRY(ensure(c, c->bwt, n));
   uint8_t *bwt = c->bwt.as<uint8_t>();
   c->stats.sort_rounds = 0;
+  c->k1_unique = false;
   if (n == 1) {
     BCE_HIP_TRY(c, hipMemcpyAsync(bwt, T, 1, hipMemcpyDeviceToDevice, c->stream));
     BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -378,6 +379,9 @@ int k1_bwt(bce_hip_ctx *c) {
   BCE_HIP_TRY(c, hipGetLastError());
   if (off >= n) { snprintf(c->err, sizeof c->err, "k1: no rank-0 rotation found"); return BCE_HIP_E_INTERNAL; }
   c->offset = off;
+  // all rotations distinct <=> rank[] is the inverse of the suffix array (used by the depth-first tail of K3)
+  c->k1_unique = (groups >= n) || (have_list && m == 0);
+  c->sa_res = res;
   return BCE_HIP_OK;
 }
 

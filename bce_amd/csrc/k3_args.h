@@ -1,0 +1,37 @@
+// k3_args.h -- kernel argument block and constants shared by the K3 kernels (k3_enumerate.hip, k3_dfs.hip).
+#pragma once
+#include "common.h"
+
+namespace bce {
+
+constexpr int K3_T = 256;
+#ifndef K3_NPT_VALUE
+#define K3_NPT_VALUE 4
+#endif
+constexpr int K3_NPT = K3_NPT_VALUE;            // nodes per thread
+constexpr uint32_t K3_TILE = K3_T * K3_NPT;     // 1024 nodes per tile
+constexpr uint32_t K3_MAXBATCH = 256;           // rounds per run-table batch
+
+struct K3Args {
+  EnumCtl *ctl;
+  Node *nodes;            // [2][8][capP]
+  const Granule *gran;    // [8][ngran]
+  const PlaneCfg *cfg;    // [8]
+  uint32_t *symkey;       // symbol records: key words (K4 sort input)
+  uint32_t *symesc;       // symbol records: escape words
+  uint32_t *scanrec;      // scan mode (`bce -s`): raw (sym, k, c1, c2, cs) per record instead of key/escape words
+  uint32_t *tilecnt;      // [tiles][4]
+  uint32_t *tileoff;      // [tiles][4]
+  RunEntry *runs;         // [K3_MAXBATCH][8]
+  uint32_t capP, ngran, n;
+  uint32_t zeros[8];
+  uint32_t par, round, run_slot;
+};
+
+__device__ __forceinline__ Node *plane_nodes(const K3Args &a, uint32_t par, uint32_t p) {
+  return a.nodes + ((size_t)(par * 8u + p)) * a.capP;
+}
+
+K3Args k3_make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot);   // k3_enumerate.hip
+
+}  // namespace bce

@@ -20,36 +20,9 @@
 
 #include "common.h"
 #include "scan_util.h"
+#include "k3_args.h"
 
 namespace bce {
-
-constexpr int K3_T = 256;
-#ifndef K3_NPT_VALUE
-#define K3_NPT_VALUE 4
-#endif
-constexpr int K3_NPT = K3_NPT_VALUE;            // nodes per thread
-constexpr uint32_t K3_TILE = K3_T * K3_NPT;     // 1024 nodes per tile
-constexpr uint32_t K3_MAXBATCH = 256;           // rounds per run-table batch
-
-struct K3Args {
-  EnumCtl *ctl;
-  Node *nodes;            // [2][8][capP]
-  const Granule *gran;    // [8][ngran]
-  const PlaneCfg *cfg;    // [8]
-  uint32_t *symkey;       // symbol records: key words (K4 sort input)
-  uint32_t *symesc;       // symbol records: escape words
-  uint32_t *scanrec;      // scan mode (`bce -s`): raw (sym, k, c1, c2, cs) per record instead of key/escape words
-  uint32_t *tilecnt;      // [tiles][4]
-  uint32_t *tileoff;      // [tiles][4]
-  RunEntry *runs;         // [K3_MAXBATCH][8]
-  uint32_t capP, ngran, n;
-  uint32_t zeros[8];
-  uint32_t par, round, run_slot;
-};
-
-__device__ __forceinline__ Node *plane_nodes(const K3Args &a, uint32_t par, uint32_t p) {
-  return a.nodes + ((size_t)(par * 8u + p)) * a.capP;
-}
 
 // tile -> plane lookup table: tp[p] = first tile of plane p, tp[8] = total tiles
 __device__ __forceinline__ void tile_prefix(const K3Args &a, uint32_t tp[9]) {
@@ -476,7 +449,7 @@ __global__ __launch_bounds__(KT_T) void k3_tail_kernel(K3Args a, RunEntry *truns
   }
 }
 
-static K3Args make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot) {
+K3Args k3_make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot) {
   K3Args a;
   a.ctl = c->ctl.as<EnumCtl>();
   a.nodes = c->nodes.as<Node>();
@@ -557,7 +530,7 @@ int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint) {
   uint64_t want = nodes_hint ? (nodes_hint * 2 + K3_TILE - 1) / K3_TILE + 16 : 2048;
   const uint32_t grid = (uint32_t)(want < 2048 ? want : 2048);
   for (uint32_t i = 0; i < count; ++i) {
-    const K3Args a = make_args(c, c->round + i, i);
+    const K3Args a = k3_make_args(c, c->round + i, i);
     hipLaunchKernelGGL((k3_tiles_kernel<false, false>), dim3(grid), dim3(K3_T), 0, c->stream, a);
     hipLaunchKernelGGL(k3_scan_kernel, dim3(8), dim3(1024), 0, c->stream, a);
     if (c->scan_mode) hipLaunchKernelGGL((k3_tiles_kernel<true, true>), dim3(grid), dim3(K3_T), 0, c->stream, a);
@@ -571,7 +544,7 @@ int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint) {
 int k3_tail(bce_hip_ctx *c) {
   BCE_TRY(ensure(c, c->truns, (size_t)K3_TAIL_MAXROUNDS * 8 * sizeof(RunEntry)));
   if (!c->h_truns) BCE_HIP_TRY(c, hipHostMalloc(&c->h_truns, (size_t)K3_TAIL_MAXROUNDS * 8 * sizeof(RunEntry), hipHostMallocDefault));
-  const K3Args a = make_args(c, c->round, 0);
+  const K3Args a = k3_make_args(c, c->round, 0);
   if (c->scan_mode) hipLaunchKernelGGL(k3_tail_kernel<true>, dim3(1), dim3(KT_T), 0, c->stream, a, c->truns.as<RunEntry>(), K3_TAIL_MAXROUNDS);
   else hipLaunchKernelGGL(k3_tail_kernel<false>, dim3(1), dim3(KT_T), 0, c->stream, a, c->truns.as<RunEntry>(), K3_TAIL_MAXROUNDS);
   BCE_HIP_TRY(c, hipGetLastError());
