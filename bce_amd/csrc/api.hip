@@ -289,13 +289,13 @@ int bce_hip_encode(bce_hip_ctx *c) {
   for (int i = 0; i < 8; ++i) cur_nodes += (C[i] && n - C[i]) ? 1 : 0;
   EnumCtl ctl;
   bool decaying = false;
-  bool have_ctl = false;
+  bool have_ctl = false, dfs_ok = true;
   for (;;) {
     if (have_ctl && decaying && !ctl.need_flush && ctl.done_round == 0xFFFFFFFFu) {
       // few live nodes and almost everything visited: finish depth-first (k3_dfs.hip).  The walkers' symbols
       // come after everything emitted so far, so flush that first.
       const uint64_t all = 8ull * (n - 1);
-      if (ctl.next_nodes && ctl.next_nodes <= 8192 && all >= ctl.nodes_total && all - ctl.nodes_total <= (8u << 20)) {
+      if (dfs_ok && ctl.next_nodes && ctl.next_nodes <= 8192 && ctl.nodes_total >= all / 8) {
         BCE_TRY(flush_symbols(c, ctl.sym_total));
         ctl.sym_total = 0;
         bool dfs_done = false;
@@ -309,7 +309,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
           BCE_TRY(flush_symbols(c, ctl.sym_total));
           break;
         }
-        decaying = false;                         // walker gave up (stack / symbol capacity): carry on with rounds
+        dfs_ok = false;                           // a walker gave up (stack / symbols / budget): carry on with rounds
       }
     }
     const uint32_t first = c->round;

@@ -23,12 +23,12 @@ constexpr int KD_T = 64;                       // one wave per block: walkers sp
 constexpr uint32_t KD_STACK = 192;             // pending siblings per walker
 constexpr uint32_t KD_MAXX = 8;                // rows compared for a chain skip
 constexpr uint32_t K3_DFS_ENTER = 8192;        // live nodes at which the depth-first tail may start
-constexpr uint64_t K3_DFS_REMAIN = 8u << 20;   // ... if at most this many of the 8n-8 nodes remain
+constexpr uint32_t K3_DFS_BUDGET = 1u << 18;   // nodes one walker may classify before the attempt is abandoned
 constexpr uint32_t K3_DFS_SYMCAP = 4u << 20;   // tagged symbols
 
 struct DfsCtl {
   uint32_t nsym;         // tagged symbols emitted
-  uint32_t err;          // 1 stack overflow, 2 symbol capacity
+  uint32_t err;          // 1 stack overflow, 2 symbol capacity, 3 a walker exceeded its budget (bushy subtree)
   uint64_t nodes;        // nodes visited (skipped pass-through nodes included)
   uint64_t maxround;
   uint32_t cntp[8];      // symbols per plane
@@ -48,21 +48,31 @@ struct DfsArgs {
   uint32_t symcap;
 };
 
-// number of bytes on which the rotations starting at p and q agree going BACKWARDS (cyclic), capped at lim
-__device__ __forceinline__ uint32_t lce_back(const uint8_t *__restrict__ T, uint32_t n, uint32_t p, uint32_t q, uint32_t lim) {
+// Number of bytes on which the rotations starting at p and q agree going BACKWARDS (cyclic), capped at lim.
+// Executed by the WHOLE wave with uniform arguments: while neither side wraps, each of the 64 lanes compares 16
+// bytes, i.e. 1 KB per step (a multi-megabyte repeat is a few thousand steps); the rest goes byte by byte.
+__device__ __forceinline__ uint32_t ld32u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+__device__ __forceinline__ uint32_t lce_back_wave(const uint8_t *__restrict__ T, uint32_t n, uint32_t p, uint32_t q,
+                                                  uint32_t lim, uint32_t lane) {
   uint32_t t = 0;
-  // positions p-1-t, q-1-t; stay in the non-wrapping region with 4-byte steps as long as possible
-  while (t + 4 <= lim && p >= t + 4 && q >= t + 4) {
-    const uint8_t *a = T + (p - t - 4), *b = T + (q - t - 4);
-    const uint32_t va = (uint32_t)a[0] | ((uint32_t)a[1] << 8) | ((uint32_t)a[2] << 16) | ((uint32_t)a[3] << 24);
-    const uint32_t vb = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
-    if (va != vb) {
-      const uint32_t d = va ^ vb;              // the highest differing byte is the nearest one going backwards
-      return t + ((uint32_t)__clz((int)d) >> 3);
+  while (t + 1024 <= lim && p >= t + 1024 && q >= t + 1024) {
+    // lane L owns the bytes at distances [t + 16 L, t + 16 L + 16), i.e. addresses p - t - 16 L - 16 .. + 15
+    const uint8_t *a = T + (p - t - 16u * lane - 16u), *b = T + (q - t - 16u * lane - 16u);
+    uint32_t match = 16;                                   // bytes matching from the NEAREST (highest address) end
+#pragma unroll
+    for (int w = 3; w >= 0; --w) {
+      const uint32_t d = ld32u(a + 4 * w) ^ ld32u(b + 4 * w);
+      if (d && match == 16) match = (uint32_t)(3 - w) * 4u + ((uint32_t)__clz((int)d) >> 3);
     }
-    t += 4;
+    const uint64_t mm = __ballot(match < 16);
+    if (mm) {
+      const uint32_t L = (uint32_t)__ffsll((long long)mm) - 1u;     // nearest lane with a mismatch
+      return t + 16u * L + (uint32_t)__builtin_amdgcn_readlane((int)match, (int)L);
+    }
+    t += 1024;
   }
-  while (t < lim) {
+  while (t < lim) {                                         // uniform scalar tail (wrap-around, last < 1 KB)
     const uint32_t ip = p >= t + 1 ? p - t - 1 : p + n - t - 1;
     const uint32_t iq = q >= t + 1 ? q - t - 1 : q + n - t - 1;
     if (T[ip] != T[iq]) break;
@@ -74,6 +84,7 @@ __device__ __forceinline__ uint32_t lce_back(const uint8_t *__restrict__ T, uint
 __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   const K3Args &k = a.k;
   const EnumCtl *ctl = k.ctl;
+  const uint32_t lane = threadIdx.x & 63u;
   const uint32_t gid = blockIdx.x * KD_T + threadIdx.x;
   // my start node: flattened index over the planes' lists
   uint32_t acc = 0, p0 = 8, idx = 0;
@@ -83,9 +94,9 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
     if (p0 == 8 && gid < acc + m) { p0 = p; idx = gid - acc; }
     acc += m;
   }
-  if (p0 == 8) return;
-  DNode cur;
-  {
+  bool alive = p0 != 8;
+  DNode cur{0u, 1u, 1u, 1u, 0ull};
+  if (alive) {
     const uint32_t c0 = ctl->cnt[k.par][p0][0];
     const Node nd = plane_nodes(k, k.par, p0)[idx < c0 ? idx : (k.capP - 1u - (idx - c0))];
     cur.s = nd.s; cur.x0 = nd.x0; cur.x1 = nd.x1; cur.plane = p0; cur.round = a.round0;
@@ -93,54 +104,69 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   DNode *stack = a.stacks + (size_t)gid * KD_STACK;
   uint32_t sp = 0;
   uint64_t nodes = 0, maxround = 0;
+  uint32_t visited = 0;
   const uint32_t n = k.n;
-  for (;;) {
-    if (a.skip_ok && cur.plane == 0) {
-      const uint32_t x = cur.x0 + cur.x1;
-      if (x <= KD_MAXX) {
+  // All 64 lanes stay in the loop until every walker of the wave is finished: finished lanes help with the
+  // cooperative text comparisons.
+  while (__any(alive)) {
+    if (alive && (++visited > K3_DFS_BUDGET || a.dctl->err)) { if (!a.dctl->err) a.dctl->err = 3; alive = false; }
+    // ---- chain skip: lanes at plane 0 with few rows, served one after the other by the whole wave ----
+    const uint32_t x = cur.x0 + cur.x1;
+    uint64_t want = __ballot(alive && a.skip_ok && cur.plane == 0 && x <= KD_MAXX);
+    uint32_t mykk = 0;
+    while (want) {
+      const int L = __ffsll((long long)want) - 1;
+      want &= want - 1;
+      const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)cur.s, L);
+      const uint32_t xL = (uint32_t)__builtin_amdgcn_readlane((int)x, L);
+      const uint32_t pa = a.sa[sL];
+      uint32_t kk = n - 1;
+      for (uint32_t i = 1; i < xL && kk; ++i) kk = lce_back_wave(a.text, n, pa, a.sa[sL + i], kk, lane);
+      if ((int)lane == L) mykk = kk;
+    }
+    if (alive) {
+      if (mykk) {                                    // mykk whole bytes of pass-through: 8*mykk rounds, no symbols
         const uint32_t pa = a.sa[cur.s];
-        uint32_t kk = n - 1;
-        for (uint32_t i = 1; i < x && kk; ++i) kk = lce_back(a.text, n, pa, a.sa[cur.s + i], kk);
-        if (kk) {                                  // kk whole bytes of pass-through: 8*kk rounds, no symbols
-          cur.s = a.isa[pa >= kk ? pa - kk : pa + n - kk];
-          cur.round += 8ull * kk;
-          nodes += 8ull * kk;
+        cur.s = a.isa[pa >= mykk ? pa - mykk : pa + n - mykk];
+        cur.round += 8ull * mykk;
+        nodes += 8ull * mykk;
+      }
+      const uint32_t p = cur.plane;
+      const Granule *G = k.gran + (size_t)p * k.ngran;
+      const Node nd{cur.s, cur.x0, cur.x1};
+      const uint32_t ga = div96(nd.s), gb = div96(nd.s + nd.x0 + nd.x1), gm = div96(nd.s + nd.x0);
+      const Granule qa = G[ga], qb = G[gb];
+      NodeFlat nf;
+      node_flat_pre(nd, granule_rank1(qa, nd.s - ga * 96u), granule_rank1(qb, nd.s + nd.x0 + nd.x1 - gb * 96u), nf);
+      Granule qm = gm == ga ? qa : qb;
+      if (nf.need_mid && gm != ga && gm != gb) qm = G[gm];
+      uint32_t has0, has1, sym, kq;
+      Node c0, c1;
+      node_flat_post(nd, k.zeros[p], nf, granule_rank1(qm, nd.s + nd.x0 - gm * 96u), has0, c0, has1, c1, sym, kq);
+      ++nodes;
+      maxround = cur.round > maxround ? cur.round : maxround;
+      if (nf.need_mid) {
+        const uint32_t i = atomicAdd(&a.dctl->nsym, 1u);
+        if (i >= a.symcap) { a.dctl->err = 2; alive = false; }
+        else {
+          uint32_t kw, ew;
+          pack_symbol(k.cfg[p], p, sym, kq, nf.n0x, nd.x1, nd.x0 + nd.x1, kw, ew);
+          a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = nd.s;
+          a.trlo[i] = (uint32_t)cur.round;
+          a.trhi[i] = (uint32_t)(cur.round >> 32) | (p << 8);      // round < 2^40
+          atomicAdd(&a.dctl->cntp[p], 1u);
         }
       }
+      const uint32_t pn = (p + 1u) & 7u;
+      if (has0 && has1) {
+        if (sp >= KD_STACK) { a.dctl->err = 1; alive = false; }
+        else stack[sp++] = DNode{c1.s, c1.x0, c1.x1, pn, cur.round + 1};
+      }
+      if (has0) { cur = DNode{c0.s, c0.x0, c0.x1, pn, cur.round + 1}; }
+      else if (has1) { cur = DNode{c1.s, c1.x0, c1.x1, pn, cur.round + 1}; }
+      else if (sp) { cur = stack[--sp]; }
+      else alive = false;
     }
-    const uint32_t p = cur.plane;
-    const Granule *G = k.gran + (size_t)p * k.ngran;
-    const Node nd{cur.s, cur.x0, cur.x1};
-    const uint32_t ga = div96(nd.s), gb = div96(nd.s + nd.x0 + nd.x1), gm = div96(nd.s + nd.x0);
-    const Granule qa = G[ga], qb = G[gb];
-    NodeFlat nf;
-    node_flat_pre(nd, granule_rank1(qa, nd.s - ga * 96u), granule_rank1(qb, nd.s + nd.x0 + nd.x1 - gb * 96u), nf);
-    Granule qm = gm == ga ? qa : qb;
-    if (nf.need_mid && gm != ga && gm != gb) qm = G[gm];
-    uint32_t has0, has1, sym, kq;
-    Node c0, c1;
-    node_flat_post(nd, k.zeros[p], nf, granule_rank1(qm, nd.s + nd.x0 - gm * 96u), has0, c0, has1, c1, sym, kq);
-    ++nodes;
-    maxround = cur.round > maxround ? cur.round : maxround;
-    if (nf.need_mid) {
-      const uint32_t i = atomicAdd(&a.dctl->nsym, 1u);
-      if (i >= a.symcap) { a.dctl->err = 2; break; }
-      uint32_t kw, ew;
-      pack_symbol(k.cfg[p], p, sym, kq, nf.n0x, nd.x1, nd.x0 + nd.x1, kw, ew);
-      a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = nd.s;
-      a.trlo[i] = (uint32_t)cur.round;
-      a.trhi[i] = (uint32_t)(cur.round >> 32) | (p << 8);      // round < 2^40
-      atomicAdd(&a.dctl->cntp[p], 1u);
-    }
-    const uint32_t pn = (p + 1u) & 7u;
-    if (has0 && has1) {
-      if (sp >= KD_STACK) { a.dctl->err = 1; break; }
-      stack[sp++] = DNode{c1.s, c1.x0, c1.x1, pn, cur.round + 1};
-    }
-    if (has0) { cur = DNode{c0.s, c0.x0, c0.x1, pn, cur.round + 1}; }
-    else if (has1) { cur = DNode{c1.s, c1.x0, c1.x1, pn, cur.round + 1}; }
-    else if (sp) { cur = stack[--sp]; }
-    else break;
   }
   atomicAdd((unsigned long long *)&a.dctl->nodes, (unsigned long long)nodes);
   atomicMax((unsigned long long *)&a.dctl->maxround, (unsigned long long)maxround);
@@ -164,8 +190,11 @@ __global__ void kd_place_kernel(const uint32_t *__restrict__ tkey, const uint32_
   }
 }
 
-// Host side.  Preconditions (checked by the caller): the symbol buffer is empty (everything emitted so far has
-// been flushed), `ctl` is current.  On success the symbol buffer holds the tail's symbols in stream order,
+// Host side.  The walkers start when the node count has stopped growing, at most K3_DFS_ENTER nodes are alive and
+// an eighth of all nodes has been visited (i.e. not in the ramp-up); a walker that meets a bushy subtree instead
+// of chains gives up after K3_DFS_BUDGET nodes and the attempt is abandoned.
+// Preconditions (checked by the caller): the symbol buffer is empty (everything emitted so far has been flushed),
+// `ctl` is current.  On success the symbol buffer holds the tail's symbols in stream order,
 // run_log holds one run per plane, and *done = true.  On a walker error nothing has been changed and the caller
 // continues with the round-based kernels.
 int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, bool *done) {
@@ -176,7 +205,7 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, bool *done) {
   const uint32_t n = c->n;
   const uint32_t live = ctl.next_nodes;
   const uint64_t all = 8ull * (n - 1);
-  if (live == 0 || live > K3_DFS_ENTER || all < ctl.nodes_total || all - ctl.nodes_total > K3_DFS_REMAIN) return BCE_HIP_OK;
+  if (live == 0 || live > K3_DFS_ENTER || ctl.nodes_total < all / 8) return BCE_HIP_OK;
   const uint32_t cap = K3_DFS_SYMCAP;
   // carve: tkey tesc ts trlo trhi | sort keys x2 vals x2 | DfsCtl | stacks
   const size_t o_sort = (size_t)cap * 4 * 5, o_ctl = o_sort + (size_t)cap * 4 * 4, o_stack = o_ctl + 256;
