@@ -138,6 +138,18 @@ int bce_hip_set_config(bce_hip_ctx *c, const uint8_t *config288) {
   return BCE_HIP_OK;
 }
 
+int bce_hip_debug_set(bce_hip_ctx *c, int knob, uint32_t value) {
+  if (!c) return BCE_HIP_E_ARG;
+  switch (knob) {
+    case 0: c->dbg_dfs_budget = value; break;
+    case 1: c->dbg_no_dfs = value; break;
+    case 2: c->dbg_no_tail = value; break;
+    case 3: c->dbg_no_skip = value; break;
+    default: return BCE_HIP_E_ARG;
+  }
+  return BCE_HIP_OK;
+}
+
 int bce_hip_set_symbol_capacity(bce_hip_ctx *c, uint64_t records) {
   if (!c || records >= (1ull << 31)) return BCE_HIP_E_ARG;
   c->sym_cap_user = records;
@@ -164,7 +176,7 @@ int bce_hip_set_bwt(bce_hip_ctx *c, const uint8_t *bwt, uint32_t n, uint32_t off
   BCE_TRY(ensure(c, c->bwt, n));
   BCE_HIP_TRY(c, hipMemcpy(c->bwt.p, bwt, n, hipMemcpyHostToDevice));
   c->n = n; c->offset = offset; c->stage = 2; c->enum_active = false;
-  c->k1_unique = false;                          // no suffix array behind an injected BWT
+  c->k1_unique = false; c->k1_valid = false;     // no suffix array behind an injected BWT
   c->archive.clear();
   memset(&c->stats, 0, sizeof c->stats);
   c->stats.n = n;
@@ -316,7 +328,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
     uint32_t executed = 0;
     static const bool use_tail = getenv("BCE_HIP_NO_TAIL") == nullptr;
     BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    if (use_tail && cur_nodes <= K3_TAIL_ENTER) {
+    if (use_tail && !c->dbg_no_tail && cur_nodes <= K3_TAIL_ENTER) {
       // narrow phase: the persistent single-workgroup kernel loops over rounds on the device
       BCE_TRY(k3_tail(c));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));

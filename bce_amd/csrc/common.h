@@ -67,8 +67,11 @@ struct bce_hip_ctx {
   uint8_t config[9][32];
   bce::PlaneCfg cfg[8];
   uint32_t zeros[8] = {0};
-  bool k1_unique = false;                        // K1 ended with all rotations distinct: sa[sa_res] / rank are SA / ISA
+  bool k1_unique = false;                        // K1 ended with all rotations distinct
+  bool k1_valid = false;                         // sa[sa_res] / rank hold this input's suffix order (K1 ran; no injected BWT)
   int sa_res = 0;
+  // debug knobs (bce_hip_debug_set): 0 = default
+  uint32_t dbg_dfs_budget = 0, dbg_no_dfs = 0, dbg_no_tail = 0, dbg_no_skip = 0;
   uint64_t sym_cap_user = 0;
 
   // device buffers (grow-only)

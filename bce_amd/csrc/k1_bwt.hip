@@ -264,6 +264,7 @@ int k1_bwt(bce_hip_ctx *c) {
   uint8_t *bwt = c->bwt.as<uint8_t>();
   c->stats.sort_rounds = 0;
   c->k1_unique = false;
+  c->k1_valid = false;
   if (n == 1) {
     BCE_HIP_TRY(c, hipMemcpyAsync(bwt, T, 1, hipMemcpyDeviceToDevice, c->stream));
     BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -382,6 +383,7 @@ int k1_bwt(bce_hip_ctx *c) {
   // all rotations distinct <=> rank[] is the inverse of the suffix array (used by the depth-first tail of K3)
   c->k1_unique = (groups >= n) || (have_list && m == 0);
   c->sa_res = res;
+  c->k1_valid = true;
   return BCE_HIP_OK;
 }
 

@@ -46,6 +46,7 @@ struct DfsArgs {
   DNode *stacks;
   uint64_t round0;
   uint32_t symcap;
+  uint32_t budget;
 };
 
 // Number of bytes on which the rotations starting at p and q agree going BACKWARDS (cyclic), capped at lim.
@@ -56,27 +57,33 @@ __device__ __forceinline__ uint32_t ld32u(const uint8_t *p) { uint32_t v; __buil
 __device__ __forceinline__ uint32_t lce_back_wave(const uint8_t *__restrict__ T, uint32_t n, uint32_t p, uint32_t q,
                                                   uint32_t lim, uint32_t lane) {
   uint32_t t = 0;
-  while (t + 1024 <= lim && p >= t + 1024 && q >= t + 1024) {
-    // lane L owns the bytes at distances [t + 16 L, t + 16 L + 16), i.e. addresses p - t - 16 L - 16 .. + 15
-    const uint8_t *a = T + (p - t - 16u * lane - 16u), *b = T + (q - t - 16u * lane - 16u);
-    uint32_t match = 16;                                   // bytes matching from the NEAREST (highest address) end
+  uint32_t cp = p, cq = q;                                   // the next bytes to compare are T[cp-1], T[cq-1] (cyclic)
+  while (t < lim) {
+    if (cp == 0) cp = n;
+    if (cq == 0) cq = n;
+    uint32_t run = cp < cq ? cp : cq;                        // bytes before either side wraps
+    if (run > lim - t) run = lim - t;
+    if (run >= 1024) {
+      // lane L owns the bytes at distances [16 L, 16 L + 16) from the current position
+      const uint8_t *a = T + (cp - 16u * lane - 16u), *b = T + (cq - 16u * lane - 16u);
+      uint32_t match = 16;                                   // bytes matching from the NEAREST (highest address) end
 #pragma unroll
-    for (int w = 3; w >= 0; --w) {
-      const uint32_t d = ld32u(a + 4 * w) ^ ld32u(b + 4 * w);
-      if (d && match == 16) match = (uint32_t)(3 - w) * 4u + ((uint32_t)__clz((int)d) >> 3);
+      for (int w = 3; w >= 0; --w) {
+        const uint32_t d = ld32u(a + 4 * w) ^ ld32u(b + 4 * w);
+        if (d && match == 16) match = (uint32_t)(3 - w) * 4u + ((uint32_t)__clz((int)d) >> 3);
+      }
+      const uint64_t mm = __ballot(match < 16);
+      if (mm) {
+        const uint32_t L = (uint32_t)__ffsll((long long)mm) - 1u;     // nearest lane with a mismatch
+        return t + 16u * L + (uint32_t)__builtin_amdgcn_readlane((int)match, (int)L);
+      }
+      t += 1024; cp -= 1024; cq -= 1024;
+    } else {                                                 // uniform scalar stretch (< 1 KB, up to the next wrap)
+      uint32_t i = 0;
+      while (i < run && T[cp - 1 - i] == T[cq - 1 - i]) ++i;
+      t += i; cp -= i; cq -= i;
+      if (i < run) return t;
     }
-    const uint64_t mm = __ballot(match < 16);
-    if (mm) {
-      const uint32_t L = (uint32_t)__ffsll((long long)mm) - 1u;     // nearest lane with a mismatch
-      return t + 16u * L + (uint32_t)__builtin_amdgcn_readlane((int)match, (int)L);
-    }
-    t += 1024;
-  }
-  while (t < lim) {                                         // uniform scalar tail (wrap-around, last < 1 KB)
-    const uint32_t ip = p >= t + 1 ? p - t - 1 : p + n - t - 1;
-    const uint32_t iq = q >= t + 1 ? q - t - 1 : q + n - t - 1;
-    if (T[ip] != T[iq]) break;
-    ++t;
   }
   return t;
 }
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   // All 64 lanes stay in the loop until every walker of the wave is finished: finished lanes help with the
   // cooperative text comparisons.
   while (__any(alive)) {
-    if (alive && (++visited > K3_DFS_BUDGET || a.dctl->err)) { if (!a.dctl->err) a.dctl->err = 3; alive = false; }
+    if (alive && (++visited > a.budget || a.dctl->err)) { if (!a.dctl->err) a.dctl->err = 3; alive = false; }
     // ---- chain skip: lanes at plane 0 with few rows, served one after the other by the whole wave ----
     const uint32_t x = cur.x0 + cur.x1;
     uint64_t want = __ballot(alive && a.skip_ok && cur.plane == 0 && x <= KD_MAXX);
@@ -121,7 +128,13 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
       const uint32_t xL = (uint32_t)__builtin_amdgcn_readlane((int)x, L);
       const uint32_t pa = a.sa[sL];
       uint32_t kk = n - 1;
-      for (uint32_t i = 1; i < xL && kk; ++i) kk = lce_back_wave(a.text, n, pa, a.sa[sL + i], kk, lane);
+      const uint32_t ra = a.isa[pa];
+      for (uint32_t i = 1; i < xL && kk; ++i) {
+        const uint32_t pb = a.sa[sL + i];
+        if (a.isa[pb] == ra) continue;                       // identical rotations (periodic input): agree for ever
+        kk = lce_back_wave(a.text, n, pa, pb, kk, lane);
+      }
+      if (kk == n - 1) kk = 0;                               // every row identical: cannot happen for a live node
       if ((int)lane == L) mykk = kk;
     }
     if (alive) {
@@ -201,7 +214,7 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, bool *done) {
   *done = false;
   static const bool enabled = getenv("BCE_HIP_NO_DFS") == nullptr;
   static const bool allow_skip = getenv("BCE_HIP_NO_SKIP") == nullptr;
-  if (!enabled || c->scan_mode) return BCE_HIP_OK;
+  if (!enabled || c->scan_mode || c->dbg_no_dfs) return BCE_HIP_OK;
   const uint32_t n = c->n;
   const uint32_t live = ctl.next_nodes;
   const uint64_t all = 8ull * (n - 1);
@@ -216,7 +229,7 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, bool *done) {
   a.text = c->text.as<uint8_t>();
   a.sa = c->sa[c->sa_res].as<uint32_t>();
   a.isa = c->rank.as<uint32_t>();
-  a.skip_ok = (allow_skip && c->k1_unique && c->text.p && c->rank.p) ? 1u : 0u;
+  a.skip_ok = (allow_skip && !c->dbg_no_skip && c->k1_valid && c->text.p && c->rank.p) ? 1u : 0u;
   uint32_t *w = reinterpret_cast<uint32_t *>(base);
   a.tkey = w; a.tesc = w + cap; a.ts = w + 2 * (size_t)cap; a.trlo = w + 3 * (size_t)cap; a.trhi = w + 4 * (size_t)cap;
   uint32_t *sk[2] = {reinterpret_cast<uint32_t *>(base + o_sort), reinterpret_cast<uint32_t *>(base + o_sort) + cap};
@@ -225,6 +238,7 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, bool *done) {
   a.stacks = reinterpret_cast<DNode *>(base + o_stack);
   a.round0 = c->round;
   a.symcap = cap;
+  a.budget = c->dbg_dfs_budget ? c->dbg_dfs_budget : K3_DFS_BUDGET;
   BCE_HIP_TRY(c, hipMemsetAsync(a.dctl, 0, sizeof(DfsCtl), c->stream));
   hipLaunchKernelGGL(k3_dfs_kernel, dim3((live + KD_T - 1) / KD_T), dim3(KD_T), 0, c->stream, a);
   DfsCtl h;

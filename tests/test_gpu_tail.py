@@ -50,3 +50,45 @@ def test_whole_file_duplicate_is_one_skipped_chain():
     assert st["nodes"] == 8 * len(data) - 8 and st["rounds"] > 8 * (2 << 20)
     assert dt < 5.0, "chain skip not taken? encode took %.1f s" % dt
     assert bce_amd.decompress(arch) == data
+
+
+def _encode_with_knobs(data, knobs):
+    ctx = bce_amd.api._Ctx(0)
+    try:
+        for k, v in knobs.items():
+            ctx.check(ctx.lib.bce_hip_debug_set(ctx.h, k, v), "bce_hip_debug_set")
+        rf = bce_amd.RankFile(data, ctx=ctx)
+        arch = bce_amd.BCE().encode(rf)
+        return arch, bce_amd.stats(rf)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("knobs", [{}, {1: 1}, {1: 1, 2: 1}, {3: 1}, {0: 50}, {0: 50, 2: 1}],
+                         ids=["default", "no-dfs", "rounds-only", "no-skip", "dfs-gives-up", "dfs-gives-up-no-tail"])
+def test_every_enumeration_path_gives_the_same_archive(knobs):
+    """Wide rounds, LDS tail, depth-first walkers (with / without chain skips, and giving up half way) are
+    interchangeable: the archive and the node count never depend on which of them ran."""
+    data = repeat_input(300000, 2500, seed=33)
+    ref = oracle.compress(data)
+    arch, st = _encode_with_knobs(data, knobs)
+    assert arch == ref
+    assert st["nodes"] == 8 * len(data) - 8
+
+
+def test_exactly_periodic_input_with_a_large_period():
+    """Two identical halves, nothing else: every rotation ties with one other.  The chain skip works on K1's
+    group-head ranks; the encoder output is well defined (the reference's DEcoder fails on such inputs, quirk Q9;
+    ours does not)."""
+    half = oracle.synth_text(8, 1 << 20)
+    data = half + half
+    rf = bce_amd.RankFile(data)
+    try:
+        t0 = time.time()
+        arch = bce_amd.BCE().encode(rf)
+        dt = time.time() - t0
+    finally:
+        rf.close()
+    assert arch == oracle.compress(data)
+    assert bce_amd.decompress(arch) == data
+    assert dt < 10.0
