@@ -239,7 +239,6 @@ int bce_hip_enum_round(bce_hip_ctx *c, uint64_t *next_nodes) {
   BCE_TRY(k3_rounds(c, 1, 0));
   EnumCtl ctl;
   BCE_TRY(k3_sync_ctl(c, &ctl));
-  if (ctl.lookback_fail) return BCE_HIP_E_INTERNAL;
   if (ctl.overflow) return BCE_HIP_E_OVERFLOW;
   if (ctl.need_flush) return BCE_HIP_E_OVERFLOW;   // the stepping interface never flushes
   BCE_TRY(k3_fetch_runs(c, first, 1));
@@ -326,9 +325,8 @@ int bce_hip_encode(bce_hip_ctx *c) {
     }
     const uint32_t first = c->round;
     uint32_t executed = 0;
-    static const bool use_tail = getenv("BCE_HIP_NO_TAIL") == nullptr;
     BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    if (use_tail && !c->dbg_no_tail && cur_nodes <= K3_TAIL_ENTER) {
+    if (!c->dbg_no_tail && cur_nodes <= K3_TAIL_ENTER) {
       // narrow phase: the persistent single-workgroup kernel loops over rounds on the device
       BCE_TRY(k3_tail(c));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -345,7 +343,6 @@ int bce_hip_encode(bce_hip_ctx *c) {
       BCE_TRY(k3_fetch_runs(c, first, executed));
     }
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms; }
-    if (ctl.lookback_fail) { snprintf(c->err, sizeof c->err, "K3 look-back gave up (round %u)", first); return BCE_HIP_E_INTERNAL; }
     if (ctl.overflow) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
     c->round = first + executed;
     decaying = ctl.next_nodes <= cur_nodes && c->round > 16;   // past the ramp-up: the node count no longer doubles
@@ -367,6 +364,9 @@ int bce_hip_encode(bce_hip_ctx *c) {
       BCE_TRY(flush_symbols(c, ctl.sym_total));
       break;
     }
+    // The host coders are the critical path from the first batch on: hand them a small first batch early
+    // instead of waiting for the symbol buffer to fill.
+    if (c->stats.flushes == 0 && ctl.sym_total >= (1u << 20)) BCE_TRY(flush_symbols(c, ctl.sym_total));
   }
   {
     const double tw = now_s();

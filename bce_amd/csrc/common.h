@@ -36,7 +36,7 @@ struct EnumCtl {
   uint32_t pad;
   uint64_t want_syms;        // symbol records of the skipped round (to grow the buffer when one round exceeds it)
   uint32_t ticket;           // k3_scan_kernel: arrival counter of its 8 plane blocks (last one runs the epilogue)
-  uint32_t lookback_fail;    // (unused; kept for layout stability)
+  uint32_t pad1;
   uint32_t ptot[8][3];       // per plane totals of the round: child0, child1, symbols
   uint64_t symbase[8];       // symbol-buffer base of each plane's records in this round
   uint32_t tail_rounds;      // rounds executed by the last k3_tail_kernel launch

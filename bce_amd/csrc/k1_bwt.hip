@@ -317,9 +317,8 @@ int k1_bwt(bce_hip_ctx *c) {
     BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return BCE_HIP_OK;
   };
-  static const bool use_active = getenv("BCE_HIP_K1_FULL") == nullptr;
   while (groups < n && h < n) {
-    if (use_active && !have_list && (uint64_t)(n - groups) * 5 < (uint64_t)n * 2 + 5) {
+    if (!have_list && (uint64_t)(n - groups) * 5 < (uint64_t)n * 2 + 5) {
       // few elements can still be in non-singleton groups (at most 2 per missing group... bound: n - groups < 0.4 n
       // means at most 0.8 n active): build the explicit list and check its real size
       BCE_TRY(build_active(nrk, nullptr, n, act[0]));

@@ -212,9 +212,7 @@ __global__ void kd_place_kernel(const uint32_t *__restrict__ tkey, const uint32_
 // continues with the round-based kernels.
 int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, bool *done) {
   *done = false;
-  static const bool enabled = getenv("BCE_HIP_NO_DFS") == nullptr;
-  static const bool allow_skip = getenv("BCE_HIP_NO_SKIP") == nullptr;
-  if (!enabled || c->scan_mode || c->dbg_no_dfs) return BCE_HIP_OK;
+  if (c->scan_mode || c->dbg_no_dfs) return BCE_HIP_OK;
   const uint32_t n = c->n;
   const uint32_t live = ctl.next_nodes;
   const uint64_t all = 8ull * (n - 1);
@@ -229,7 +227,7 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, bool *done) {
   a.text = c->text.as<uint8_t>();
   a.sa = c->sa[c->sa_res].as<uint32_t>();
   a.isa = c->rank.as<uint32_t>();
-  a.skip_ok = (allow_skip && !c->dbg_no_skip && c->k1_valid && c->text.p && c->rank.p) ? 1u : 0u;
+  a.skip_ok = (!c->dbg_no_skip && c->k1_valid && c->text.p && c->rank.p) ? 1u : 0u;
   uint32_t *w = reinterpret_cast<uint32_t *>(base);
   a.tkey = w; a.tesc = w + cap; a.ts = w + 2 * (size_t)cap; a.trlo = w + 3 * (size_t)cap; a.trhi = w + 4 * (size_t)cap;
   uint32_t *sk[2] = {reinterpret_cast<uint32_t *>(base + o_sort), reinterpret_cast<uint32_t *>(base + o_sort) + cap};

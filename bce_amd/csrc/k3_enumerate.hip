@@ -11,11 +11,12 @@
 // reference's Q[i][0]) grows up from index 0, the child1 list (Q[i][1]) grows DOWN from capP-1, so the
 // two lists share the capacity whatever their split is.
 //
-// Round structure (v1): count kernel -> single-block scan -> write kernel, all parameterised by the
-// round parity and driven by a device-resident control block, so the host can queue many rounds
-// without reading anything back.  If the symbol buffer could overflow the scan kernel marks the round
-// as skipped (need_flush) and every later queued round becomes a no-op; the host flushes the model
-// (K4) and resumes from that round.
+// Wide rounds: count kernel -> per-plane scan (last block folds the totals into the control block) -> write
+// kernel, all parameterised by the round parity and driven by a device-resident control block, so the host can
+// queue many rounds without reading anything back.  If the symbol buffer could overflow, the scan marks the
+// round as skipped (need_flush) and every later queued round becomes a no-op; the host flushes the model (K4)
+// and resumes from that round.  Narrow rounds: k3_tail_kernel below (one persistent workgroup, lists in LDS).
+// The end of the enumeration: k3_dfs.hip (depth-first walkers with chain skipping).
 #include <stdlib.h>
 
 #include "common.h"
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(KT_T) void k3_tail_kernel(K3Args a, RunEntry *truns
   __shared__ uint64_t ws[KT_T / 64];
   __shared__ uint64_t pstart[9];
   EnumCtl *ctl = a.ctl;
-  if (ctl->need_flush || ctl->overflow || ctl->lookback_fail) return;
+  if (ctl->need_flush || ctl->overflow) return;
   const uint32_t tid = threadIdx.x;
   uint32_t par = a.par, round = a.round, cur = 0, executed = 0;
   if (tid < 16) cnt[par][tid >> 1][tid & 1] = ctl->cnt[par][tid >> 1][tid & 1];

@@ -30,11 +30,6 @@
 //   3. (cum, freq, total) go back to the record's ORIGINAL index; the host range coders read them in
 //      stream order.
 // Counter state persists in HBM between flushes, so flushes can be arbitrarily small.
-#include <stdlib.h>
-
-#include <algorithm>
-#include <vector>
-
 #include "common.h"
 
 namespace bce {
@@ -373,11 +368,6 @@ int k4_prepare(bce_hip_ctx *c) {
   return BCE_HIP_OK;
 }
 
-static uint32_t k4_digit_bits() {
-  static const uint32_t v = [] { const char *e = getenv("BCE_HIP_K4_DIGIT"); return e ? (uint32_t)atoi(e) : 8u; }();
-  return v;
-}
-
 int k4_flush(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   if (nsym64 == 0) return BCE_HIP_OK;
   if (nsym64 >= (1ull << 31)) return BCE_HIP_E_OVERFLOW;
@@ -403,7 +393,7 @@ int k4_flush(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   const uint32_t grid = (uint32_t)(gb < 8192 ? gb : 8192);
   hipLaunchKernelGGL(k4_iota_kernel, dim3(grid), dim3(K4_T), 0, c->stream, nsym, val[0]);
   int res = 0;
-  BCE_TRY(radix_sort_pairs(c, key, val, nsym, kSymRunShift, kSymRunBits, &res, k4_digit_bits()));
+  BCE_TRY(radix_sort_pairs(c, key, val, nsym, kSymRunShift, kSymRunBits, &res, 8));
   // per-window work arrays, carved from one buffer: histT | stateW | winfo | queue | haltW | qcount
   const size_t nwin = ((size_t)nsym + 63) / 64;
   auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -412,24 +402,6 @@ int k4_flush(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
                o_qc = up16(o_bits + nwin * 8);
   BCE_TRY(ensure(c, c->k4w, o_qc + 16));
   uint8_t *wbuf = c->k4w.as<uint8_t>();
-  if (getenv("BCE_HIP_DEBUG_RUNS")) {      // diagnostic: longest slot runs of this flush
-    std::vector<uint32_t> hk(nsym);
-    BCE_HIP_TRY(c, hipMemcpy(hk.data(), key[res], b4, hipMemcpyDeviceToHost));
-    std::vector<std::pair<uint32_t, uint32_t>> runs;   // (length, key)
-    uint64_t longsum = 0;
-    for (uint32_t i = 0; i < nsym;) {
-      uint32_t j = i;
-      while (j < nsym && (hk[j] >> kSymRunShift) == (hk[i] >> kSymRunShift)) ++j;
-      runs.push_back({j - i, hk[i]});
-      if (j - i >= K4_LONG) longsum += j - i;
-      i = j;
-    }
-    std::sort(runs.begin(), runs.end(), [](auto &x, auto &y) { return x.first > y.first; });
-    fprintf(stderr, "[bce] flush %u syms, %zu runs, %llu syms in long runs; top:", nsym, runs.size(), (unsigned long long)longsum);
-    for (size_t r = 0; r < runs.size() && r < 8; ++r)
-      fprintf(stderr, " %u(k=%u,p=%u)", runs[r].first, key_k(runs[r].second), key_plane(runs[r].second));
-    fprintf(stderr, "\n");
-  }
   K4Args a;
   a.keys = key[res]; a.vals = val[res];
   a.stat = c->stat.as<uint8_t>();
