@@ -46,7 +46,6 @@ int flush_symbols(bce_hip_ctx *c, uint64_t nsym) {
     BCE_TRY(k4_flush(c, nsym, slot));
     c->stats.t_model += now_s() - t1;
     slot.batch.out = slot.h_out;
-    slot.batch.esc = slot.h_esc;
     for (int p = 0; p < 8; ++p) {
       slot.batch.runs[p].clear();
       slot.batch.runs[p].reserve(c->run_log[p].size());
@@ -99,7 +98,6 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   if (c->coder) c->coder->drain();
   for (FlushSlot &sl : c->slot) {
     if (sl.h_out) (void)hipHostFree(sl.h_out);
-    if (sl.h_esc) (void)hipHostFree(sl.h_esc);
   }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -277,7 +275,7 @@ int bce_hip_enum_model(bce_hip_ctx *c, uint32_t *out, uint64_t cap_records, uint
   BCE_TRY(k4_flush(c, ctl.sym_total, c->slot[0]));
   for (uint64_t i = 0; i < ctl.sym_total; ++i) {
     const uint64_t o = c->slot[0].h_out[i];
-    out[3 * i + 0] = (uint32_t)(o & 0xFFFF); out[3 * i + 1] = (uint32_t)((o >> 16) & 0xFFFF); out[3 * i + 2] = (uint32_t)((o >> 32) & 0xFFFF);
+    out[3 * i + 0] = out_cum(o); out[3 * i + 1] = out_freq(o); out[3 * i + 2] = out_total(o);
   }
   BCE_TRY(k3_reset_symbols(c));
   return BCE_HIP_OK;

@@ -207,10 +207,21 @@ BCE_HD uint32_t key_plane(uint32_t k) { return (k >> 26) & 7u; }
 BCE_HD uint32_t esc_bits(uint32_t e) { return e & 0x7FFFFFFu; }
 BCE_HD uint32_t esc_n(uint32_t e) { return e >> 27; }
 
+// Record handed to the host range coder, one u64 per symbol:
+//   [12:0] cum   [20:13] freq - 1   [33:21] total   [61:34] escape bits with a sentinel: bits | 1 << nesc
+// (cum, total < 8192: k <= 31 counters <= 254 each, + k; freq <= 255; nesc <= 27.)
+BCE_HD uint64_t pack_model_out(uint32_t cum, uint32_t freq, uint32_t total, uint32_t esc_word) {
+  const uint32_t sent = esc_bits(esc_word) | (1u << esc_n(esc_word));
+  return (uint64_t)cum | ((uint64_t)(freq - 1u) << 13) | ((uint64_t)total << 21) | ((uint64_t)sent << 34);
+}
+BCE_HD uint32_t out_cum(uint64_t o) { return (uint32_t)(o & 0x1FFFu); }
+BCE_HD uint32_t out_freq(uint64_t o) { return (uint32_t)((o >> 13) & 0xFFu) + 1u; }
+BCE_HD uint32_t out_total(uint64_t o) { return (uint32_t)((o >> 21) & 0x1FFFu); }
+BCE_HD uint32_t out_esc_sentinel(uint64_t o) { return (uint32_t)(o >> 34); }     // 1 = no escape bits
+
 // One adaptive-model step on a slot's k byte counters (bce.cpp:512-518,529,531-533), the sequential
-// definition the K4 kernel is tested against.  Output record for the host range coder:
-// cum | freq<<16 | total<<32.
-BCE_HD uint64_t model_step(uint8_t *ctr, uint32_t k, uint32_t s) {
+// definition the K4 kernel is tested against.
+BCE_HD uint64_t model_step(uint8_t *ctr, uint32_t k, uint32_t s, uint32_t esc_word) {
   uint32_t l = 0;
   for (uint32_t i = 0; i < s; ++i) l += ctr[i];
   const uint32_t cum = l + s;
@@ -219,7 +230,7 @@ BCE_HD uint64_t model_step(uint8_t *ctr, uint32_t k, uint32_t s) {
   const uint32_t freq = (uint32_t)ctr[s] + 1u;
   if (++ctr[s] == 0xFF)
     for (uint32_t i = 0; i < k; ++i) ctr[i] >>= 1;
-  return (uint64_t)cum | ((uint64_t)freq << 16) | ((uint64_t)total << 32);
+  return pack_model_out(cum, freq, total, esc_word);
 }
 
 }  // namespace bce

@@ -45,8 +45,7 @@ struct EnumCtl {
 
 // Pinned host staging of one model flush + the batch descriptor handed to the coder threads.
 struct FlushSlot {
-  uint64_t *h_out = nullptr;
-  uint32_t *h_esc = nullptr;
+  uint64_t *h_out = nullptr;     // one packed u64 per symbol (bce_core.h pack_model_out)
   size_t cap = 0;
   CoderBatch batch;
 };

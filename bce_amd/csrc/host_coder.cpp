@@ -1,6 +1,8 @@
 // host_coder.cpp -- see host_coder.h.  Plain C++ (no HIP).
 #include "host_coder.h"
 
+#include "bce_core.h"
+
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -100,7 +102,7 @@ uint64_t bce_test_div_recip(uint64_t x, uint32_t d) {
 
 // Same arithmetic as encode() (bce.cpp:520-529 + shift_out :655-661) on the pair (l, r = h - l): the next
 // range r' = step * freq - 1 then depends on r alone, and l accumulates off the critical chain.
-void RangeCoder::encode_run(const uint64_t *out, const uint32_t *esc, uint64_t begin, uint64_t end) {
+void RangeCoder::encode_run(const uint64_t *out, uint64_t begin, uint64_t end) {
   const Recip *rt = recip_table();
   uint64_t l = l_, r = h_ - l_;
   auto step1 = [&](uint32_t cum, uint32_t freq, uint32_t total) {
@@ -119,17 +121,17 @@ void RangeCoder::encode_run(const uint64_t *out, const uint32_t *esc, uint64_t b
   };
   for (uint64_t i = begin; i < end; ++i) {
     const uint64_t o = out[i];
-    uint32_t bits = esc[i];                             // [26:0] escape bits, [31:27] their count
-    if (__builtin_expect(bits != 0, 0))                 // k > 31 escape, bce.cpp:507-510
-      for (uint32_t nesc = bits >> 27; nesc; --nesc, bits >>= 1) step1(bits & 1, 1, 2);
-    step1((uint32_t)(o & 0xFFFF), (uint32_t)((o >> 16) & 0xFFFF), (uint32_t)((o >> 32) & 0xFFFF));
+    uint32_t es = out_esc_sentinel(o);                  // escape bits below a sentinel bit; 1 = none
+    if (__builtin_expect(es != 1u, 0))                  // k > 31 escape, bce.cpp:507-510: uniform bits, LSB first
+      for (; es > 1u; es >>= 1) step1(es & 1u, 1, 2);
+    step1(out_cum(o), out_freq(o), out_total(o));
   }
   l_ = l; h_ = l + r;
 }
 
-void HostCoder::consume(int p, const SymRun *runs, size_t nruns, const uint64_t *out, const uint32_t *esc) {
+void HostCoder::consume(int p, const SymRun *runs, size_t nruns, const uint64_t *out) {
   RangeCoder &rc = plane[p];
-  for (size_t r = 0; r < nruns; ++r) rc.encode_run(out, esc, runs[r].start, runs[r].start + runs[r].count);
+  for (size_t r = 0; r < nruns; ++r) rc.encode_run(out, runs[r].start, runs[r].start + runs[r].count);
 }
 
 HostCoder::HostCoder() {
@@ -156,7 +158,7 @@ void HostCoder::run(int p) {
       w.q.pop_front();
     }
     const auto t0 = std::chrono::steady_clock::now();
-    consume(p, b->runs[p].data(), b->runs[p].size(), b->out, b->esc);
+    consume(p, b->runs[p].data(), b->runs[p].size(), b->out);
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     {
       std::lock_guard<std::mutex> g(done_mu_);

@@ -43,22 +43,20 @@ class alignas(128) RangeCoder {
   const std::vector<uint16_t> &data() const { return data_; }
   std::vector<uint16_t> &data() { return data_; }
   // bulk form of encode() for the GPU model records of one run (state kept in registers)
-  void encode_run(const uint64_t *out, const uint32_t *esc, uint64_t begin, uint64_t end);
+  void encode_run(const uint64_t *out, uint64_t begin, uint64_t end);
 
  private:
   uint64_t l_, h_;
   std::vector<uint16_t> data_;
 };
 
-// One GPU model record: cum | freq<<16 | total<<32 (bce_core.h model_step); escape word aside
-// ([26:0] bits, [31:27] count; bce_core.h pack_symbol).
+// One GPU model record per symbol: bce_core.h pack_model_out (cum, freq, total and the k > 31 escape bits).
 struct SymRun { uint64_t start; uint32_t count; uint32_t round; };
 
 // One model flush handed to the coder threads: the GPU outputs of its records (pinned host memory
 // owned by the caller) and, per plane, the (round-ordered) runs of record indices that belong to it.
 struct CoderBatch {
   const uint64_t *out = nullptr;
-  const uint32_t *esc = nullptr;
   std::vector<SymRun> runs[8];
   std::atomic<int> pending{0};      // planes that have not finished this batch yet
 };
@@ -71,7 +69,7 @@ struct HostCoder {
   // C[i] = zeros(plane (i+7)%8) with range n+1.
   void begin(const uint8_t config[9][32], const uint32_t C[8], uint32_t n);
   // Feed plane p's records of one flush, run by run (coder_[i].set(...), bce.cpp:1302, coder half).
-  void consume(int p, const SymRun *runs, size_t nruns, const uint64_t *out, const uint32_t *esc);
+  void consume(int p, const SymRun *runs, size_t nruns, const uint64_t *out);
   // Asynchronous form: 8 persistent threads, one per plane (the reference's OpenMP loop :1250-1252 has
   // the same 8-way split); batches are coded in submission order while the GPU produces the next one.
   void submit(CoderBatch *b);

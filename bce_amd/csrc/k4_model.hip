@@ -44,6 +44,7 @@ struct K4Args {
   uint8_t *stat;
   const PlaneCfg *cfg;
   uint64_t *out;
+  const uint32_t *esc;           // escape words in original record order (K3 wrote them)
   uint8_t *histT;                // [nwin][32] symbol counts of each window's leading run fragment
   uint8_t *stateW;               // [nwin][32] counters at the window start (long runs)
   uint32_t *winfo;               // [nwin] runid<<7 | length of the leading fragment
@@ -126,7 +127,7 @@ __device__ __forceinline__ uint64_t k4_replay(const K4Args &a, uint64_t pos, uin
     const bool commit = lane < nc;
     if (commit) {
       const uint32_t cum = Ps + ltb + s, total = T + lane + k, freq = before + 1u;
-      a.out[idx] = (uint64_t)cum | ((uint64_t)freq << 16) | ((uint64_t)total << 32);
+      a.out[idx] = pack_model_out(cum, freq, total, a.esc[idx]);
     }
     const uint64_t cm = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);
     C += k4_symbol_counts(s, eq, cm, commit, cb, lane);
@@ -378,15 +379,11 @@ int k4_flush(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   BCE_TRY(ensure(c, c->sout, (size_t)nsym * 8));
   if (slot.cap < nsym) {
     if (slot.h_out) (void)hipHostFree(slot.h_out);
-    if (slot.h_esc) (void)hipHostFree(slot.h_esc);
-    slot.h_out = nullptr; slot.h_esc = nullptr; slot.cap = 0;
+    slot.h_out = nullptr; slot.cap = 0;
     size_t cap = (size_t)c->sym_cap > nsym ? (size_t)c->sym_cap : nsym;
     BCE_HIP_TRY(c, hipHostMalloc((void **)&slot.h_out, cap * 8, hipHostMallocDefault));
-    BCE_HIP_TRY(c, hipHostMalloc((void **)&slot.h_esc, cap * 4, hipHostMallocDefault));
     slot.cap = cap;
   }
-  // the escape words are final as K3 wrote them: start their copy first
-  BCE_HIP_TRY(c, hipMemcpyAsync(slot.h_esc, c->sesc.p, b4, hipMemcpyDeviceToHost, c->stream));
   uint32_t *key[2] = {c->skey[0].as<uint32_t>(), c->skey[1].as<uint32_t>()};
   uint32_t *val[2] = {c->sval[0].as<uint32_t>(), c->sval[1].as<uint32_t>()};
   uint64_t gb = ((uint64_t)nsym + K4_T - 1) / K4_T;
@@ -407,6 +404,7 @@ int k4_flush(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   a.stat = c->stat.as<uint8_t>();
   a.cfg = c->dcfg.as<PlaneCfg>();
   a.out = c->sout.as<uint64_t>();
+  a.esc = c->sesc.as<uint32_t>();
   a.histT = wbuf + o_hist; a.stateW = wbuf + o_state;
   a.winfo = reinterpret_cast<uint32_t *>(wbuf + o_info);
   a.queue = reinterpret_cast<uint2 *>(wbuf + o_queue);

@@ -70,7 +70,6 @@ extern "C" int emul_encode_from_bwt(const uint8_t *bwt, uint32_t n, uint32_t off
     bool any = false;
     for (int p = 0; p < 8; ++p) {
       std::vector<uint64_t> outrec;
-      std::vector<uint32_t> esc;
       auto rank1 = [&](uint32_t s) { const uint32_t g = div96(s); return granule_rank1(G[p][g], s - g * 96); };
       for (int j = 0; j < 2; ++j)
         for (const Node &nd : cur[p][j]) {
@@ -94,13 +93,12 @@ extern "C" int emul_encode_from_bwt(const uint8_t *bwt, uint32_t n, uint32_t off
             pack_symbol(cfg[p], (uint32_t)p, so.sym, so.k, so.ctx1, so.ctx2, so.ctxs, kw, ew);
             const uint32_t k = key_k(kw);
             uint8_t *ctr = stat[p].data() + cfg[p].off[k] + (key_slot(kw) - cfg[p].ctxoff[k]) * k;
-            outrec.push_back(model_step(ctr, k, key_sym(kw)));
-            esc.push_back(ew);
+            outrec.push_back(model_step(ctr, k, key_sym(kw), ew));
             ++syms;
           }
         }
       SymRun run{0, (uint32_t)outrec.size(), 0};
-      hc.consume(p, &run, 1, outrec.data(), esc.data());
+      hc.consume(p, &run, 1, outrec.data());
     }
     for (int p = 0; p < 8; ++p)
       for (int j = 0; j < 2; ++j) { cur[p][j].swap(nxt[p][j]); nxt[p][j].clear(); if (!cur[p][j].empty()) any = true; }
