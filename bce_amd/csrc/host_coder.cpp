@@ -53,7 +53,7 @@ void RangeCoder::flush() {
 void HostCoder::begin(const uint8_t config[9][32], const uint32_t C[8], uint32_t n) {
   drain();
   for (int i = 0; i < 8; ++i) {
-    w_[i].busy = 0;
+    w_[i].busy = 0; w_[i].nsym = 0;
     plane[i] = RangeCoder();
     plane[i].preamble(config[i]);
     plane[i].uniform(C[i], n + 1);
@@ -104,28 +104,41 @@ uint64_t bce_test_div_recip(uint64_t x, uint32_t d) {
 // range r' = step * freq - 1 then depends on r alone, and l accumulates off the critical chain.
 void RangeCoder::encode_run(const uint64_t *out, uint64_t begin, uint64_t end) {
   const Recip *rt = recip_table();
-  uint64_t l = l_, r = h_ - l_;
-  auto step1 = [&](uint32_t cum, uint32_t freq, uint32_t total) {
-    if (__builtin_expect(r < total, 0)) {               // :520-525
-      for (int i = 0; i < 4; ++i) data_.push_back((uint16_t)(l >> (48 - 16 * i)));
-      l = 0; r = ~0ull;
-    }
-    const uint64_t step = (__builtin_expect(r == ~0ull, 0) || total >= kRecipMax) ? r / total : div_recip(r, rt[total]);
-    l += step * cum;                                    // :528
-    r = step * freq - 1;                                // h = l + step*freq - 1  (:529)
-    while (__builtin_expect(!(((l + r) ^ l) >> 48), 0)) {   // shift_out :655-661
-      data_.push_back((uint16_t)((l + r) >> 48));
-      l <<= 16;
-      r = (r << 16) | 0xFFFF;
-    }
-  };
+  uint64_t l = l_, r = h_ - l_;                         // kept in registers: the chain is r -> step -> r
+  uint16_t stage[64];                                   // output words, appended to data_ 64 at a time
+  uint32_t ns = 0;
+#define BCE_EMIT(v)                                                                                       \
+  do {                                                                                                    \
+    stage[ns++] = (uint16_t)(v);                                                                          \
+    if (__builtin_expect(ns == 64, 0)) { data_.insert(data_.end(), stage, stage + 64); ns = 0; }          \
+  } while (0)
+#define BCE_STEP(cum, freq, total)                                                                        \
+  do {                                                                                                    \
+    const uint32_t t_ = (total);                                                                          \
+    if (__builtin_expect(r < t_, 0)) {                  /* :520-525 */                                    \
+      for (int i_ = 0; i_ < 4; ++i_) BCE_EMIT(l >> (48 - 16 * i_));                                       \
+      l = 0; r = ~0ull;                                                                                   \
+    }                                                                                                     \
+    const uint64_t step_ =                                                                                \
+        (__builtin_expect(r == ~0ull, 0) || t_ >= kRecipMax) ? r / t_ : div_recip(r, rt[t_]);             \
+    l += step_ * (cum);                                 /* :528 */                                        \
+    r = step_ * (freq) - 1;                             /* h = l + step*freq - 1  (:529) */               \
+    while (__builtin_expect(!(((l + r) ^ l) >> 48), 0)) {   /* shift_out :655-661 */                      \
+      BCE_EMIT((l + r) >> 48);                                                                            \
+      l <<= 16;                                                                                           \
+      r = (r << 16) | 0xFFFF;                                                                             \
+    }                                                                                                     \
+  } while (0)
   for (uint64_t i = begin; i < end; ++i) {
     const uint64_t o = out[i];
     uint32_t es = out_esc_sentinel(o);                  // escape bits below a sentinel bit; 1 = none
     if (__builtin_expect(es != 1u, 0))                  // k > 31 escape, bce.cpp:507-510: uniform bits, LSB first
-      for (; es > 1u; es >>= 1) step1(es & 1u, 1, 2);
-    step1(out_cum(o), out_freq(o), out_total(o));
+      for (; es > 1u; es >>= 1) BCE_STEP(es & 1u, 1u, 2u);
+    BCE_STEP(out_cum(o), out_freq(o), out_total(o));
   }
+#undef BCE_STEP
+#undef BCE_EMIT
+  data_.insert(data_.end(), stage, stage + ns);
   l_ = l; h_ = l + r;
 }
 
@@ -159,6 +172,7 @@ void HostCoder::run(int p) {
     }
     const auto t0 = std::chrono::steady_clock::now();
     consume(p, b->runs[p].data(), b->runs[p].size(), b->out);
+    for (const SymRun &r : b->runs[p]) w.nsym += r.count;
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     {
       std::lock_guard<std::mutex> g(done_mu_);
@@ -197,6 +211,8 @@ double HostCoder::busy_seconds() {
 }
 
 void HostCoder::finish(const uint8_t config[9][32], uint32_t n, uint32_t offset, std::vector<uint16_t> &archive) {
+  if (getenv("BCE_HIP_CODER_DEBUG"))
+    for (int p = 0; p < 8; ++p) fprintf(stderr, "coder %d: busy %.1f ms, %llu symbols, %zu words\n", p, w_[p].busy * 1e3, (unsigned long long)w_[p].nsym, plane[p].data().size());
   unsigned size = 0u;                                   // :1134-1138
   for (int i = 0; i < 8; ++i) { plane[i].flush(); size += (unsigned)plane[i].data().size(); }
   RangeCoder mainc;                                     // coder_type main(-1) :1141 -> config row 8

@@ -86,6 +86,7 @@ struct HostCoder {
     std::condition_variable cv;
     std::deque<CoderBatch *> q;
     double busy = 0;
+    uint64_t nsym = 0;
     bool stop = false;
   };
   Worker w_[8];

@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--file", default=os.environ.get("BCE_BENCH_FILE"))
     ap.add_argument("--cpu-sample", type=int, default=64 << 20, help="bytes of the workload the CPU baseline compresses")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--scan-config", action="store_true",
+                    help="BASELINE config 5: run `bce -s` on the input first (untimed), compress with the scanned table")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU path); gloo = rehearsal of the N>1 control flow on one GPU")
     return ap.parse_args()
@@ -93,6 +95,12 @@ def main():
     t_in = torch.from_numpy(data).to(dev)       # input resident in HBM before the timed region
     torch.cuda.synchronize()
     ctx = bce_amd.api._Ctx(local)
+    config, coder_config = None, "default AdaptiveCoder<31> tables"
+    if args.scan_config:       # the .bcc a user would have produced beforehand with `bce -s` (not part of `bce -c`)
+        t0 = time.perf_counter()
+        config, _ = bce_amd.scan(data, device=local)
+        coder_config = "table scanned from the input by bce -s (GPU enumeration + host ScanCoder, %.1f s, untimed), sha256 %s" % (
+            time.perf_counter() - t0, hashlib.sha256(bytes(config)).hexdigest()[:16])
 
     def barrier():
         torch.cuda.synchronize()
@@ -103,7 +111,7 @@ def main():
     gathered = [None]
 
     def step():
-        arch, st = bce_amd.compress_device(t_in.data_ptr(), n, ctx=ctx)
+        arch, st = bce_amd.compress_device(t_in.data_ptr(), n, config=config, ctx=ctx)
         if dist is not None:
             # RCCL gather of the per-block coded streams to rank 0 (size exchange, then padded gather)
             gathered[0] = sharding.gather_streams(arch, dist, comm_dev)
@@ -152,7 +160,7 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32 integer",
             "data": "synthetic" if not args.file else "file",
-            "config": {"workload": workload, "bytes_per_gpu": n, "coder_config": "default AdaptiveCoder<31> tables",
+            "config": {"workload": workload, "bytes_per_gpu": n, "coder_config": coder_config,
                        "sharding": "one independent block per GPU, RCCL gather of coded streams to rank 0" if n_gpus > 1 else "single block"},
             "archive_bytes": len(arch), "archive_sha256": hashlib.sha256(arch).hexdigest(),
             "ratio": round(len(arch) / n, 5),
