@@ -298,18 +298,22 @@ int bce_hip_encode(bce_hip_ctx *c) {
   for (int i = 0; i < 8; ++i) cur_nodes += (C[i] && n - C[i]) ? 1 : 0;
   EnumCtl ctl;
   bool decaying = false;
-  bool have_ctl = false, dfs_ok = true;
+  bool have_ctl = false;
+  // depth-first tail: first attempt when the live set is small, a second one (if the first ran out of room) when tiny
+  uint32_t kDfsEnter[2] = {65536u, 2048u};
+  if (const char *e = getenv("BCE_HIP_DFS_ENTER")) kDfsEnter[0] = (uint32_t)strtoul(e, nullptr, 10);
+  int dfs_try = 0;
   for (;;) {
     if (have_ctl && decaying && !ctl.need_flush && ctl.done_round == 0xFFFFFFFFu) {
       // few live nodes and almost everything visited: finish depth-first (k3_dfs.hip).  The walkers' symbols
       // come after everything emitted so far, so flush that first.
       const uint64_t all = 8ull * (n - 1);
-      if (dfs_ok && ctl.next_nodes && ctl.next_nodes <= 8192 && ctl.nodes_total >= all / 8) {
+      if (dfs_try < 2 && ctl.next_nodes && ctl.next_nodes <= kDfsEnter[dfs_try] && ctl.nodes_total >= all / 8) {
         BCE_TRY(flush_symbols(c, ctl.sym_total));
         ctl.sym_total = 0;
         bool dfs_done = false;
         BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-        BCE_TRY(k3_dfs_tail(c, ctl, &dfs_done));
+        BCE_TRY(k3_dfs_tail(c, ctl, kDfsEnter[dfs_try], &dfs_done));
         BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         BCE_HIP_TRY(c, hipEventSynchronize(c->ev1));
         { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms; }
@@ -318,7 +322,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
           BCE_TRY(flush_symbols(c, ctl.sym_total));
           break;
         }
-        dfs_ok = false;                           // a walker gave up (stack / symbols / budget): carry on with rounds
+        ++dfs_try;                                // out of room (symbols / queue): carry on with rounds
       }
     }
     const uint32_t first = c->round;

@@ -156,7 +156,7 @@ int k2_get_plane_bits(bce_hip_ctx *c, int plane, uint8_t *out);
 int k2_rank1(bce_hip_ctx *c, int plane, const uint32_t *idx, uint32_t count, uint32_t *out);
 int k3_begin(bce_hip_ctx *c);                       // k3_enumerate.hip
 int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint);   // queue `count` rounds from c->round (no sync)
-int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, bool *done);   // k3_dfs.hip: finish the enumeration depth-first
+int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done);   // k3_dfs.hip: finish the enumeration depth-first
 int k3_tail(bce_hip_ctx *c);                        // queue the persistent narrow-round kernel from c->round (no sync)
 int k3_fetch_tail_runs(bce_hip_ctx *c, uint32_t rounds);
 int k3_sync_ctl(bce_hip_ctx *c, EnumCtl *out);      // copy the control block back (syncs the stream)

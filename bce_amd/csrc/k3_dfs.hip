@@ -12,6 +12,7 @@
 // bytes), and they end at row ISA[SA[s] - k], 8k rounds later, with (x0, x1) unchanged.  k is found by comparing
 // the text backwards from the x suffix-array positions (exact, no hashing).  SA / ISA are K1's arrays; the skip
 // is disabled when K1 did not end with all rotations distinct (periodic inputs) or the BWT was injected.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -20,18 +21,22 @@
 namespace bce {
 
 constexpr int KD_T = 64;                       // one wave per block: walkers spread over the CUs
-constexpr uint32_t KD_STACK = 192;             // pending siblings per walker
-constexpr uint32_t KD_MAXX = 8;                // rows compared for a chain skip
-constexpr uint32_t K3_DFS_ENTER = 8192;        // live nodes at which the depth-first tail may start
-constexpr uint32_t K3_DFS_BUDGET = 1u << 18;   // nodes one walker may classify before the attempt is abandoned
-constexpr uint32_t K3_DFS_SYMCAP = 4u << 20;   // tagged symbols
+constexpr uint32_t KD_STACK = 32;              // pending siblings per walker (the older half is handed on when full)
+constexpr uint32_t KD_MAXX = 2048;             // rows compared for a chain skip
+constexpr uint32_t KD_NEAR = 256;              // bytes compared one lane per row before the whole wave takes one pair
+constexpr uint32_t KD_WALKERS = 1u << 17;      // walkers per pass (each takes several queued nodes when more are queued)
+constexpr uint32_t KD_QUEUE = 4u << 20;        // queued nodes between passes
+constexpr uint32_t K3_DFS_PASS = 4096;         // nodes one walker classifies per pass before it hands its work on
 
 struct DfsCtl {
   uint32_t nsym;         // tagged symbols emitted
-  uint32_t err;          // 1 stack overflow, 2 symbol capacity, 3 a walker exceeded its budget (bushy subtree)
+  uint32_t err;          // 2 symbol capacity, 4 queue capacity
   uint64_t nodes;        // nodes visited (skipped pass-through nodes included)
   uint64_t maxround;
   uint32_t cntp[8];      // symbols per plane
+  uint32_t queued;       // nodes handed to the next pass
+  uint32_t pad;
+  uint32_t dbg_hist[32]; uint32_t dbg_maxvis; uint32_t dbg_skips; uint64_t dbg_skipbytes;
 };
 
 struct DNode { uint32_t s, x0, x1, plane; uint64_t round; };
@@ -44,16 +49,26 @@ struct DfsArgs {
   DfsCtl *dctl;
   uint32_t *tkey, *tesc, *ts, *trlo, *trhi;
   DNode *stacks;
+  const DNode *in;       // queued nodes of this pass; nullptr = the planes' node lists (first pass)
+  DNode *out;            // nodes handed to the next pass
+  uint32_t in_count, out_cap;
   uint64_t round0;
   uint32_t symcap;
   uint32_t budget;
+  uint32_t dbg;
 };
+
+__device__ __forceinline__ uint32_t ld32u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) { const uint32_t w = (uint32_t)__shfl_xor((int)v, o); v = w < v ? w : v; }
+  return v;
+}
+__device__ __forceinline__ uint32_t cyc_back(uint32_t p, uint32_t d, uint32_t n) { return p >= d ? p - d : p + n - d; }   // d < n
 
 // Number of bytes on which the rotations starting at p and q agree going BACKWARDS (cyclic), capped at lim.
 // Executed by the WHOLE wave with uniform arguments: while neither side wraps, each of the 64 lanes compares 16
 // bytes, i.e. 1 KB per step (a multi-megabyte repeat is a few thousand steps); the rest goes byte by byte.
-__device__ __forceinline__ uint32_t ld32u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
-
 __device__ __forceinline__ uint32_t lce_back_wave(const uint8_t *__restrict__ T, uint32_t n, uint32_t p, uint32_t q,
                                                   uint32_t lim, uint32_t lane) {
   uint32_t t = 0;
@@ -88,61 +103,138 @@ __device__ __forceinline__ uint32_t lce_back_wave(const uint8_t *__restrict__ T,
   return t;
 }
 
+// One lane: how many of the 16 bytes at backward distances [t, t + 16) from p and q agree (counted from the nearest).
+__device__ __forceinline__ uint32_t match16_back(const uint8_t *__restrict__ T, uint32_t n, uint32_t p, uint32_t q,
+                                                 uint32_t t) {
+  const uint32_t cp = cyc_back(p, t, n), cq = cyc_back(q, t, n);      // next bytes: T[cp-1], T[cq-1] (cyclic)
+  if (cp >= 16u && cq >= 16u) {
+    const uint8_t *a = T + (cp - 16u), *b = T + (cq - 16u);
+    uint32_t match = 16;
+#pragma unroll
+    for (int w = 3; w >= 0; --w) {
+      const uint32_t d = ld32u(a + 4 * w) ^ ld32u(b + 4 * w);
+      if (d && match == 16) match = (uint32_t)(3 - w) * 4u + ((uint32_t)__clz((int)d) >> 3);
+    }
+    return match;
+  }
+  uint32_t i = 0;
+  for (; i < 16u; ++i) {
+    const uint32_t ia = cp > i ? cp - 1u - i : cp + n - 1u - i, ib = cq > i ? cq - 1u - i : cq + n - 1u - i;
+    if (T[ia] != T[ib]) break;
+  }
+  return i;
+}
+
+// Length in bytes of the pass-through chain below the x rows [s, s + x) of plane 0: the number of preceding bytes
+// on which all x rotations agree (0 = none).  Whole wave, uniform arguments.  First one lane per row for the
+// nearest KD_NEAR bytes (most chains of many rows end there); if every row survives that, the whole wave takes
+// the rows one after the other (long repeats: 1 KB per step).
+__device__ __forceinline__ uint32_t chain_bytes(const DfsArgs &a, uint32_t s, uint32_t x, uint32_t lane) {
+  const uint32_t n = a.k.n;
+  const uint32_t pa = a.sa[s];
+  const uint32_t ra = a.isa[pa];
+  uint32_t kk = n - 1;
+  for (uint32_t base = 1; base < x && kk; base += 64) {
+    const uint32_t i = base + lane;
+    bool have = i < x;
+    uint32_t pb = pa;
+    if (have) {
+      pb = a.sa[s + i];
+      if (a.isa[pb] == ra) have = false;                     // identical rotations (periodic input): agree for ever
+    }
+    const uint32_t lim = kk < KD_NEAR ? kk : KD_NEAR;
+    for (uint32_t t = 0; t < lim; t += 16) {
+      const uint32_t m = have ? match16_back(a.text, n, pa, pb, t) : 16u;
+      if (__ballot(m < 16u)) {
+        const uint32_t e = t + wave_min_u32(m);
+        kk = e < kk ? e : kk;
+        break;
+      }
+    }
+  }
+  if (kk > KD_NEAR) {                                         // n - 1 > KD_NEAR here, so the offsets below are < n
+    const uint32_t pa2 = cyc_back(pa, KD_NEAR, n);
+    for (uint32_t i = 1; i < x && kk > KD_NEAR; ++i) {
+      const uint32_t pb = a.sa[s + i];
+      if (a.isa[pb] == ra) continue;
+      kk = KD_NEAR + lce_back_wave(a.text, n, pa2, cyc_back(pb, KD_NEAR, n), kk - KD_NEAR, lane);
+    }
+  }
+  return kk == n - 1 ? 0u : kk;                               // every row identical: cannot happen for a live node
+}
+
+// One pass of the walkers.  Lane = walker.  A walker takes queued nodes gid, gid + W, ... and walks each subtree
+// depth-first; after a.budget classified nodes it hands everything it still holds (current node, stack, queued
+// nodes not started) to the next pass, where each of those gets a walker of its own: that is the load balancing.
 __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   const K3Args &k = a.k;
   const EnumCtl *ctl = k.ctl;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t gid = blockIdx.x * KD_T + threadIdx.x;
-  // my start node: flattened index over the planes' lists
-  uint32_t acc = 0, p0 = 8, idx = 0;
+  const uint32_t W = gridDim.x * KD_T;
+  const uint32_t n = k.n;
+  uint32_t pbase[9];
+  {
+    uint32_t acc = 0;
 #pragma unroll
-  for (uint32_t p = 0; p < 8; ++p) {
-    const uint32_t m = ctl->cnt[k.par][p][0] + ctl->cnt[k.par][p][1];
-    if (p0 == 8 && gid < acc + m) { p0 = p; idx = gid - acc; }
-    acc += m;
+    for (uint32_t p = 0; p < 8; ++p) { pbase[p] = acc; acc += ctl->cnt[k.par][p][0] + ctl->cnt[k.par][p][1]; }
+    pbase[8] = acc;
   }
-  bool alive = p0 != 8;
+  auto fetch = [&](uint32_t q) -> DNode {                     // queued node q of this pass
+    if (a.in) return a.in[q];
+    uint32_t p = 0;
+#pragma unroll
+    for (uint32_t j = 1; j < 8; ++j) p += q >= pbase[j] ? 1u : 0u;
+    const uint32_t idx = q - pbase[p], c0 = ctl->cnt[k.par][p][0];
+    const Node nd = plane_nodes(k, k.par, p)[idx < c0 ? idx : (k.capP - 1u - (idx - c0))];
+    return DNode{nd.s, nd.x0, nd.x1, p, a.round0};
+  };
+  uint32_t next = gid;                                        // my next queued node
+  bool alive = next < a.in_count;
   DNode cur{0u, 1u, 1u, 1u, 0ull};
-  if (alive) {
-    const uint32_t c0 = ctl->cnt[k.par][p0][0];
-    const Node nd = plane_nodes(k, k.par, p0)[idx < c0 ? idx : (k.capP - 1u - (idx - c0))];
-    cur.s = nd.s; cur.x0 = nd.x0; cur.x1 = nd.x1; cur.plane = p0; cur.round = a.round0;
-  }
+  if (alive) { cur = fetch(next); next += W; }
   DNode *stack = a.stacks + (size_t)gid * KD_STACK;
   uint32_t sp = 0;
   uint64_t nodes = 0, maxround = 0;
   uint32_t visited = 0;
-  const uint32_t n = k.n;
+  uint32_t quiet = 8;                                         // pass-through nodes in a row (8 = one whole byte)
   // All 64 lanes stay in the loop until every walker of the wave is finished: finished lanes help with the
   // cooperative text comparisons.
   while (__any(alive)) {
-    if (alive && (++visited > a.budget || a.dctl->err)) { if (!a.dctl->err) a.dctl->err = 3; alive = false; }
-    // ---- chain skip: lanes at plane 0 with few rows, served one after the other by the whole wave ----
+    if (alive && (visited >= a.budget || a.dctl->err)) {
+      // hand on: current node, stack, queued nodes not started
+      uint32_t rest = 0;
+      if (next < a.in_count) rest = (a.in_count - next + W - 1u) / W;
+      const uint32_t cnt = 1u + sp + rest;
+      const uint32_t o = atomicAdd(&a.dctl->queued, cnt);
+      if (o + cnt > a.out_cap) { a.dctl->err = 4; }
+      else {
+        a.out[o] = cur;
+        for (uint32_t j = 0; j < sp; ++j) a.out[o + 1u + j] = stack[j];
+        for (uint32_t j = 0; j < rest; ++j) a.out[o + 1u + sp + j] = fetch(next + j * W);
+      }
+      alive = false;
+    }
+    // ---- chain skip: lanes at plane 0 after a whole byte of pass-through, served one after the other by the wave ----
     const uint32_t x = cur.x0 + cur.x1;
-    uint64_t want = __ballot(alive && a.skip_ok && cur.plane == 0 && x <= KD_MAXX);
+    uint64_t want = __ballot(alive && a.skip_ok && cur.plane == 0 && x <= KD_MAXX && quiet >= 8u);
     uint32_t mykk = 0;
     while (want) {
       const int L = __ffsll((long long)want) - 1;
       want &= want - 1;
       const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)cur.s, L);
       const uint32_t xL = (uint32_t)__builtin_amdgcn_readlane((int)x, L);
-      const uint32_t pa = a.sa[sL];
-      uint32_t kk = n - 1;
-      const uint32_t ra = a.isa[pa];
-      for (uint32_t i = 1; i < xL && kk; ++i) {
-        const uint32_t pb = a.sa[sL + i];
-        if (a.isa[pb] == ra) continue;                       // identical rotations (periodic input): agree for ever
-        kk = lce_back_wave(a.text, n, pa, pb, kk, lane);
-      }
-      if (kk == n - 1) kk = 0;                               // every row identical: cannot happen for a live node
-      if ((int)lane == L) mykk = kk;
+      const uint32_t kk = chain_bytes(a, sL, xL, lane);
+      if ((int)lane == L) { mykk = kk; if (!kk) quiet = 0; }
     }
     if (alive) {
+      ++visited;
       if (mykk) {                                    // mykk whole bytes of pass-through: 8*mykk rounds, no symbols
         const uint32_t pa = a.sa[cur.s];
-        cur.s = a.isa[pa >= mykk ? pa - mykk : pa + n - mykk];
+        cur.s = a.isa[cyc_back(pa, mykk, n)];
         cur.round += 8ull * mykk;
         nodes += 8ull * mykk;
+        if (a.dbg) { atomicAdd(&a.dctl->dbg_skips, 1u); atomicAdd((unsigned long long *)&a.dctl->dbg_skipbytes, (unsigned long long)mykk); }
       }
       const uint32_t p = cur.plane;
       const Granule *G = k.gran + (size_t)p * k.ngran;
@@ -157,7 +249,9 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
       Node c0, c1;
       node_flat_post(nd, k.zeros[p], nf, granule_rank1(qm, nd.s + nd.x0 - gm * 96u), has0, c0, has1, c1, sym, kq);
       ++nodes;
+      if (a.dbg) atomicAdd(&a.dctl->dbg_hist[31 - __clz((int)(nd.x0 + nd.x1))], 1u);
       maxround = cur.round > maxround ? cur.round : maxround;
+      quiet = (nf.need_mid || (has0 && has1)) ? 0u : quiet + 1u;
       if (nf.need_mid) {
         const uint32_t i = atomicAdd(&a.dctl->nsym, 1u);
         if (i >= a.symcap) { a.dctl->err = 2; alive = false; }
@@ -172,15 +266,26 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
       }
       const uint32_t pn = (p + 1u) & 7u;
       if (has0 && has1) {
-        if (sp >= KD_STACK) { a.dctl->err = 1; alive = false; }
-        else stack[sp++] = DNode{c1.s, c1.x0, c1.x1, pn, cur.round + 1};
+        if (sp >= KD_STACK) {                                // full: the older half becomes queued nodes of the next pass
+          const uint32_t h = KD_STACK / 2;
+          const uint32_t o = atomicAdd(&a.dctl->queued, h);
+          if (o + h > a.out_cap) { a.dctl->err = 4; alive = false; }
+          else {
+            for (uint32_t j = 0; j < h; ++j) a.out[o + j] = stack[j];
+            for (uint32_t j = h; j < sp; ++j) stack[j - h] = stack[j];
+            sp -= h;
+          }
+        }
+        stack[sp++] = DNode{c1.s, c1.x0, c1.x1, pn, cur.round + 1};
       }
       if (has0) { cur = DNode{c0.s, c0.x0, c0.x1, pn, cur.round + 1}; }
       else if (has1) { cur = DNode{c1.s, c1.x0, c1.x1, pn, cur.round + 1}; }
-      else if (sp) { cur = stack[--sp]; }
+      else if (sp) { cur = stack[--sp]; quiet = 8; }
+      else if (next < a.in_count) { cur = fetch(next); next += W; quiet = 8; }
       else alive = false;
     }
   }
+  if (a.dbg) atomicMax(&a.dctl->dbg_maxvis, visited);
   atomicAdd((unsigned long long *)&a.dctl->nodes, (unsigned long long)nodes);
   atomicMax((unsigned long long *)&a.dctl->maxround, (unsigned long long)maxround);
 }
@@ -203,24 +308,32 @@ __global__ void kd_place_kernel(const uint32_t *__restrict__ tkey, const uint32_
   }
 }
 
-// Host side.  The walkers start when the node count has stopped growing, at most K3_DFS_ENTER nodes are alive and
-// an eighth of all nodes has been visited (i.e. not in the ramp-up); a walker that meets a bushy subtree instead
-// of chains gives up after K3_DFS_BUDGET nodes and the attempt is abandoned.
-// Preconditions (checked by the caller): the symbol buffer is empty (everything emitted so far has been flushed),
-// `ctl` is current.  On success the symbol buffer holds the tail's symbols in stream order,
-// run_log holds one run per plane, and *done = true.  On a walker error nothing has been changed and the caller
-// continues with the round-based kernels.
-int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, bool *done) {
+// Host side.  The walkers start when the node count has stopped growing, at most `enter` nodes are alive and an
+// eighth of all nodes has been visited (i.e. not in the ramp-up).  Passes follow each other until no node is
+// queued.  Preconditions (checked by the caller): the symbol buffer is empty (everything emitted so far has been
+// flushed), `ctl` is current.  On success the symbol buffer holds the tail's symbols in stream order, run_log
+// holds one run per plane, and *done = true.  On an error (more symbols than the tagged buffer holds, queue full)
+// nothing has been changed and the caller continues with the round-based kernels.
+int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) {
   *done = false;
   if (c->scan_mode || c->dbg_no_dfs) return BCE_HIP_OK;
   const uint32_t n = c->n;
   const uint32_t live = ctl.next_nodes;
   const uint64_t all = 8ull * (n - 1);
-  if (live == 0 || live > K3_DFS_ENTER || ctl.nodes_total < all / 8) return BCE_HIP_OK;
-  const uint32_t cap = K3_DFS_SYMCAP;
-  // carve: tkey tesc ts trlo trhi | sort keys x2 vals x2 | DfsCtl | stacks
-  const size_t o_sort = (size_t)cap * 4 * 5, o_ctl = o_sort + (size_t)cap * 4 * 4, o_stack = o_ctl + 256;
-  BCE_TRY(ensure(c, c->dfs, o_stack + (size_t)K3_DFS_ENTER * KD_STACK * sizeof(DNode)));
+  if (live == 0 || live > enter || ctl.nodes_total < all / 8) return BCE_HIP_OK;
+  // tagged symbols: the tail is mostly pass-through, a fraction of the nodes that are left is plenty
+  const uint64_t left = all > ctl.nodes_total ? all - ctl.nodes_total : 0;
+  uint64_t cap64 = left / 8 + (1u << 20);
+  if (cap64 < (4u << 20)) cap64 = 4u << 20;
+  if (cap64 > (32u << 20)) cap64 = 32u << 20;
+  if (cap64 > left + 64) cap64 = left + 64;                  // a node codes at most one symbol
+  const uint32_t cap = ((uint32_t)cap64 + 63u) & ~63u;       // keeps the carved arrays 8-byte aligned
+  const uint32_t qcap = (uint32_t)(left + 64 < KD_QUEUE ? left + 64 : KD_QUEUE);      // queued nodes are distinct unvisited nodes
+  const uint32_t wmax = qcap < KD_WALKERS ? qcap : KD_WALKERS;
+  // carve: tkey tesc ts trlo trhi | sort keys x2 vals x2 | DfsCtl | queue x2 | stacks
+  const size_t o_sort = (size_t)cap * 4 * 5, o_ctl = o_sort + (size_t)cap * 4 * 4, o_q = o_ctl + 512,
+               o_stack = o_q + 2 * (size_t)qcap * sizeof(DNode);
+  BCE_TRY(ensure(c, c->dfs, o_stack + (size_t)wmax * KD_STACK * sizeof(DNode)));
   uint8_t *base = c->dfs.as<uint8_t>();
   DfsArgs a;
   a.k = k3_make_args(c, c->round, 0);
@@ -233,17 +346,37 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, bool *done) {
   uint32_t *sk[2] = {reinterpret_cast<uint32_t *>(base + o_sort), reinterpret_cast<uint32_t *>(base + o_sort) + cap};
   uint32_t *sv[2] = {reinterpret_cast<uint32_t *>(base + o_sort) + 2 * (size_t)cap, reinterpret_cast<uint32_t *>(base + o_sort) + 3 * (size_t)cap};
   a.dctl = reinterpret_cast<DfsCtl *>(base + o_ctl);
+  DNode *queue[2] = {reinterpret_cast<DNode *>(base + o_q), reinterpret_cast<DNode *>(base + o_q) + qcap};
   a.stacks = reinterpret_cast<DNode *>(base + o_stack);
   a.round0 = c->round;
   a.symcap = cap;
-  a.budget = c->dbg_dfs_budget ? c->dbg_dfs_budget : K3_DFS_BUDGET;
+  a.out_cap = qcap;
+  a.budget = c->dbg_dfs_budget ? c->dbg_dfs_budget : K3_DFS_PASS;
+  a.dbg = getenv("BCE_HIP_DFS_DEBUG") ? 1u : 0u;
   BCE_HIP_TRY(c, hipMemsetAsync(a.dctl, 0, sizeof(DfsCtl), c->stream));
-  hipLaunchKernelGGL(k3_dfs_kernel, dim3((live + KD_T - 1) / KD_T), dim3(KD_T), 0, c->stream, a);
   DfsCtl h;
-  BCE_HIP_TRY(c, hipMemcpyAsync(&h, a.dctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
-  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  BCE_HIP_TRY(c, hipGetLastError());
-  c->stats.k3_launches += 1.0;
+  uint32_t count = live, passes = 0;
+  const DNode *in = nullptr;
+  for (;;) {
+    a.in = in; a.in_count = count; a.out = queue[passes & 1];
+    const uint32_t walkers = count < wmax ? count : wmax;
+    hipLaunchKernelGGL(k3_dfs_kernel, dim3((walkers + KD_T - 1) / KD_T), dim3(KD_T), 0, c->stream, a);
+    BCE_HIP_TRY(c, hipMemcpyAsync(&h, a.dctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    BCE_HIP_TRY(c, hipGetLastError());
+    c->stats.k3_launches += 1.0;
+    ++passes;
+    if (h.err || h.queued == 0) break;
+    in = queue[(passes - 1) & 1];
+    count = h.queued;
+    BCE_HIP_TRY(c, hipMemsetAsync(&a.dctl->queued, 0, 4, c->stream));
+  }
+  if (a.dbg) {
+    fprintf(stderr, "dfs: live %u passes %u err %u nsym %u (cap %u) nodes %llu maxround %llu maxvisited %u skips %u skipbytes %llu\n", live,
+            passes, h.err, h.nsym, cap, (unsigned long long)h.nodes, (unsigned long long)h.maxround, h.dbg_maxvis, h.dbg_skips,
+            (unsigned long long)h.dbg_skipbytes);
+    for (int i = 0; i < 32; ++i) if (h.dbg_hist[i]) fprintf(stderr, "  x in [2^%d, 2^%d): %u nodes\n", i, i + 1, h.dbg_hist[i]);
+  }
   if (h.err) return BCE_HIP_OK;                     // fall back to the rounds; nothing was modified
   const uint32_t m = h.nsym;
   if (m > c->sym_cap) BCE_TRY(k3_grow_symbols(c, (uint64_t)m + 1024));

@@ -92,3 +92,36 @@ def test_exactly_periodic_input_with_a_large_period():
     assert arch == oracle.compress(data)
     assert bce_amd.decompress(arch) == data
     assert dt < 10.0
+
+
+def many_copies(copies, length, seed):
+    """`copies` copies of one block, each followed by a different separator: chains of `copies` rows."""
+    block = oracle.synth_text(seed, length)
+    out = bytearray(oracle.synth_text(seed + 1, 20000))
+    for i in range(copies):
+        out += block + b"<%06d>" % (i * 7919 % 1000003)
+    out += oracle.synth_text(seed + 2, 20000)
+    return bytes(out)
+
+
+@pytest.mark.parametrize("copies,length", [(40, 3000), (150, 600), (9, 200), (700, 40), (3, 70000)])
+def test_many_row_chains_match_oracle(copies, length):
+    """Chains of many rows: the skip compares all rows (one lane per row for the near bytes, then the whole wave
+    per row pair), in batches of 64 rows; every path and the walkers without skipping give the oracle's archive."""
+    data = many_copies(copies, length, 31)
+    want = oracle.compress(data)
+    for knobs in ({}, {3: 1}, {0: 7}, {1: 1}):
+        arch, st = _encode_with_knobs(data, knobs)
+        assert arch == want, "knobs %r" % (knobs,)
+        assert st["nodes"] == 8 * len(data) - 8
+    assert bce_amd.decompress(want) == data
+
+
+def test_periodic_blocks_with_many_rows():
+    """A block repeated back to back (periodic stretch, overlapping rows) inside other text."""
+    unit = oracle.synth_text(77, 257)
+    data = oracle.synth_text(78, 30000) + unit * 60 + oracle.synth_text(79, 30000) + unit * 12 + b"!"
+    want = oracle.compress(data)
+    for knobs in ({}, {3: 1}, {0: 5}):
+        arch, _ = _encode_with_knobs(data, knobs)
+        assert arch == want, "knobs %r" % (knobs,)
