@@ -302,6 +302,7 @@ int k1_bwt(bce_hip_ctx *c) {
   };
   BCE_TRY(rerank(key[res], nullptr, val[res]));
   const uint32_t bits = ceil_log2(n);
+  const uint32_t dg = 9;   // digit width of the rank sorts (7..9 measured equal)
   uint64_t h = 4;
   uint32_t *act[2] = {c->act[0].as<uint32_t>(), c->act[1].as<uint32_t>()};
   uint32_t m = n;                 // active elements; the list is implicit (identity) while every element is active
@@ -334,13 +335,13 @@ int k1_bwt(bce_hip_ctx *c) {
       hipLaunchKernelGGL(k1_act_gather_kernel, dim3(ga), dim3(K1_T), 0, c->stream, A, val[res], rank, n, m, (uint32_t)h,
                          ki[0], vi[0]);
       int r1 = 0;
-      BCE_TRY(radix_sort_pairs(c, ki, vi, m, 0, bits, &r1, 9));
+      BCE_TRY(radix_sort_pairs(c, ki, vi, m, 0, bits, &r1, dg));
       // second sort: by group, input = output of the first
       uint32_t *kj[2] = {ki[r1 ^ 1], ki[r1]};
       uint32_t *vj[2] = {vi[r1], vi[r1 ^ 1]};
       hipLaunchKernelGGL(k1_act_group_kernel, dim3(ga), dim3(K1_T), 0, c->stream, vj[0], rank, m, kj[0]);
       int r2 = 0;
-      BCE_TRY(radix_sort_pairs(c, kj, vj, m, 0, bits, &r2, 9));
+      BCE_TRY(radix_sort_pairs(c, kj, vj, m, 0, bits, &r2, dg));
       const K1Plan ap = k1_plan(m);
       hipLaunchKernelGGL(k1_act_heads_kernel, dim3(ap.nb), dim3(K1_T), 0, c->stream, A, vj[r2], kj[r2], rank, n, m,
                          (uint32_t)h, ap.per_block, val[res], nrk, blockmax);
@@ -360,7 +361,7 @@ int k1_bwt(bce_hip_ctx *c) {
     hipLaunchKernelGGL(k1_gather_prev_kernel, dim3(g), dim3(K1_T), 0, c->stream, val[res], rank, n, (uint32_t)h,
                        ki[0], vi[0]);
     int r2 = 0;
-    BCE_TRY(radix_sort_pairs(c, ki, vi, n, 0, bits, &r2, 9));
+    BCE_TRY(radix_sort_pairs(c, ki, vi, n, 0, bits, &r2, dg));
     uint32_t *sk = ki[r2], *ssa = vi[r2];
     hipLaunchKernelGGL(k1_gather_next_kernel, dim3(g), dim3(K1_T), 0, c->stream, ssa, rank, n, (uint32_t)h, k2);
     BCE_TRY(rerank(sk, k2, ssa));

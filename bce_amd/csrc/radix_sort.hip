@@ -5,17 +5,19 @@
 // match-any masks (one ballot per digit bit) + popcount of the lower lanes; per-wave digit counters
 // live in LDS and are bumped once per peer group (one ds_add_rtn per distinct digit per 64 keys).
 // Each block owns ONE contiguous range of the input, so the digit-major histogram matrix is at most
-// 256 x 1024 and a single-block scan suffices; per pass: histogram, scan, scatter.
+// 512 x 768 and one block per digit row scans it; per pass: histogram, scan, scatter.
+// The scatter reorders each 4096-pair chunk by digit in LDS first, so that consecutive lanes write consecutive
+// addresses of a digit's output segment (64 B+ runs instead of 4 B scatters).
 #include "common.h"
 #include "scan_util.h"
 
 namespace bce {
 
 constexpr int RS_THREADS = 256;
-constexpr int RS_ITEMS = 8;
-constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;  // 2048 keys per block iteration
-constexpr int RS_MAXB = 1024;
-constexpr int RS_MAXBITS = 10;                   // digit width per pass (<= 1024 bins)
+constexpr int RS_ITEMS = 16;
+constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;  // 4096 keys per block iteration
+constexpr int RS_MAXB = 768;                     // 3 blocks per CU (44 KB of LDS each) x 256 CUs
+constexpr int RS_MAXBITS = 9;                    // digit width per pass (<= 512 bins)
 constexpr int RS_MAXBINS = 1 << RS_MAXBITS;
 
 struct RsPlan { uint32_t nb, per_block; };
@@ -39,13 +41,15 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, int nbits, bool vali
   return valid ? peers : 0ull;
 }
 
+// Per-block digit histogram.  Counting needs no ranks: one LDS add per key into the wave's private row (a wave
+// whose 64 keys share the digit -- the usual case in the top passes -- adds 64 at once instead of colliding).
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n,
                                                              uint32_t per_block, uint32_t nb, int shift, int nbits,
                                                              uint32_t *__restrict__ hist) {
-  __shared__ uint32_t lh[RS_MAXBINS];
-  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  __shared__ uint32_t lh[4][RS_MAXBINS];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
   const uint32_t nbins = 1u << nbits, mask = nbins - 1u;
-  for (uint32_t d = tid; d < nbins; d += RS_THREADS) lh[d] = 0;
+  for (uint32_t d = tid; d < nbins; d += RS_THREADS) { lh[0][d] = 0; lh[1][d] = 0; lh[2][d] = 0; lh[3][d] = 0; }
   __syncthreads();
   const uint64_t beg = (uint64_t)blockIdx.x * per_block;
   uint64_t end = beg + per_block;
@@ -62,12 +66,16 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint32_t *__r
       const uint64_t i = base + (uint64_t)it * RS_THREADS + tid;
       const bool valid = i < end;
       const uint32_t d = (k[it] >> shift) & mask;
-      const uint64_t peers = match_digit(d, nbits, valid);
-      if (valid && lane == (uint32_t)(__ffsll((long long)peers) - 1)) atomicAdd(&lh[d], (uint32_t)__popcll(peers));
+      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+      if (__all(valid && d == d0)) {
+        if (lane == 0) atomicAdd(&lh[w][d0], 64u);
+      } else if (valid) {
+        atomicAdd(&lh[w][d], 1u);
+      }
     }
   }
   __syncthreads();
-  for (uint32_t d = tid; d < nbins; d += RS_THREADS) hist[(size_t)d * nb + blockIdx.x] = lh[d];
+  for (uint32_t d = tid; d < nbins; d += RS_THREADS) hist[(size_t)d * nb + blockIdx.x] = lh[0][d] + lh[1][d] + lh[2][d] + lh[3][d];
 }
 
 // One block per digit: exclusive scan of the digit's row hist[d][0..nb) in place (coalesced), row total aside.
@@ -94,24 +102,27 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
                                                                 uint32_t per_block, uint32_t nb, int shift, int nbits,
                                                                 const uint32_t *__restrict__ hist,
                                                                 const uint32_t *__restrict__ rowtotal) {
-  __shared__ uint32_t wcnt[4][RS_MAXBINS];
-  __shared__ uint32_t goff[RS_MAXBINS];
+  __shared__ uint32_t wcnt[4][RS_MAXBINS];     // per-wave digit counts of the chunk, then per-wave local bases
+  __shared__ uint32_t goff[RS_MAXBINS];        // this block's next output position per digit
+  __shared__ uint32_t gdelta[RS_MAXBINS];      // output position - position in the chunk's LDS order (mod 2^32)
+  __shared__ uint32_t skey[RS_CHUNK], sval[RS_CHUNK];
+  constexpr int BPT = RS_MAXBINS / RS_THREADS;  // digits per thread in the per-digit steps
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
   const uint32_t nbins = 1u << nbits, mask = nbins - 1u;
-  // digit bases: exclusive scan of the row totals (<= 1024 entries, 4 per thread), plus this block's row offset
+  // digit bases: exclusive scan of the row totals, plus this block's row offset
   {
-    uint32_t v[RS_MAXBINS / RS_THREADS], sum = 0;
+    uint32_t v[BPT], sum = 0;
 #pragma unroll
-    for (int q = 0; q < RS_MAXBINS / RS_THREADS; ++q) {
-      const uint32_t d = tid * (RS_MAXBINS / RS_THREADS) + q;
+    for (int q = 0; q < BPT; ++q) {
+      const uint32_t d = tid * BPT + q;
       v[q] = d < nbins ? rowtotal[d] : 0u;
       sum += v[q];
     }
     uint32_t tot;
     uint32_t run = block_excl_scan_sum<RS_THREADS>(sum, &tot);
 #pragma unroll
-    for (int q = 0; q < RS_MAXBINS / RS_THREADS; ++q) {
-      const uint32_t d = tid * (RS_MAXBINS / RS_THREADS) + q;
+    for (int q = 0; q < BPT; ++q) {
+      const uint32_t d = tid * BPT + q;
       if (d < nbins) goff[d] = run + hist[(size_t)d * nb + blockIdx.x];
       run += v[q];
     }
@@ -121,21 +132,22 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
   if (end > n) end = n;
   const uint64_t lt = (1ull << lane) - 1ull;
   for (uint64_t base = beg; base < end; base += RS_CHUNK) {
+    const uint32_t cnt = (uint32_t)(end - base < (uint64_t)RS_CHUNK ? end - base : (uint64_t)RS_CHUNK);
     for (uint32_t d = tid; d < nbins; d += RS_THREADS) { wcnt[0][d] = 0; wcnt[1][d] = 0; wcnt[2][d] = 0; wcnt[3][d] = 0; }
     __syncthreads();
     uint32_t key[RS_ITEMS], val[RS_ITEMS], lr[RS_ITEMS];
-    // wave w owns the contiguous quarter [base + w*512, base + (w+1)*512): order = (wave, step, lane)
+    // wave w owns the contiguous quarter [w*1024, (w+1)*1024) of the chunk: order = (wave, step, lane)
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
-      const uint64_t i = base + (uint64_t)w * (RS_CHUNK / 4) + (uint64_t)it * 64 + lane;
-      const bool valid = i < end;
-      key[it] = valid ? keys_in[i] : 0u;
-      val[it] = valid ? vals_in[i] : 0u;
+      const uint32_t q = w * (RS_CHUNK / 4) + (uint32_t)it * 64u + lane;
+      const bool valid = q < cnt;
+      key[it] = valid ? keys_in[base + q] : 0u;
+      val[it] = valid ? vals_in[base + q] : 0u;
     }
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
-      const uint64_t i = base + (uint64_t)w * (RS_CHUNK / 4) + (uint64_t)it * 64 + lane;
-      const bool valid = i < end;
+      const uint32_t q = w * (RS_CHUNK / 4) + (uint32_t)it * 64u + lane;
+      const bool valid = q < cnt;
       const uint32_t d = (key[it] >> shift) & mask;
       const uint64_t peers = match_digit(d, nbits, valid);
       const uint32_t leader = valid ? (uint32_t)(__ffsll((long long)peers) - 1) : lane;
@@ -145,21 +157,51 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
       lr[it] = pre + (uint32_t)__popcll(peers & lt);
     }
     __syncthreads();
-    for (uint32_t d = tid; d < nbins; d += RS_THREADS) {
-      const uint32_t c0 = wcnt[0][d], c1 = wcnt[1][d], c2 = wcnt[2][d], c3 = wcnt[3][d];
-      const uint32_t b = goff[d];
-      wcnt[0][d] = b; wcnt[1][d] = b + c0; wcnt[2][d] = b + c0 + c1; wcnt[3][d] = b + c0 + c1 + c2;
-      goff[d] = b + c0 + c1 + c2 + c3;
+    {
+      // chunk-local digit bases (exclusive scan over the digits), per-wave bases, output deltas
+      uint32_t c[BPT][4], sum = 0;
+#pragma unroll
+      for (int q = 0; q < BPT; ++q) {
+        const uint32_t d = tid * BPT + q;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { c[q][ww] = d < nbins ? wcnt[ww][d] : 0u; sum += c[q][ww]; }
+      }
+      uint32_t tot;
+      uint32_t run = block_excl_scan_sum<RS_THREADS>(sum, &tot);
+#pragma unroll
+      for (int q = 0; q < BPT; ++q) {
+        const uint32_t d = tid * BPT + q;
+        if (d < nbins) {
+          const uint32_t t4 = c[q][0] + c[q][1] + c[q][2] + c[q][3];
+          wcnt[0][d] = run; wcnt[1][d] = run + c[q][0]; wcnt[2][d] = run + c[q][0] + c[q][1];
+          wcnt[3][d] = run + c[q][0] + c[q][1] + c[q][2];
+          const uint32_t g = goff[d];
+          gdelta[d] = g - run;
+          goff[d] = g + t4;
+          run += t4;
+        }
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
-      const uint64_t i = base + (uint64_t)w * (RS_CHUNK / 4) + (uint64_t)it * 64 + lane;
-      if (i < end) {
+      const uint32_t q = w * (RS_CHUNK / 4) + (uint32_t)it * 64u + lane;
+      if (q < cnt) {
         const uint32_t d = (key[it] >> shift) & mask;
         const uint32_t pos = wcnt[w][d] + lr[it];
-        keys_out[pos] = key[it];
-        vals_out[pos] = val[it];
+        skey[pos] = key[it];
+        sval[pos] = val[it];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+      const uint32_t q = (uint32_t)it * RS_THREADS + tid;
+      if (q < cnt) {
+        const uint32_t k = skey[q];
+        const uint32_t pos = gdelta[(k >> shift) & mask] + q;
+        keys_out[pos] = k;
+        vals_out[pos] = sval[q];
       }
     }
     __syncthreads();
