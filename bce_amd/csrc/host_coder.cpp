@@ -70,41 +70,42 @@ void HostCoder::begin(const uint8_t config[9][32], const uint32_t C[8], uint32_t
 // 64-bit divide on the coder's dependency chain (step = (h - l) / total, bce.cpp:527); the quotient is
 // bit-identical.  x = 2^64 - 1 (right after a range reset) and larger divisors take the real divide.
 namespace {
-struct Recip { uint64_t m; uint32_t add; uint32_t sh; };
+struct Recip { uint64_t m; int32_t am1; uint32_t sh; };   // am1 = add - 1: the multiplicand is (r + 1) + am1
 constexpr uint32_t kRecipMax = 8192;
 const Recip *recip_table() {
   static const std::vector<Recip> tab = [] {
     std::vector<Recip> t(kRecipMax);
-    t[0] = t[1] = Recip{0, 0, 0};
+    t[0] = t[1] = Recip{0, -1, 0};
     for (uint32_t d = 2; d < kRecipMax; ++d) {
       uint32_t L = 0;
       while ((2ull << L) <= d) ++L;                       // floor(log2 d)
-      if ((d & (d - 1)) == 0) { t[d] = Recip{1ull << (64 - L), 0, 0}; continue; }
+      if ((d & (d - 1)) == 0) { t[d] = Recip{1ull << (64 - L), -1, 0}; continue; }
       const unsigned __int128 two_s = (unsigned __int128)1 << (64 + L);
       const uint64_t m_dn = (uint64_t)(two_s / d);
       const uint64_t e_dn = (uint64_t)(two_s - (unsigned __int128)m_dn * d);   // e'
       const uint64_t e_up = d - e_dn;                                           // e
-      if (e_up <= (1ull << L)) t[d] = Recip{m_dn + 1, 0, L};
-      else t[d] = Recip{m_dn, 1, L};
+      if (e_up <= (1ull << L)) t[d] = Recip{m_dn + 1, -1, L};
+      else t[d] = Recip{m_dn, 0, L};
     }
     return t;
   }();
   return tab.data();
 }
-inline uint64_t div_recip(uint64_t x, const Recip &r) {   // requires x != 2^64 - 1
-  return (uint64_t)(((unsigned __int128)r.m * (x + r.add)) >> 64) >> r.sh;
+inline uint64_t div_recip1(uint64_t x1, const Recip &r) {   // floor((x1 - 1) / d) for x1 = x + 1 != 0
+  return (uint64_t)(((unsigned __int128)r.m * (x1 + (uint64_t)(int64_t)r.am1)) >> 64) >> r.sh;
 }
 }  // namespace
 
 uint64_t bce_test_div_recip(uint64_t x, uint32_t d) {
-  return x == ~0ull ? x / d : div_recip(x, recip_table()[d]);
+  return x == ~0ull ? x / d : div_recip1(x + 1, recip_table()[d]);
 }
 
-// Same arithmetic as encode() (bce.cpp:520-529 + shift_out :655-661) on the pair (l, r = h - l): the next
-// range r' = step * freq - 1 then depends on r alone, and l accumulates off the critical chain.
+// Same arithmetic as encode() (bce.cpp:520-529 + shift_out :655-661) on the pair (l, R = h - l + 1): the next
+// R' = step * freq depends on R alone (one add, one high multiply, one shift, one multiply), l accumulates off
+// the critical chain, and shift_out is l <<= 16, R <<= 16.  R == 0 stands for the full range (h - l = 2^64 - 1).
 void RangeCoder::encode_run(const uint64_t *out, uint64_t begin, uint64_t end) {
   const Recip *rt = recip_table();
-  uint64_t l = l_, r = h_ - l_;                         // kept in registers: the chain is r -> step -> r
+  uint64_t l = l_, R = h_ - l_ + 1;
   uint16_t stage[64];                                   // output words, appended to data_ 64 at a time
   uint32_t ns = 0;
 #define BCE_EMIT(v)                                                                                       \
@@ -115,18 +116,18 @@ void RangeCoder::encode_run(const uint64_t *out, uint64_t begin, uint64_t end) {
 #define BCE_STEP(cum, freq, total)                                                                        \
   do {                                                                                                    \
     const uint32_t t_ = (total);                                                                          \
-    if (__builtin_expect(r < t_, 0)) {                  /* :520-525 */                                    \
+    if (__builtin_expect(R - 1 < t_, 0)) {              /* :520-525 */                                    \
       for (int i_ = 0; i_ < 4; ++i_) BCE_EMIT(l >> (48 - 16 * i_));                                       \
-      l = 0; r = ~0ull;                                                                                   \
+      l = 0; R = 0;                                                                                       \
     }                                                                                                     \
     const uint64_t step_ =                                                                                \
-        (__builtin_expect(r == ~0ull, 0) || t_ >= kRecipMax) ? r / t_ : div_recip(r, rt[t_]);             \
+        (__builtin_expect(R == 0, 0) || t_ >= kRecipMax) ? (R - 1) / t_ : div_recip1(R, rt[t_]);          \
     l += step_ * (cum);                                 /* :528 */                                        \
-    r = step_ * (freq) - 1;                             /* h = l + step*freq - 1  (:529) */               \
-    while (__builtin_expect(!(((l + r) ^ l) >> 48), 0)) {   /* shift_out :655-661 */                      \
-      BCE_EMIT((l + r) >> 48);                                                                            \
+    R = step_ * (freq);                                 /* h = l + step*freq - 1  (:529) */               \
+    while (__builtin_expect(!(((l + R - 1) ^ l) >> 48), 0)) {   /* shift_out :655-661 */                  \
+      BCE_EMIT((l + R - 1) >> 48);                                                                        \
       l <<= 16;                                                                                           \
-      r = (r << 16) | 0xFFFF;                                                                             \
+      R <<= 16;                                         /* ((r << 16) | 0xFFFF) + 1 */                    \
     }                                                                                                     \
   } while (0)
   for (uint64_t i = begin; i < end; ++i) {
@@ -139,7 +140,7 @@ void RangeCoder::encode_run(const uint64_t *out, uint64_t begin, uint64_t end) {
 #undef BCE_STEP
 #undef BCE_EMIT
   data_.insert(data_.end(), stage, stage + ns);
-  l_ = l; h_ = l + r;
+  l_ = l; h_ = l + R - 1;
 }
 
 void HostCoder::consume(int p, const SymRun *runs, size_t nruns, const uint64_t *out) {
