@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--size", type=int, default=100_000_000, help="input bytes per GPU (enwik8 = 10^8)")
     ap.add_argument("--workload", default="synth-text", choices=["synth-text", "synth-rand"])
     ap.add_argument("--file", default=os.environ.get("BCE_BENCH_FILE"))
-    ap.add_argument("--cpu-sample", type=int, default=64 << 20, help="bytes of the workload the CPU baseline compresses")
+    ap.add_argument("--cpu-sample", type=int, default=48 << 20, help="bytes of the workload the CPU baseline compresses")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--scan-config", action="store_true",
                     help="BASELINE config 5: run `bce -s` on the input first (untimed), compress with the scanned table")
@@ -59,15 +59,25 @@ def make_input(args, rank):
 
 
 def cpu_baseline(data, sample_bytes):
-    """The oracle (bit-exact CPU restatement of bce -c) timed on this host, 1 thread, bounded sample."""
+    """The oracle (bit-exact CPU restatement of bce -c) timed on this host on a bounded sample: single thread (the
+    reference built without OpenMP) and 8 threads (its OpenMP build: one thread per plane, joined every round,
+    bce.cpp:1250-1252; suffix sort and plane build stay serial there too).  The faster one is `value`."""
     import oracle
     oracle.build()
     sample = data[:sample_bytes].tobytes()
-    t0 = time.time()
-    arch = oracle.compress(sample)
-    dt = time.time() - t0
-    return {"value": round(len(sample) / dt / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": "port",
-            "sample": "first %d B of the workload, oracle/bce_oracle.c single thread, %.1f s, archive %d B" % (len(sample), dt, len(arch)),
+    runs = {}
+    for threads in (1, 8):
+        oracle.set_threads(threads)
+        t0 = time.time()
+        arch = oracle.compress(sample)
+        runs[threads] = (time.time() - t0, len(arch), hashlib.sha256(arch).hexdigest())
+    oracle.set_threads(1)
+    assert runs[1][2] == runs[8][2]
+    best = min(runs, key=lambda t: runs[t][0])
+    return {"value": round(len(sample) / runs[best][0] / 1e6, 3), "unit": "MB/s", "cores": best, "kind": "port",
+            "sample": "first %d B of the workload, oracle/bce_oracle.c: 1 thread %.1f s (%.2f MB/s), 8 OpenMP threads %.1f s (%.2f MB/s), archive %d B" % (
+                len(sample), runs[1][0], len(sample) / runs[1][0] / 1e6, runs[8][0], len(sample) / runs[8][0] / 1e6, runs[1][1]),
+            "single_thread_value": round(len(sample) / runs[1][0] / 1e6, 3),
             "host_cpus": os.cpu_count()}
 
 

@@ -240,7 +240,7 @@ typedef struct {
   uint8_t *stat_;
   uint32_t stat_size;
   int id;       /* 0..7 plane coder, 8 header coder (trace only) */
-} Coder;
+} __attribute__((aligned(128))) Coder;   /* own cache lines per coder: the OpenMP baseline should not lose to false sharing */
 
 static void coder_shift_out(Coder *c) {                                   /* :655-661 */
   while (!((c->h_ ^ c->l_) >> 48)) {
@@ -322,19 +322,25 @@ static void coder_free(Coder *c) { free(c->data_.p); free(c->stat_); }
  * (bce.cpp:226-356,1237) are plain arrays of (delta, x0, x1) here: pArray stores exactly the
  * values pushed, so the queue contents are the same.
  * ---------------------------------------------------------------------------------------------- */
+static int g_threads = 1;   /* bce_oracle_set_threads: 1 = the reference built without OpenMP, 8 = with (CMakeLists.txt) */
+
 static void bce_code(Coder coder_[8], const uint32_t C[8], Rank ranks[8], uint32_t n) {
-  vec32 Q[8][4];
-  memset(Q, 0, sizeof Q);
+  typedef struct { vec32 q[4]; } __attribute__((aligned(128))) PlaneQ;   /* the four queues of a plane (:1237) */
+  PlaneQ QQ[8];
+  memset(QQ, 0, sizeof QQ);
+#define Q(i, j) QQ[i].q[j]
   for (int i = 0; i < 8; ++i)
-    if (C[i] && n - C[i]) v32_push3(&Q[i][0], 1, C[i], n - C[i]);               /* :1238-1240 */
+    if (C[i] && n - C[i]) v32_push3(&Q(i, 0), 1, C[i], n - C[i]);               /* :1238-1240 */
   int again;
   uint32_t round = 0;
   do {
     again = 0;
+    /* the reference's only parallel region: one OpenMP thread per plane, joined every round (:1250-1252) */
+#pragma omp parallel for schedule(static, 1) num_threads(g_threads) if (g_threads > 1 && !g_tr.on)
     for (int i = 0; i < 8; ++i) {                                                /* :1252 */
       uint32_t offset[2] = {0, 0};
       for (int j = 0; j < 2; ++j) {                                              /* :1256 */
-        const uint32_t *cur = Q[i][j].p, *end = Q[i][j].p + Q[i][j].n;
+        const uint32_t *cur = Q(i, j).p, *end = Q(i, j).p + Q(i, j).n;
         uint32_t s = C[i] * (uint32_t)j;                                         /* :1259 */
         while (cur != end) {
           s += *cur++ - 1;                                                       /* :1264 */
@@ -345,13 +351,13 @@ static void bce_code(Coder coder_[8], const uint32_t C[8], Rank ranks[8], uint32
           uint32_t _1x = rank_get1(&ranks[i], s + _x) - s1;                      /* :1271 */
           uint32_t s0 = s - s1;
           if (!_1x) {                                                            /* :1274-1279 */
-            v32_push3(&Q[i][2], s0 - offset[0] + 1, _x0, _x1);
+            v32_push3(&Q(i, 2), s0 - offset[0] + 1, _x0, _x1);
             offset[0] = s0;
             continue;
           }
           uint32_t _0x = _x - _1x;
           if (!_0x) {                                                            /* :1282-1287 */
-            v32_push3(&Q[i][3], s1 - offset[1] + 1, _x0, _x1);
+            v32_push3(&Q(i, 3), s1 - offset[1] + 1, _x0, _x1);
             offset[1] = s1;
             continue;
           }
@@ -366,24 +372,25 @@ static void bce_code(Coder coder_[8], const uint32_t C[8], Rank ranks[8], uint32
             coder_set5(&coder_[i], _0x0 - mn, mx - mn + 1, _0x, _x1, _x);
           }
           uint32_t _0x1 = _0x - _0x0;                                            /* :1337-1348 */
-          if (_0x0 && _0x1) { v32_push3(&Q[i][2], s0 - offset[0] + 1, _0x0, _0x1); offset[0] = s0; }
+          if (_0x0 && _0x1) { v32_push3(&Q(i, 2), s0 - offset[0] + 1, _0x0, _0x1); offset[0] = s0; }
           uint32_t _1x1 = _x1 - _0x1;
           uint32_t _1x0 = _1x - _1x1;
-          if (_1x0 && _1x1) { v32_push3(&Q[i][3], s1 - offset[1] + 1, _1x0, _1x1); offset[1] = s1; }
+          if (_1x0 && _1x1) { v32_push3(&Q(i, 3), s1 - offset[1] + 1, _1x0, _1x1); offset[1] = s1; }
         }
       }
     }
     for (int i = 0; i < 8; ++i) {                                                /* :1361-1370 */
       vec32 t;
-      t = Q[(i + 1) % 8][0]; Q[(i + 1) % 8][0] = Q[i][2]; Q[i][2] = t;
-      t = Q[(i + 1) % 8][1]; Q[(i + 1) % 8][1] = Q[i][3]; Q[i][3] = t;
-      Q[i][2].n = 0; Q[i][3].n = 0;
-      if (Q[(i + 1) % 8][0].n || Q[(i + 1) % 8][1].n) again = 1;
+      t = Q((i + 1) % 8, 0); Q((i + 1) % 8, 0) = Q(i, 2); Q(i, 2) = t;
+      t = Q((i + 1) % 8, 1); Q((i + 1) % 8, 1) = Q(i, 3); Q(i, 3) = t;
+      Q(i, 2).n = 0; Q(i, 3).n = 0;
+      if (Q((i + 1) % 8, 0).n || Q((i + 1) % 8, 1).n) again = 1;
     }
     round++;
   } while (again);
   g_tr.rounds = round;
-  for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) free(Q[i][j].p);
+  for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) free(Q(i, j).p);
+#undef Q
 }
 
 /* BCE::encode (bce.cpp:1117-1167): 8 plane coders, header coder main(-1), concatenation. */
@@ -481,6 +488,9 @@ int bce_oracle_plane_bits(const uint8_t *bwt, uint32_t n, uint8_t *out) {
   }
   return 0;
 }
+
+/* Threads of the round loop for later calls (1..8); the archive does not depend on it. */
+void bce_oracle_set_threads(int t) { g_threads = t < 1 ? 1 : (t > 8 ? 8 : t); }
 
 /* Tracing: switch on, run a compress/encode call, read the arrays, switch off. */
 void bce_oracle_trace_begin(void) {

@@ -61,6 +61,11 @@ def _cfg(config):
     return a, p
 
 
+def set_threads(t: int):
+    """Threads of the round loop: 1 = reference built without OpenMP, 8 = with (one per plane, bce.cpp:1250-1252)."""
+    lib().bce_oracle_set_threads(int(t))
+
+
 def compress(data, config=None) -> bytes:
     """Reference `bce -c` on an in-memory buffer -> archive bytes."""
     a, p = _buf(data)

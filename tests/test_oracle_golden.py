@@ -61,3 +61,16 @@ def test_oracle_scan_matches_reference_config():
     a = oracle.compress(d, cfg)
     assert len(a) == v["archive_bytes"] and hashlib.sha256(a).hexdigest() == v["archive_sha256"]
     assert len(res) == 9 and res[8] == 0.0
+
+
+def test_openmp_round_loop_gives_the_same_archive():
+    """The 8-thread round loop (the reference's OpenMP build, bce.cpp:1250-1252) is only a schedule."""
+    data = oracle.synth_text(9, 300000) + oracle.synth_rand(9, 20000)
+    try:
+        oracle.set_threads(1)
+        a1 = oracle.compress(data)
+        oracle.set_threads(8)
+        a8 = oracle.compress(data)
+    finally:
+        oracle.set_threads(1)
+    assert a1 == a8
