@@ -33,23 +33,37 @@ int set_input(bce_hip_ctx *c, const void *src, uint32_t n, hipMemcpyKind kind) {
   return BCE_HIP_OK;
 }
 
-// Flush the model (K4) for the symbols buffered so far and hand the result to the coder threads.
-// The GPU part is synchronous; the range coding of this batch overlaps the next rounds / flushes.
+// GPU time of a finished flush (K4 kernels + copy), from its events
+void account_slot(bce_hip_ctx *c, FlushSlot &slot) {
+  if (!slot.timed) return;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, slot.ev_start, slot.ev_copy) == hipSuccess) c->stats.t_model += ms * 1e-3;
+  slot.timed = false;
+}
+
+// Flush the model (K4) for the symbols buffered so far and hand the result to the coder threads.  Nothing here
+// waits for the GPU: the kernels are queued on the compute stream, the device-to-host copy on the copy stream,
+// and the coder threads wait for the copy's event before they touch the batch; the next rounds overlap both.
 int flush_symbols(bce_hip_ctx *c, uint64_t nsym) {
   if (nsym) {
     FlushSlot &slot = c->slot[c->slot_next];
     c->slot_next = (c->slot_next + 1) % 3;
     double t0 = now_s();
-    c->coder->wait(&slot.batch);                 // the slot's previous batch must be fully coded
-    double t1 = now_s();
-    c->stats.t_coder += t1 - t0;
-    BCE_TRY(k4_flush(c, nsym, slot));
-    c->stats.t_model += now_s() - t1;
+    c->coder->wait(&slot.batch);                 // the slot's previous batch must be fully coded (so its copy is done)
+    c->stats.t_coder += now_s() - t0;
+    account_slot(c, slot);
+    BCE_TRY(k4_flush_async(c, nsym, slot));
     slot.batch.out = slot.h_out;
     for (int p = 0; p < 8; ++p) {
       slot.batch.runs[p].clear();
       slot.batch.runs[p].reserve(c->run_log[p].size());
       for (const RunEntry &e : c->run_log[p]) slot.batch.runs[p].push_back(SymRun{e.start, e.count, e.round});
+    }
+    slot.once = std::make_shared<std::once_flag>();
+    {
+      std::shared_ptr<std::once_flag> once = slot.once;
+      hipEvent_t ev = slot.ev_copy;
+      slot.batch.wait_ready = [once, ev]() { std::call_once(*once, [ev]() { (void)hipEventSynchronize(ev); }); };
     }
     c->coder->submit(&slot.batch);
     c->stats.flushes++;
@@ -73,7 +87,8 @@ int bce_hip_create(bce_hip_ctx **out, int device) {
   memcpy(c->config, kDefaultConfig, sizeof c->config);
   memset(&c->stats, 0, sizeof c->stats);
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev_k4) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return BCE_HIP_E_DEVICE;
   }
@@ -86,7 +101,9 @@ int bce_hip_create(bce_hip_ctx **out, int device) {
 void bce_hip_destroy(bce_hip_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->coder) c->coder->drain();
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   DevBuf *bufs[] = {&c->text, &c->bwt, &c->sa[0], &c->sa[1], &c->key[0], &c->key[1], &c->rank, &c->k2, &c->nrk, &c->act[0], &c->act[1],
                     &c->rs_hist, &c->blk, &c->ptmp[0], &c->ptmp[1], &c->gran, &c->nodes, &c->ctl, &c->tilecnt,
                     &c->tileoff, &c->runs, &c->truns, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
@@ -98,7 +115,11 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   if (c->coder) c->coder->drain();
   for (FlushSlot &sl : c->slot) {
     if (sl.h_out) (void)hipHostFree(sl.h_out);
+    if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
+    if (sl.ev_copy) (void)hipEventDestroy(sl.ev_copy);
   }
+  if (c->ev_k4) (void)hipEventDestroy(c->ev_k4);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -285,7 +306,6 @@ int bce_hip_enum_model(bce_hip_ctx *c, uint32_t *out, uint64_t cap_records, uint
 int bce_hip_encode(bce_hip_ctx *c) {
   BCE_TRY(check_stage(c, 3));
   BCE_HIP_TRY(c, hipSetDevice(c->device));
-  const double t0 = now_s();
   const uint32_t n = c->n;
   BCE_TRY(k4_prepare(c));
   BCE_TRY(k3_begin(c));
@@ -374,6 +394,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
     const double tw = now_s();
     c->coder->drain();                           // coding of the last batches (the exposed part)
     c->stats.t_coder += now_s() - tw;
+    for (FlushSlot &sl : c->slot) account_slot(c, sl);
   }
   c->stats.t_coder_busy = c->coder->busy_seconds();
   c->stats.rounds = ctl.done_round;
@@ -381,7 +402,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
   c->coder->finish(c->config, n, c->offset, c->archive);
   c->enum_active = false;
   c->stage = 4;
-  c->stats.t_enum = now_s() - t0 - c->stats.t_model - c->stats.t_coder;
+  c->stats.t_enum = c->stats.k3_ms * 1e-3;      // GPU time of the enumeration; K4, copies and coding overlap it and each other
   return BCE_HIP_OK;
 }
 

@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <chrono>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "../../include/bce_hip.h"
@@ -48,6 +50,9 @@ struct FlushSlot {
   uint64_t *h_out = nullptr;     // one packed u64 per symbol (bce_core.h pack_model_out)
   size_t cap = 0;
   CoderBatch batch;
+  hipEvent_t ev_start = nullptr, ev_copy = nullptr;   // K4 start (compute stream), outputs in h_out (copy stream)
+  bool timed = false;            // the events of the last flush have not been added to stats.t_model yet
+  std::shared_ptr<std::once_flag> once;   // the first coder thread to arrive waits for ev_copy, the others for it
 };
 
 struct RunEntry { uint64_t start; uint32_t count; uint32_t round; };  // symbols of (round, plane): [start, start+count)
@@ -57,7 +62,9 @@ struct RunEntry { uint64_t start; uint32_t count; uint32_t round; };  // symbols
 struct bce_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t copy_stream = nullptr;             // device-to-host copies of the model outputs, overlapping the next rounds
+  hipEvent_t copy_busy = nullptr;                // last copy out of `sout` (the next K4 must not overwrite it earlier)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_k4 = nullptr;
   char err[256] = {0};
 
   uint32_t n = 0;
@@ -165,7 +172,8 @@ int k3_get_nodes(bce_hip_ctx *c, int plane, uint32_t *out, uint32_t cap, uint32_
 int k3_reset_symbols(bce_hip_ctx *c);               // after a flush: sym_total = 0, need_flush = 0
 int k3_grow_symbols(bce_hip_ctx *c, uint64_t cap);  // enlarge the (empty) symbol buffer, clear need_flush
 int k4_prepare(bce_hip_ctx *c);                     // k4_model.hip: counters to zero, cfg upload
-int k4_flush(bce_hip_ctx *c, uint64_t nsym, FlushSlot &slot);   // sort + replay + D2H into the slot (synchronous)
+int k4_flush(bce_hip_ctx *c, uint64_t nsym, FlushSlot &slot);         // synchronous: outputs are in slot.h_out on return
+int k4_flush_async(bce_hip_ctx *c, uint64_t nsym, FlushSlot &slot);   // outputs are in slot.h_out once slot.ev_copy has fired   // sort + replay + D2H into the slot (synchronous)
 
 // radix sort (radix_sort.hip): stable LSD sort of (key,val) u32 pairs on key bits [first_bit, first_bit+bits).
 // Result is left in key[res]/val[res]; returns res (0 or 1) through *res.

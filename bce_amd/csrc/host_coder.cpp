@@ -171,6 +171,7 @@ void HostCoder::run(int p) {
       b = w.q.front();
       w.q.pop_front();
     }
+    if (b->wait_ready) b->wait_ready();
     const auto t0 = std::chrono::steady_clock::now();
     consume(p, b->runs[p].data(), b->runs[p].size(), b->out);
     for (const SymRun &r : b->runs[p]) w.nsym += r.count;

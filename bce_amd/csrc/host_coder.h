@@ -10,6 +10,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -57,6 +58,7 @@ struct SymRun { uint64_t start; uint32_t count; uint32_t round; };
 // owned by the caller) and, per plane, the (round-ordered) runs of record indices that belong to it.
 struct CoderBatch {
   const uint64_t *out = nullptr;
+  std::function<void()> wait_ready;  // optional: returns once `out` is filled (the device-to-host copy is asynchronous)
   std::vector<SymRun> runs[8];
   std::atomic<int> pending{0};      // planes that have not finished this batch yet
 };

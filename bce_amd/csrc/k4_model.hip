@@ -369,7 +369,7 @@ int k4_prepare(bce_hip_ctx *c) {
   return BCE_HIP_OK;
 }
 
-int k4_flush(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
+int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   if (nsym64 == 0) return BCE_HIP_OK;
   if (nsym64 >= (1ull << 31)) return BCE_HIP_E_OVERFLOW;
   const uint32_t nsym = (uint32_t)nsym64;
@@ -384,6 +384,11 @@ int k4_flush(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
     BCE_HIP_TRY(c, hipHostMalloc((void **)&slot.h_out, cap * 8, hipHostMallocDefault));
     slot.cap = cap;
   }
+  if (!slot.ev_start) BCE_HIP_TRY(c, hipEventCreate(&slot.ev_start));
+  // blocking sync: the coder thread that waits for the copy sleeps instead of spinning next to the busy coders
+  if (!slot.ev_copy) BCE_HIP_TRY(c, hipEventCreateWithFlags(&slot.ev_copy, hipEventBlockingSync));
+  if (c->copy_busy) BCE_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_busy, 0));   // `sout` is still being copied out
+  BCE_HIP_TRY(c, hipEventRecord(slot.ev_start, c->stream));
   uint32_t *key[2] = {c->skey[0].as<uint32_t>(), c->skey[1].as<uint32_t>()};
   uint32_t *val[2] = {c->sval[0].as<uint32_t>(), c->sval[1].as<uint32_t>()};
   uint64_t gb = ((uint64_t)nsym + K4_T - 1) / K4_T;
@@ -419,9 +424,22 @@ int k4_flush(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   hipLaunchKernelGGL(k4_window_kernel, dim3(sgrid), dim3(K4_T), 0, c->stream, a);
   hipLaunchKernelGGL(k4_long_kernel, dim3(1024), dim3(K4_T), 0, c->stream, a);
   hipLaunchKernelGGL(k4_emit_kernel, dim3(sgrid), dim3(K4_T), 0, c->stream, a);
-  BCE_HIP_TRY(c, hipMemcpyAsync(slot.h_out, c->sout.p, (size_t)nsym * 8, hipMemcpyDeviceToHost, c->stream));
-  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
   BCE_HIP_TRY(c, hipGetLastError());
+  // the copy runs on its own stream so that the next rounds (K3) overlap it
+  BCE_HIP_TRY(c, hipEventRecord(c->ev_k4, c->stream));
+  BCE_HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_k4, 0));
+  BCE_HIP_TRY(c, hipMemcpyAsync(slot.h_out, c->sout.p, (size_t)nsym * 8, hipMemcpyDeviceToHost, c->copy_stream));
+  BCE_HIP_TRY(c, hipEventRecord(slot.ev_copy, c->copy_stream));
+  c->copy_busy = slot.ev_copy;
+  slot.timed = true;
+  return BCE_HIP_OK;
+}
+
+int k4_flush(bce_hip_ctx *c, uint64_t nsym, FlushSlot &slot) {
+  if (nsym == 0) return BCE_HIP_OK;
+  BCE_TRY(k4_flush_async(c, nsym, slot));
+  BCE_HIP_TRY(c, hipEventSynchronize(slot.ev_copy));
+  slot.timed = false;
   return BCE_HIP_OK;
 }
 

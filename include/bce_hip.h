@@ -125,7 +125,10 @@ typedef struct bce_hip_stats {
   uint32_t sort_rounds;  /* prefix-doubling rounds of K1 */
   uint32_t flushes;      /* K4 model flushes */
   uint32_t reserved;
-  double t_load, t_bwt, t_planes, t_enum, t_model, t_coder, t_total;   /* host wall seconds */
+  /* t_load, t_bwt, t_planes, t_total: host wall seconds.  t_enum, t_model: GPU seconds (HIP events) of K3 and of
+   * K4 + device-to-host copies.  t_coder: host seconds spent waiting for the coder threads (the part of the range
+   * coding that nothing hides).  The last three overlap, so they do not add up to t_total. */
+  double t_load, t_bwt, t_planes, t_enum, t_model, t_coder, t_total;
   double k3_ms, k3_launches;   /* HIP-event time and launch count of the interval-count kernels */
   double t_coder_busy;         /* busiest host coder thread (t_coder is only the part not hidden behind GPU work) */
 } bce_hip_stats;
