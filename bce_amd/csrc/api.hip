@@ -106,7 +106,7 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   DevBuf *bufs[] = {&c->text, &c->bwt, &c->sa[0], &c->sa[1], &c->key[0], &c->key[1], &c->rank, &c->k2, &c->nrk, &c->act[0], &c->act[1],
                     &c->rs_hist, &c->blk, &c->ptmp[0], &c->ptmp[1], &c->gran, &c->nodes, &c->ctl, &c->tilecnt,
-                    &c->tileoff, &c->runs, &c->truns, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
+                    &c->tileoff, &c->runs, &c->smwords, &c->truns, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
                     &c->sesc, &c->stat, &c->dcfg, &c->k4w, &c->scanrec, &c->dfs};
   for (DevBuf *b : bufs) release(*b);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
@@ -162,6 +162,8 @@ int bce_hip_debug_set(bce_hip_ctx *c, int knob, uint32_t value) {
   switch (knob) {
     case 0: c->dbg_dfs_budget = value; break;
     case 1: c->dbg_no_dfs = value; break;
+    case 4: c->dbg_no_small = value; break;
+    case 5: c->dbg_step_small = value; break;
     case 2: c->dbg_no_tail = value; break;
     case 3: c->dbg_no_skip = value; break;
     default: return BCE_HIP_E_ARG;
@@ -255,7 +257,8 @@ int bce_hip_enum_round(bce_hip_ctx *c, uint64_t *next_nodes) {
   if (!c || !c->enum_active) return BCE_HIP_E_STATE;
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t first = c->round;
-  BCE_TRY(k3_rounds(c, 1, 0));
+  if (c->dbg_step_small) BCE_TRY(k3_rounds_small(c, 1, K3_SMALL_NODES, false));   // test hook: step with the one-launch kernel
+  else BCE_TRY(k3_rounds(c, 1, 0));
   EnumCtl ctl;
   BCE_TRY(k3_sync_ctl(c, &ctl));
   if (ctl.overflow) return BCE_HIP_E_OVERFLOW;
@@ -318,7 +321,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
   for (int i = 0; i < 8; ++i) cur_nodes += (C[i] && n - C[i]) ? 1 : 0;
   EnumCtl ctl;
   bool decaying = false;
-  bool have_ctl = false;
+  bool have_ctl = false, wide_once = false;
   // depth-first tail: first attempt when the live set is small, a second one (if the first ran out of room) when tiny
   uint32_t kDfsEnter[2] = {65536u, 2048u};
   if (const char *e = getenv("BCE_HIP_DFS_ENTER")) kDfsEnter[0] = (uint32_t)strtoul(e, nullptr, 10);
@@ -355,8 +358,23 @@ int bce_hip_encode(bce_hip_ctx *c) {
       BCE_TRY(k3_sync_ctl(c, &ctl));
       executed = ctl.tail_rounds;
       BCE_TRY(k3_fetch_tail_runs(c, executed));
+    } else if (!c->dbg_no_small && !wide_once && cur_nodes <= K3_SMALL_NODES) {
+      // narrow rounds: one launch per round (k3_small_kernel); while the count still doubles, queue only as many
+      // rounds as stay within its range
+      uint32_t batch = 64;
+      if (!decaying) {
+        batch = 1;
+        while (batch < 16 && (cur_nodes << (batch + 1)) <= 2ull * K3_SMALL_NODES) ++batch;
+      }
+      BCE_TRY(k3_rounds_small(c, batch, cur_nodes, !decaying));
+      BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+      BCE_TRY(k3_sync_ctl(c, &ctl));
+      executed = (ctl.need_flush || ctl.small_bail) ? ctl.skip_round - first : batch;
+      BCE_TRY(k3_fetch_runs(c, first, executed));
+      if (ctl.small_bail) { BCE_TRY(k3_clear_small_bail(c)); wide_once = true; }
     } else {
       // wide rounds: sync often (the round dominates); medium rounds: queue many per sync
+      wide_once = false;
       const uint32_t batch = cur_nodes > (1u << 20) ? 4u : (cur_nodes > (1u << 14) ? 16u : 64u);
       BCE_TRY(k3_rounds(c, batch, decaying ? cur_nodes : 0));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -388,7 +406,10 @@ int bce_hip_encode(bce_hip_ctx *c) {
     }
     // The host coders are the critical path from the first batch on: hand them a small first batch early
     // instead of waiting for the symbol buffer to fill.
-    if (c->stats.flushes == 0 && ctl.sym_total >= (1u << 20)) BCE_TRY(flush_symbols(c, ctl.sym_total));
+    if (c->stats.flushes == 0 && ctl.sym_total >= (1u << 20)) {
+      BCE_TRY(flush_symbols(c, ctl.sym_total));
+      ctl.sym_total = 0;                         // the host copy is consulted again at the top of the loop
+    }
   }
   {
     const double tw = now_s();

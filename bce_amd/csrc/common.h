@@ -42,6 +42,8 @@ struct EnumCtl {
   uint32_t ptot[8][3];       // per plane totals of the round: child0, child1, symbols
   uint64_t symbase[8];       // symbol-buffer base of each plane's records in this round
   uint32_t tail_rounds;      // rounds executed by the last k3_tail_kernel launch
+  uint32_t small_bail;       // k3_small_kernel: the round (skip_round) does not fit its grid / tile table: run it wide
+  uint32_t sm_ticket;        // k3_small_kernel: next tile to hand out (dynamic order = look-back order)
   uint32_t pad2;
 };
 
@@ -77,7 +79,7 @@ struct bce_hip_ctx {
   bool k1_valid = false;                         // sa[sa_res] / rank hold this input's suffix order (K1 ran; no injected BWT)
   int sa_res = 0;
   // debug knobs (bce_hip_debug_set): 0 = default
-  uint32_t dbg_dfs_budget = 0, dbg_no_dfs = 0, dbg_no_tail = 0, dbg_no_skip = 0;
+  uint32_t dbg_dfs_budget = 0, dbg_no_dfs = 0, dbg_no_tail = 0, dbg_no_skip = 0, dbg_no_small = 0, dbg_step_small = 0;
   uint64_t sym_cap_user = 0;
 
   // device buffers (grow-only)
@@ -90,6 +92,7 @@ struct bce_hip_ctx {
   bce::DevBuf nodes;                             // 2 parities x 8 planes x capP nodes
   uint32_t capP = 0;
   bce::DevBuf ctl, tilecnt, tileoff, runs;       // K3 control
+  bce::DevBuf smwords;                           // k3_small_kernel: one published count word per tile
   bce::DevBuf dfs;                               // depth-first tail: tagged symbols, sort scratch, walker stacks
   bce::DevBuf truns;                             // run table of the persistent tail kernel [K3_TAIL_MAXROUNDS][8]
   void *h_truns = nullptr;
@@ -151,6 +154,8 @@ inline double now_s() {
 }
 
 constexpr uint32_t K3_TAIL_CAP = 1024;        // nodes the tail kernel holds in LDS (all 8 planes together)
+constexpr uint32_t K3_SMALL_MAXTILES = 2048;  // tile table of the one-launch round kernel
+constexpr uint32_t K3_SMALL_NODES = 1u << 19;   // rounds up to this many nodes use it
 constexpr uint32_t K3_TAIL_ENTER = 512;       // the host switches to the tail kernel at or below this many nodes
 constexpr uint32_t K3_TAIL_MAXROUNDS = 65536; // rounds per tail launch (bounded by its run table)
 
@@ -162,7 +167,9 @@ int k2_build_planes(bce_hip_ctx *c);                // k2_planes.hip
 int k2_get_plane_bits(bce_hip_ctx *c, int plane, uint8_t *out);
 int k2_rank1(bce_hip_ctx *c, int plane, const uint32_t *idx, uint32_t count, uint32_t *out);
 int k3_begin(bce_hip_ctx *c);                       // k3_enumerate.hip
-int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint);   // queue `count` rounds from c->round (no sync)
+int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint);
+int k3_rounds_small(bce_hip_ctx *c, uint32_t count, uint64_t cur_nodes, bool growing);   // one launch per round, narrow rounds
+int k3_clear_small_bail(bce_hip_ctx *c);   // queue `count` rounds from c->round (no sync)
 int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done);   // k3_dfs.hip: finish the enumeration depth-first
 int k3_tail(bce_hip_ctx *c);                        // queue the persistent narrow-round kernel from c->round (no sync)
 int k3_fetch_tail_runs(bce_hip_ctx *c, uint32_t rounds);

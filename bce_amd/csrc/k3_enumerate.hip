@@ -105,6 +105,39 @@ __device__ __forceinline__ void k3_classify(const K3Args &a, uint32_t p, uint32_
   }
 }
 
+// Write one classified tile: children into plane p+1's lists of the other parity (child0 list grows up from o0,
+// child1 list down from the top), symbol records from os.  lds_cnt = per (item, wave) counts of the tile.
+template <bool SCAN>
+__device__ __forceinline__ void k3_place(const K3Args &a, uint32_t p, const TileOut &t, const uint32_t (&pre0)[K3_NPT],
+                                         const uint32_t (&pre1)[K3_NPT], const uint32_t (&pres)[K3_NPT],
+                                         uint32_t (*lds_cnt)[4][3], uint32_t o0, uint32_t o1, uint64_t os) {
+  const uint32_t w = threadIdx.x >> 6;
+  const uint32_t pn = (p + 1u) & 7u;
+  Node *dst = plane_nodes(a, a.par ^ 1u, pn);
+  uint32_t run0 = 0, run1 = 0, runs_ = 0;   // counts of earlier (it, wave) groups
+#pragma unroll
+  for (int it = 0; it < K3_NPT; ++it) {
+    uint32_t b0 = run0, b1 = run1, bs = runs_;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      const uint32_t x0 = lds_cnt[it][ww][0], x1 = lds_cnt[it][ww][1], xs = lds_cnt[it][ww][2];
+      if ((uint32_t)ww < w) { b0 += x0; b1 += x1; bs += xs; }
+      run0 += x0; run1 += x1; runs_ += xs;
+    }
+    if (t.has0[it]) dst[o0 + b0 + pre0[it]] = t.c0[it];
+    if (t.has1[it]) dst[a.capP - 1u - (o1 + b1 + pre1[it])] = t.c1[it];
+    if (t.hassym[it]) {
+      if (SCAN) {
+        uint32_t *r = a.scanrec + (os + bs + pres[it]) * 5;
+        r[0] = t.kw[it]; r[1] = t.ew[it]; r[2] = t.raw[it][0]; r[3] = t.raw[it][1]; r[4] = t.raw[it][2];
+      } else {
+        a.symkey[os + bs + pres[it]] = t.kw[it];
+        a.symesc[os + bs + pres[it]] = t.ew[it];
+      }
+    }
+  }
+}
+
 // Process one tile.  WRITE=false: count children/symbols.  WRITE=true: place them.
 template <bool WRITE, bool SCAN>
 __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t tile_in_plane, uint32_t tile_global,
@@ -138,30 +171,7 @@ __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t ti
     const uint32_t o0 = a.tileoff[(size_t)tile_global * 4 + 0];
     const uint32_t o1 = a.tileoff[(size_t)tile_global * 4 + 1];
     const uint64_t os = a.ctl->symbase[p] + a.tileoff[(size_t)tile_global * 4 + 2];
-    const uint32_t pn = (p + 1u) & 7u;
-    Node *dst = plane_nodes(a, a.par ^ 1u, pn);
-    uint32_t run0 = 0, run1 = 0, runs_ = 0;   // counts of earlier (it, wave) groups
-#pragma unroll
-    for (int it = 0; it < K3_NPT; ++it) {
-      uint32_t b0 = run0, b1 = run1, bs = runs_;
-#pragma unroll
-      for (int ww = 0; ww < 4; ++ww) {
-        const uint32_t x0 = lds_cnt[it][ww][0], x1 = lds_cnt[it][ww][1], xs = lds_cnt[it][ww][2];
-        if ((uint32_t)ww < w) { b0 += x0; b1 += x1; bs += xs; }
-        run0 += x0; run1 += x1; runs_ += xs;
-      }
-      if (t.has0[it]) dst[o0 + b0 + pre0[it]] = t.c0[it];
-      if (t.has1[it]) dst[a.capP - 1u - (o1 + b1 + pre1[it])] = t.c1[it];
-      if (t.hassym[it]) {
-        if (SCAN) {
-          uint32_t *r = a.scanrec + (os + bs + pres[it]) * 5;
-          r[0] = t.kw[it]; r[1] = t.ew[it]; r[2] = t.raw[it][0]; r[3] = t.raw[it][1]; r[4] = t.raw[it][2];
-        } else {
-          a.symkey[os + bs + pres[it]] = t.kw[it];
-          a.symesc[os + bs + pres[it]] = t.ew[it];
-        }
-      }
-    }
+    k3_place<SCAN>(a, p, t, pre0, pre1, pres, lds_cnt, o0, o1, os);
   }
   __syncthreads();
 }
@@ -216,21 +226,33 @@ __global__ __launch_bounds__(1024) void k3_scan_kernel(K3Args a) {
     s_last = atomicAdd(&ctl->ticket, 1u) == 7u ? 1u : 0u;
   }
   __syncthreads();
-  if (!s_last || tid != 0) return;
+  if (!s_last) return;
+  // epilogue of the last block: fetch everything it reads in parallel (a serial chain of ~45 dependent loads by
+  // one thread was most of this kernel's 11 us), then thread 0 decides and stores
+  __shared__ uint32_t s_pt[8][3], s_cnt[8][2];
+  __shared__ uint64_t s_sym[2];
+  __shared__ uint32_t s_done;
   __threadfence();
+  if (tid < 24) s_pt[tid / 3][tid % 3] = ((const volatile uint32_t *)&ctl->ptot[0][0])[tid];
+  else if (tid < 40) s_cnt[(tid - 24) >> 1][(tid - 24) & 1] = ((const volatile uint32_t *)&ctl->cnt[a.par][0][0])[tid - 24];
+  else if (tid == 40) s_sym[0] = *(const volatile uint64_t *)&ctl->sym_total;
+  else if (tid == 41) s_sym[1] = *(const volatile uint64_t *)&ctl->sym_cap;
+  else if (tid == 42) s_done = *(const volatile uint32_t *)&ctl->done_round;
+  __syncthreads();
+  if (tid != 0) return;
   ctl->ticket = 0;
   uint64_t symsum = 0, nextn = 0, curn = 0;
   bool ovf = false;
-  const volatile uint32_t (*pt)[3] = ctl->ptot;
+  const uint32_t (*pt)[3] = s_pt;
   for (int q = 0; q < 8; ++q) {
     symsum += pt[q][2];
     nextn += (uint64_t)pt[q][0] + pt[q][1];
-    curn += (uint64_t)ctl->cnt[a.par][q][0] + ctl->cnt[a.par][q][1];
+    curn += (uint64_t)s_cnt[q][0] + s_cnt[q][1];
     if ((uint64_t)pt[q][0] + pt[q][1] > a.capP) ovf = true;
   }
   if (ovf) { ctl->overflow = 1; return; }
-  if (ctl->sym_total + symsum > ctl->sym_cap) { ctl->need_flush = 1; ctl->skip_round = a.round; ctl->want_syms = symsum; return; }
-  uint64_t acc = ctl->sym_total;
+  if (s_sym[0] + symsum > s_sym[1]) { ctl->need_flush = 1; ctl->skip_round = a.round; ctl->want_syms = symsum; return; }
+  uint64_t acc = s_sym[0];
   for (uint32_t q = 0; q < 8; ++q) {
     const uint32_t qn = (q + 1u) & 7u;
     ctl->symbase[q] = acc;
@@ -241,9 +263,139 @@ __global__ __launch_bounds__(1024) void k3_scan_kernel(K3Args a) {
     acc += pt[q][2];
   }
   ctl->sym_total = acc;
-  ctl->nodes_total += curn;
+  atomicAdd((unsigned long long *)&ctl->nodes_total, (unsigned long long)curn);
+  ctl->next_nodes = (uint32_t)nextn;
+  if (nextn == 0 && s_done == 0xFFFFFFFFu) ctl->done_round = a.round + 1u;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Narrow rounds in ONE launch.  A dependent kernel costs ~8 us on this GPU whatever it does, so count / scan /
+// write spend ~30 us on a round of a few thousand nodes.  Here every block takes one tile (dynamic ticket =
+// look-back order), classifies it once, publishes its three counts in one 64-bit word tagged with the round
+// (agent-scope store; nothing to reset), waits for the words of ALL earlier tiles (at most K3_SMALL_MAXTILES,
+// one per thread per sweep -- earlier tickets belong to blocks that are running or done, so this cannot
+// deadlock), sums them into its offsets and writes.  The block with the last ticket waits for every tile's word
+// and folds them into the control block exactly as k3_scan_kernel's epilogue does.  Whether the symbol buffer could overflow is decided
+// up front from the node count (a node codes at most one symbol), identically in every block; a round that does
+// not fit the grid or the tile table sets small_bail and is run again by the wide kernels.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ld_word(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool SCAN>
+__global__ __launch_bounds__(K3_T) void k3_small_kernel(K3Args a, unsigned long long *words) {
+  __shared__ uint32_t tp[9];
+  __shared__ uint32_t lds_cnt[K3_NPT][4][3];
+  __shared__ uint32_t s_tile;
+  __shared__ unsigned long long s_acc[3];
+  __shared__ unsigned long long s_tot[8];
+  EnumCtl *ctl = a.ctl;
+  if (ctl->need_flush || ctl->overflow || ctl->small_bail) return;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) tile_prefix(a, tp);
+  if (tid < 3) s_acc[tid] = 0;
+  if (tid < 8) s_tot[tid] = 0;
+  __syncthreads();
+  const uint32_t T = tp[8];
+  // decisions every block takes identically from the state the previous launch left
+  uint64_t M = 0;
+  bool fits = T <= gridDim.x && T <= K3_SMALL_MAXTILES;      // (<= 2048 tiles: per-plane totals stay below 2^21)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const uint64_t m = (uint64_t)ctl->cnt[a.par][q][0] + ctl->cnt[a.par][q][1];
+    M += m;
+    if (2 * m > a.capP) fits = false;                        // children could overflow a list: let the wide path decide
+  }
+  if (M >= (1u << 21)) fits = false;
+  const uint64_t sym0 = ctl->sym_total;
+  if (!fits) {
+    if (blockIdx.x == 0 && tid == 0) { ctl->skip_round = a.round; ctl->small_bail = 1; }
+    return;
+  }
+  if (sym0 + M > ctl->sym_cap) {
+    if (blockIdx.x == 0 && tid == 0) { ctl->skip_round = a.round; ctl->want_syms = M; ctl->need_flush = 1; }
+    return;
+  }
+  if (tid == 0) s_tile = atomicAdd(&ctl->sm_ticket, 1u);
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint64_t epoch = (uint64_t)((a.round + 1u) & 0x7FFFFFFFu);
+  if (tile < T) {
+    uint32_t p = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) p += (tile >= tp[k]) ? 1u : 0u;
+    const uint32_t lane = tid & 63u, w = tid >> 6;
+    TileOut t;
+    k3_classify<true, SCAN>(a, p, tile - tp[p], t);
+    uint32_t pre0[K3_NPT], pre1[K3_NPT], pres[K3_NPT];
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int it = 0; it < K3_NPT; ++it) {
+      const uint64_t b0 = __ballot(t.has0[it]), b1 = __ballot(t.has1[it]), bs = __ballot(t.hassym[it]);
+      pre0[it] = (uint32_t)__popcll(b0 & lt);
+      pre1[it] = (uint32_t)__popcll(b1 & lt);
+      pres[it] = (uint32_t)__popcll(bs & lt);
+      if (lane == 0) {
+        lds_cnt[it][w][0] = (uint32_t)__popcll(b0);
+        lds_cnt[it][w][1] = (uint32_t)__popcll(b1);
+        lds_cnt[it][w][2] = (uint32_t)__popcll(bs);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint64_t tt[3] = {0, 0, 0};
+      for (int it = 0; it < K3_NPT; ++it)
+        for (int ww = 0; ww < 4; ++ww)
+          for (int j = 0; j < 3; ++j) tt[j] += lds_cnt[it][ww][j];
+      // [10:0] child0, [21:11] child1, [32:22] symbols (<= 1024 each), [63:33] round tag
+      __hip_atomic_store(&words[tile], (epoch << 33) | (tt[2] << 22) | (tt[1] << 11) | tt[0], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // look back: all earlier tiles give the symbol offset, those of my plane the child offsets
+    uint64_t c0 = 0, c1 = 0, cs = 0;
+    for (uint32_t j = tid; j < tile; j += K3_T) {
+      uint64_t wv;
+      while (((wv = ld_word(&words[j])) >> 33) != epoch) __builtin_amdgcn_s_sleep(1);
+      cs += (wv >> 22) & 0x7FFu;
+      if (j >= tp[p]) { c0 += wv & 0x7FFu; c1 += (wv >> 11) & 0x7FFu; }
+    }
+    if (c0) atomicAdd(&s_acc[0], (unsigned long long)c0);
+    if (c1) atomicAdd(&s_acc[1], (unsigned long long)c1);
+    if (cs) atomicAdd(&s_acc[2], (unsigned long long)cs);
+    __syncthreads();
+    k3_place<SCAN>(a, p, t, pre0, pre1, pres, lds_cnt, (uint32_t)s_acc[0], (uint32_t)s_acc[1], sym0 + s_acc[2]);
+  }
+  // ---- the block with the last ticket folds the round into the control block ----
+  // (every other block has drawn its ticket, hence read everything it reads from the control block)
+  if (tile != gridDim.x - 1u) return;
+  for (uint32_t j = tid; j < T; j += K3_T) {
+    uint32_t p = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) p += (j >= tp[k]) ? 1u : 0u;
+    uint64_t wv;
+    while (((wv = ld_word(&words[j])) >> 33) != epoch) __builtin_amdgcn_s_sleep(1);
+    // per-plane totals fit 21-bit fields: a plane's children / symbols number at most its nodes < 2^21 (checked: M)
+    atomicAdd(&s_tot[p], (unsigned long long)((wv & 0x7FFu) | (((wv >> 11) & 0x7FFu) << 21) | (((wv >> 22) & 0x7FFu) << 42)));
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  uint64_t acc = sym0, nextn = 0;
+  for (uint32_t q = 0; q < 8; ++q) {
+    const uint32_t qn = (q + 1u) & 7u;
+    const uint32_t t0 = (uint32_t)(s_tot[q] & 0x1FFFFFu), t1 = (uint32_t)((s_tot[q] >> 21) & 0x1FFFFFu), ts = (uint32_t)(s_tot[q] >> 42);
+    ctl->cnt[a.par ^ 1u][qn][0] = t0;
+    ctl->cnt[a.par ^ 1u][qn][1] = t1;
+    RunEntry e; e.start = acc; e.count = ts; e.round = a.round;
+    a.runs[(size_t)a.run_slot * 8 + q] = e;
+    acc += ts;
+    nextn += (uint64_t)t0 + t1;
+  }
+  ctl->sym_total = acc;
+  atomicAdd((unsigned long long *)&ctl->nodes_total, (unsigned long long)M);
   ctl->next_nodes = (uint32_t)nextn;
   if (nextn == 0 && ctl->done_round == 0xFFFFFFFFu) ctl->done_round = a.round + 1u;
+  ctl->sm_ticket = 0;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -516,6 +668,9 @@ int k3_begin(bce_hip_ctx *c) {
   }
   BCE_HIP_TRY(c, hipMemcpyAsync(c->ctl.p, &ctl, sizeof ctl, hipMemcpyHostToDevice, c->stream));
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // round tags of an earlier compression must not look current
+  BCE_TRY(ensure(c, c->smwords, (size_t)K3_SMALL_MAXTILES * 8));
+  BCE_HIP_TRY(c, hipMemsetAsync(c->smwords.p, 0, (size_t)K3_SMALL_MAXTILES * 8, c->stream));
   c->round = 0;
   c->enum_active = true;
   for (int p = 0; p < 8; ++p) c->run_log[p].clear();
@@ -539,6 +694,32 @@ int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint) {
   }
   BCE_HIP_TRY(c, hipGetLastError());
   c->stats.k3_launches += 3.0 * count;
+  return BCE_HIP_OK;
+}
+
+// Narrow rounds, one launch each (k3_small_kernel).  The grid must cover the tiles of every queued round: the node
+// count at most doubles per round while it grows and is taken as <= 1.5x the last known count once it decays; a
+// round that does not fit bails out (small_bail) and the caller runs it with the wide kernels.
+int k3_rounds_small(bce_hip_ctx *c, uint32_t count, uint64_t cur_nodes, bool growing) {
+  if (count > K3_MAXBATCH) count = K3_MAXBATCH;
+  BCE_TRY(ensure(c, c->smwords, (size_t)K3_SMALL_MAXTILES * 8));
+  unsigned long long *words = c->smwords.as<unsigned long long>();
+  for (uint32_t i = 0; i < count; ++i) {
+    uint64_t bound = growing ? (cur_nodes << (i + 1 < 20 ? i + 1 : 20)) : cur_nodes + (cur_nodes >> 1);
+    uint64_t tiles = (bound + K3_TILE - 1) / K3_TILE + 8;
+    const uint32_t grid = (uint32_t)(tiles < K3_SMALL_MAXTILES ? tiles : K3_SMALL_MAXTILES);
+    const K3Args a = k3_make_args(c, c->round + i, i);
+    if (c->scan_mode) hipLaunchKernelGGL((k3_small_kernel<true>), dim3(grid), dim3(K3_T), 0, c->stream, a, words);
+    else hipLaunchKernelGGL((k3_small_kernel<false>), dim3(grid), dim3(K3_T), 0, c->stream, a, words);
+  }
+  BCE_HIP_TRY(c, hipGetLastError());
+  c->stats.k3_launches += 1.0 * count;
+  return BCE_HIP_OK;
+}
+
+int k3_clear_small_bail(bce_hip_ctx *c) {
+  EnumCtl *d = c->ctl.as<EnumCtl>();
+  BCE_HIP_TRY(c, hipMemsetAsync(&d->small_bail, 0, sizeof(uint32_t), c->stream));
   return BCE_HIP_OK;
 }
 

@@ -376,12 +376,12 @@ int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   const size_t b4 = (size_t)nsym * 4;
   BCE_TRY(ensure(c, c->skey[1], b4));
   for (int i = 0; i < 2; ++i) BCE_TRY(ensure(c, c->sval[i], b4));
-  BCE_TRY(ensure(c, c->sout, (size_t)nsym * 8));
+  BCE_TRY(ensure(c, c->sout, (size_t)nsym * 8 + 16));      // + slack: the copy-out moves 16-byte units
   if (slot.cap < nsym) {
     if (slot.h_out) (void)hipHostFree(slot.h_out);
     slot.h_out = nullptr; slot.cap = 0;
     size_t cap = (size_t)c->sym_cap > nsym ? (size_t)c->sym_cap : nsym;
-    BCE_HIP_TRY(c, hipHostMalloc((void **)&slot.h_out, cap * 8, hipHostMallocDefault));
+    BCE_HIP_TRY(c, hipHostMalloc((void **)&slot.h_out, cap * 8 + 16, hipHostMallocDefault));
     slot.cap = cap;
   }
   if (!slot.ev_start) BCE_HIP_TRY(c, hipEventCreate(&slot.ev_start));

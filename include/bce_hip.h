@@ -47,7 +47,7 @@ int bce_hip_set_config(bce_hip_ctx *ctx, const uint8_t *config288);
 int bce_hip_set_symbol_capacity(bce_hip_ctx *ctx, uint64_t records);
 
 /* test knobs for the enumeration's alternative code paths (all 0 by default): 0 = nodes a depth-first walker
- * classifies per pass, 1 = disable the depth-first tail, 2 = disable the persistent LDS tail kernel, 3 = disable chain skipping.
+ * classifies per pass, 1 = disable the depth-first tail, 2 = disable the persistent LDS tail kernel, 3 = disable chain skipping, 4 = disable the one-launch kernel for narrow rounds.
  * The archive never depends on them. */
 int bce_hip_debug_set(bce_hip_ctx *ctx, int knob, uint32_t value);
 
