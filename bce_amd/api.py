@@ -68,6 +68,7 @@ SYMBOLS = [
     ("bce_hip_enum_model", C.c_int, [C.c_void_p, _u32p, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("bce_hip_scan", C.c_int, [C.c_void_p, _u8p, C.POINTER(C.c_double)]),
     ("bce_hip_decompress", C.c_int, [_u8p, C.c_size_t, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("bce_hip_decompress_device", C.c_int, [C.c_void_p, _u8p, C.c_size_t, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("bce_hip_get_stats", C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     ("bce_hip_synth_text", None, [C.c_uint64, _u8p, C.c_size_t]),
     ("bce_hip_synth_rand", None, [C.c_uint64, _u8p, C.c_size_t]),
@@ -312,6 +313,23 @@ def decompress(archive) -> bytes:
     if rc != 0:
         raise BceError(rc, "bce_hip_decompress")
     return out.tobytes()
+
+
+def decompress_device(archive, device=0, ctx=None) -> bytes:
+    """`bce -d` with the GPU doing everything but the eight sequential range decoders (kd_decode.hip)."""
+    own = ctx is None
+    c = ctx or _Ctx(device)
+    try:
+        a = _as_u8(archive)
+        n = C.c_size_t()
+        c.check(c.lib.bce_hip_decompress_device(c.h, a.ctypes.data, len(a), None, 0, C.byref(n)), "bce_hip_decompress_device")
+        out = np.empty(n.value, dtype=np.uint8)
+        c.check(c.lib.bce_hip_decompress_device(c.h, a.ctypes.data, len(a), out.ctypes.data, n.value, C.byref(n)),
+                "bce_hip_decompress_device")
+        return out.tobytes()
+    finally:
+        if own:
+            c.close()
 
 
 def synth_text(seed, n) -> np.ndarray:

@@ -15,83 +15,20 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <stdio.h>
 #include <vector>
 
 #include "../../include/bce_hip.h"
 #include "bce_core.h"
 #include "host_coder.h"
 
+#include "decoder_core.h"
+
 namespace {
 
-constexpr uint32_t kUnknown = 0xFFFFFFFFu;
-
-// AdaptiveCoder<31>, decode side
-struct Decoder {
-  uint64_t l = 0, h = ~0ull, m = 0;
-  const uint16_t *data = nullptr;
-  size_t size = 0, o = 0;
-  bce::PlaneCfg cfg;
-  uint8_t bits[32];
-  std::vector<uint8_t> stat;
-  bool overrun = false;
-
-  uint16_t next() { const uint16_t v = o < size ? data[o] : 0; ++o; return v; }   // reads past the end give 0 (:568)
-  void open(const uint16_t *d, size_t n) {                       // ctor :495-504: the first 4 words, missing ones as 0
-    data = d; size = n; o = 0; l = 0; h = ~0ull; m = 0;
-    for (int i = 0; i < 4; ++i) m = (m << 16) + next();
-  }
-  void shift_in() {                                              // :663-669
-    while (!((h ^ l) >> 48)) {
-      m = (m << 16) + next();
-      l = (l << 16) + 0x0000;
-      h = (h << 16) + 0xFFFF;
-    }
-  }
-  uint32_t get(uint32_t k) {                                     // :592-608
-    if (h - l < k) { for (int i = 0; i < 4; ++i) m = (m << 16) + next(); l = 0; h = ~0ull; }
-    const uint64_t step = (h - l) / k;
-    const uint32_t s = (uint32_t)((m - l) / step);
-    l += step * s;
-    h = step + l - 1;
-    shift_in();
-    return s;
-  }
-  uint32_t getv() {                                              // :372-377
-    uint32_t s = 0;
-    int i = 0;
-    for (uint32_t j = get(3); i < 31 && j != 2; ++i, j = get(3)) s |= j << i;
-    return s;
-  }
-  void init() {                                                  // init(0, i) :692-705
-    uint32_t last = 0;
-    for (int b = 0; b < 32; ++b) { const uint32_t bit = get(2) ? get(6) : last; bits[b] = (uint8_t)bit; last = bit; }
-    bce::plane_cfg_init(cfg, bits);
-    stat.assign(cfg.stat_bytes + 1, 0);
-  }
-  uint32_t get_adaptive(uint32_t k, uint32_t c1, uint32_t c2, uint32_t cs) {   // :555-590
-    if (k > (uint32_t)bce::kMaxK) {
-      const uint32_t s = get(2);
-      return (get_adaptive((k + (~s & 1u)) >> 1, c1, c2, cs) << 1) | s;
-    }
-    const uint32_t b = cfg.bits[k];
-    const uint32_t ctxv = (((uint32_t)(c1 << b) / cs) << b) | ((uint32_t)(c2 << b) / cs);   // :671-677
-    uint8_t *ctx = stat.data() + cfg.off[k] + ctxv * k;
-    uint32_t tot = k;
-    for (uint32_t i = 0; i < k; ++i) tot += ctx[i];
-    if (h - l < tot) { for (int i = 0; i < 4; ++i) m = (m << 16) + next(); l = 0; h = ~0ull; }
-    const uint64_t step = (h - l) / tot;
-    h = l - 1;
-    uint32_t s = ~0u;
-    do {
-      ++s;
-      l = h + 1;
-      h += step * ((uint64_t)ctx[s] + 1);
-    } while (h < m && s + 1 < k);
-    if (++ctx[s] == 0xFF) for (uint32_t i = 0; i < k; ++i) ctx[i] >>= 1;
-    shift_in();
-    return s;
-  }
-};
+using bce::Decoder;
+using bce::kUnknown;
 
 struct Triple { uint32_t s, x0, x1; };
 
@@ -99,45 +36,23 @@ struct Triple { uint32_t s, x0, x1; };
 
 // Decode an archive produced by `bce -c`.  out == NULL: only report the decoded size in *out_len.
 extern "C" int bce_hip_decompress(const uint8_t *archive, size_t len, uint8_t *out, size_t cap, size_t *out_len) {
-  if (!archive || !out_len || len < 4 || (len & 1)) return BCE_HIP_E_ARG;
-  const uint16_t *w = reinterpret_cast<const uint16_t *>(archive);
-  const size_t nw = len / 2;
-  const uint32_t header_size = w[0];                              // :1178
-  if ((size_t)header_size + 1 > nw) return BCE_HIP_E_ARG;
-  Decoder mainc;
-  mainc.open(w + 1, header_size);
-  mainc.init();
-  const uint32_t n = mainc.getv();                                // :1181-1183
-  if (n == 0) return BCE_HIP_E_ARG;
-  const uint32_t offset = mainc.get(n + 1);
-  uint32_t size = mainc.getv();
-  *out_len = n;
+  if (!archive || !out_len) return BCE_HIP_E_ARG;
+  bce::ArchiveHead hd;
+  if (bce::parse_archive(archive, len, hd, /*header_only=*/true) != 0) return BCE_HIP_E_ARG;
+  *out_len = hd.n;
   if (!out) return BCE_HIP_OK;
-  if (cap < n) return BCE_HIP_E_OVERFLOW;
-  size_t coff[9];
-  coff[0] = (size_t)header_size + 1;
-  for (int i = 0; i < 7; ++i) {                                   // :1187-1190
-    const uint32_t li = mainc.get(size + 1u);
-    coff[i + 1] = coff[i] + li;
-    size -= li;
-  }
-  coff[8] = nw;
-  for (int i = 0; i < 9; ++i) if (coff[i] > nw) return BCE_HIP_E_ARG;
-  std::vector<Decoder> dec(8);
-  for (int i = 0; i < 8; ++i) {                                   // :1193-1202
-    if (coff[i + 1] < coff[i]) return BCE_HIP_E_ARG;
-    dec[i].open(w + coff[i], coff[i + 1] - coff[i]);
-    dec[i].init();
-  }
+  if (cap < hd.n) return BCE_HIP_E_OVERFLOW;
+  if (bce::parse_archive(archive, len, hd, false) != 0) return BCE_HIP_E_ARG;
+  const uint32_t n = hd.n, offset = hd.offset;
+  std::vector<Decoder> &dec = hd.dec;
+  const uint32_t *C = hd.C;
   // boundary ranks: r1[p][x] = rank1_p(x) once known
   std::vector<std::vector<uint32_t>> r1(8);
   for (int p = 0; p < 8; ++p) { r1[p].assign((size_t)n + 1, kUnknown); r1[p][0] = 0; }
-  uint32_t C[8];
-  for (int i = 0; i < 8; ++i) {                                   // :1207-1211
-    C[i] = dec[i].get(n + 1);
-    if (C[i] > n) return BCE_HIP_E_ARG;
-    r1[(i + 7) & 7][n] = n - C[i];
-  }
+  for (int i = 0; i < 8; ++i) r1[(i + 7) & 7][n] = n - C[i];
+  const bool timing = getenv("BCE_DEC_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tp0 = tnow();
   std::vector<Triple> cur[8][2], nxt[8][2];
   for (int i = 0; i < 8; ++i)
     if (C[i] && n - C[i]) cur[i][0].push_back(Triple{0u, C[i], n - C[i]});   // :1214-1216
@@ -182,6 +97,7 @@ extern "C" int bce_hip_decompress(const uint8_t *archive, size_t len, uint8_t *o
       for (int j = 0; j < 2; ++j) { cur[i][j].swap(nxt[i][j]); nxt[i][j].clear(); if (!cur[i][j].empty()) again = true; }
   }
   if (bad) return BCE_HIP_E_INTERNAL;
+  if (timing) { fprintf(stderr, "decode: code loop %.2f s\n", tnow() - tp0); tp0 = tnow(); }
   // materialise the planes: between two known boundaries all bits are equal
   std::vector<std::vector<uint8_t>> bit(8);
   for (int p = 0; p < 8; ++p) {
@@ -220,6 +136,7 @@ extern "C" int bce_hip_decompress(const uint8_t *archive, size_t len, uint8_t *o
     }
   }
   for (int p = 0; p < 8; ++p) std::vector<uint8_t>().swap(bit[p]);
+  if (timing) { fprintf(stderr, "decode: planes + unbwt %.2f s\n", tnow() - tp0); tp0 = tnow(); }
   // inverse_bw_transform(out, out, nullptr, n, 1) + rotate (:1091-1093).  The encoder's BWT is the BWT of all
   // cyclic rotations with row 0 = the minimal rotation R (that is what idx = 1 says in libdivsufsort's
   // sentinel convention), so R is recovered by a cyclic LF walk from row 0; for periodic inputs the walk runs
@@ -243,5 +160,6 @@ extern "C" int bce_hip_decompress(const uint8_t *archive, size_t len, uint8_t *o
     memcpy(out, text.data() + (n - off), off);
     memcpy(out + off, text.data(), n - off);
   }
+  if (timing) fprintf(stderr, "decode: inverse BWT %.2f s\n", tnow() - tp0);
   return BCE_HIP_OK;
 }

@@ -69,9 +69,6 @@ void HostCoder::begin(const uint8_t config[9][32], const uint32_t C[8], uint32_t
 // The model totals are < 8192 (k <= 31 counters <= 254, + k), so a table indexed by the divisor replaces the
 // 64-bit divide on the coder's dependency chain (step = (h - l) / total, bce.cpp:527); the quotient is
 // bit-identical.  x = 2^64 - 1 (right after a range reset) and larger divisors take the real divide.
-namespace {
-struct Recip { uint64_t m; int32_t am1; uint32_t sh; };   // am1 = add - 1: the multiplicand is (r + 1) + am1
-constexpr uint32_t kRecipMax = 8192;
 const Recip *recip_table() {
   static const std::vector<Recip> tab = [] {
     std::vector<Recip> t(kRecipMax);
@@ -91,10 +88,6 @@ const Recip *recip_table() {
   }();
   return tab.data();
 }
-inline uint64_t div_recip1(uint64_t x1, const Recip &r) {   // floor((x1 - 1) / d) for x1 = x + 1 != 0
-  return (uint64_t)(((unsigned __int128)r.m * (x1 + (uint64_t)(int64_t)r.am1)) >> 64) >> r.sh;
-}
-}  // namespace
 
 uint64_t bce_test_div_recip(uint64_t x, uint32_t d) {
   return x == ~0ull ? x / d : div_recip1(x + 1, recip_table()[d]);

@@ -98,6 +98,17 @@ struct HostCoder {
   void run(int p);
 };
 
+// Exact floor(x / d) for d < kRecipMax by one multiplication (host_coder.cpp explains the two magic variants).
+struct Recip { uint64_t m; int32_t am1; uint32_t sh; };   // am1 = add - 1: the multiplicand is (x + 1) + am1
+constexpr uint32_t kRecipMax = 8192;
+const Recip *recip_table();
+inline uint64_t div_recip1(uint64_t x1, const Recip &r) {   // floor((x1 - 1) / d) for x1 = x + 1 != 0
+  return (uint64_t)(((unsigned __int128)r.m * (x1 + (uint64_t)(int64_t)r.am1)) >> 64) >> r.sh;
+}
+inline uint64_t div_small(uint64_t x, uint32_t d, const Recip *rt) {   // any x; table for d < kRecipMax
+  return (x == ~0ull || d >= kRecipMax) ? x / d : div_recip1(x + 1, rt[d]);
+}
+
 extern const uint8_t kDefaultConfig[9][32];
 uint64_t bce_test_div_recip(uint64_t x, uint32_t d);   // exposed for tests/core_emul.cpp             // AdaptiveCoder<31>::init_ :713-724
 

@@ -1,0 +1,827 @@
+// kd_decode.hip -- GPU-assisted decoder (`bce -d`), SURVEY section 8f "next #1".
+//
+// BCE::decode (bce.cpp:1169-1233) walks the same 8 tries as the encoder (BCE::code mode 0, bce.cpp:1236-1374),
+// but the split of every interval comes out of the plane's range decoder, whose state depends on every symbol
+// before it: one strictly sequential stream per plane.  What is NOT sequential is everything around it, and
+// that is where the reference spends its time (8n nodes, 3 rank look-ups each; then 8 cursor reads per byte for
+// unbwt and one cache miss per byte for the inverse BWT).  So, per round:
+//   GPU  (1) classify every node from the dense boundary-rank arrays R[p][x] = rank1_p(x) (known at every
+//            boundary learnt so far); nodes whose split is forced need no symbol; the others become QUERIES
+//            (k, c1, c2, cs) in stream order (count / scan / write, the K3 pattern),
+//   host (2) the eight plane decoders answer their queries in order (8 threads: AdaptiveCoder::get,
+//            bce.cpp:555-590; the adaptive counters live here because each answer feeds the next),
+//   GPU  (3) children + the new boundary rank R[s + x0] from the answers (count / scan / write).
+// After the last round: gap fill (between two known boundaries a plane is constant) -> rank granules ->
+// wavelet-matrix access = unbwt::bytewise (bce.cpp:1043-1085) -> LF mapping by one radix pass -> inverse BWT by
+// 2^18..2^19 concurrent walkers that stop at marked rows (segments are chained on the host, then written in
+// place, rotated by `offset`, bce.cpp:1091-1093).
+// The archive format, the model and the coder arithmetic are the reference's; parity = decode(reference
+// archive) == input (tests/test_gpu_decode.py).  Inputs whose LF mapping is not one cycle (periodic inputs)
+// finish on the host walk of decoder.cpp.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+#include "decoder_core.h"
+#include "k3_args.h"
+#include "scan_util.h"
+
+namespace bce {
+
+namespace {
+
+struct DecCtl {
+  uint32_t cnt[2][8][2];     // [parity][plane][seg] node counts, as EnumCtl
+  uint32_t ptot[8][3];       // per plane totals of the scan in flight: child0, child1, queries
+  uint32_t qbase[8];         // first query of each plane in this round's query buffer
+  uint32_t ticket, err;      // err: 1 inconsistent archive, 2 node list overflow
+  uint32_t next_nodes, pad;
+  uint64_t nodes_total;
+};
+
+struct DecInfo {             // what the host needs after the query pass (pinned host memory)
+  uint32_t qbase[8], qtot[8];
+  uint32_t cur_nodes, err;
+  uint64_t nodes_total;
+};
+
+struct DecArgs {
+  DecCtl *ctl;
+  DecInfo *info;             // device pointer of the pinned DecInfo
+  Node *nodes;               // [2][8][capP]
+  uint32_t *R;               // [8][n + 1] boundary ranks, kUnknown where not learnt yet
+  uint32_t *tilecnt, *tileoff;   // [tiles][4]: 0 child0, 1 child1, 2 queries
+  uint4 *Q;                  // queries of the round: (k, ctx, 0, 0) with the context resolved, or (k, c1, c2, cs) for k > 31
+  const PlaneCfg *cfg;       // [8] the archive's context-bit tables (the preamble of each stream)
+  const uint32_t *res;       // answers, same indexing
+  uint32_t capP, n, par;
+  uint32_t zeros[8];         // zeros of plane p = C[(p+1)&7]: the child1 lists of plane p start there
+};
+
+__device__ __forceinline__ Node *dec_nodes(const DecArgs &a, uint32_t par, uint32_t p) {
+  return a.nodes + ((size_t)(par * 8u + p)) * a.capP;
+}
+
+__device__ __forceinline__ void dec_tile_prefix(const DecArgs &a, uint32_t tp[9]) {
+  uint32_t acc = 0;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    tp[p] = acc;
+    const uint32_t m = a.ctl->cnt[a.par][p][0] + a.ctl->cnt[a.par][p][1];
+    acc += (m + K3_TILE - 1) / K3_TILE;
+  }
+  tp[8] = acc;
+}
+
+// Exclusive ranks of up to three flag sets over the nodes of a tile in list order (item, wave, lane), and the
+// tile totals.  Two barriers; `lds` may be reused afterwards.
+__device__ __forceinline__ void tile_ranks(const uint32_t (&f0)[K3_NPT], const uint32_t (&f1)[K3_NPT],
+                                           const uint32_t (&f2)[K3_NPT], uint32_t (*lds)[4][3], uint32_t (&r0)[K3_NPT],
+                                           uint32_t (&r1)[K3_NPT], uint32_t (&r2)[K3_NPT], uint32_t (&tot)[3]) {
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int it = 0; it < K3_NPT; ++it) {
+    const uint64_t b0 = __ballot(f0[it]), b1 = __ballot(f1[it]), b2 = __ballot(f2[it]);
+    r0[it] = (uint32_t)__popcll(b0 & lt);
+    r1[it] = (uint32_t)__popcll(b1 & lt);
+    r2[it] = (uint32_t)__popcll(b2 & lt);
+    if (lane == 0) {
+      lds[it][w][0] = (uint32_t)__popcll(b0);
+      lds[it][w][1] = (uint32_t)__popcll(b1);
+      lds[it][w][2] = (uint32_t)__popcll(b2);
+    }
+  }
+  __syncthreads();
+  uint32_t run0 = 0, run1 = 0, run2 = 0;
+#pragma unroll
+  for (int it = 0; it < K3_NPT; ++it) {
+    uint32_t b0 = run0, b1 = run1, b2 = run2;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      const uint32_t x0 = lds[it][ww][0], x1 = lds[it][ww][1], x2 = lds[it][ww][2];
+      if ((uint32_t)ww < w) { b0 += x0; b1 += x1; b2 += x2; }
+      run0 += x0; run1 += x1; run2 += x2;
+    }
+    r0[it] += b0; r1[it] += b1; r2[it] += b2;
+  }
+  tot[0] = run0; tot[1] = run1; tot[2] = run2;
+  __syncthreads();
+}
+
+// One node of BCE::code, decode mode (bce.cpp:1261-1351), split in two: what the ranks alone say ...
+struct DCls { uint32_t s1, n1x, kind, mn, mx, bad; };   // kind 0: all zeros, 1: all ones, 2: forced split, 3: coded split
+__device__ __forceinline__ DCls dec_classify(const Node &nd, const uint32_t *__restrict__ R, uint32_t n) {
+  DCls c;
+  const uint32_t x = nd.x0 + nd.x1;
+  c.bad = ((uint64_t)nd.s + x > n || nd.x0 == 0 || nd.x1 == 0) ? 1u : 0u;
+  const uint32_t s1 = c.bad ? 0u : R[nd.s], e1 = c.bad ? 0u : R[nd.s + x];
+  if (s1 == kUnknown || e1 == kUnknown || e1 < s1 || e1 - s1 > x) c.bad = 1u;
+  c.s1 = s1;
+  c.n1x = c.bad ? 0u : e1 - s1;
+  c.mn = c.mx = 0;
+  if (c.n1x == 0) c.kind = 0;                                    // :1274-1279
+  else if (c.n1x == x) c.kind = 1;                               // :1282-1287
+  else {
+    uint32_t mn = nd.x0 - c.n1x, mx = c.n1x - nd.x1;             // :1290-1294
+    mn = ((int32_t)mn < 0) ? 0u : mn;
+    mx = ((int32_t)mx < 0) ? 0u : mx;
+    c.mn = mn;
+    c.mx = nd.x0 - mx;
+    c.kind = c.mx != c.mn ? 3u : 2u;
+  }
+  return c;
+}
+// ... and the children once the split n0x0 is known (:1337-1350).  Returns the value for R[s + x0].
+__device__ __forceinline__ uint32_t dec_children(const Node &nd, const DCls &c, uint32_t n0x0, uint32_t zi, uint32_t &has0,
+                                                 Node &c0, uint32_t &has1, Node &c1) {
+  const uint32_t x = nd.x0 + nd.x1, s0 = nd.s - c.s1;
+  has0 = has1 = 0;
+  c0 = Node{0, 0, 0}; c1 = Node{0, 0, 0};
+  if (c.kind == 0) { has0 = 1; c0 = Node{s0, nd.x0, nd.x1}; return c.s1; }
+  if (c.kind == 1) { has1 = 1; c1 = Node{zi + c.s1, nd.x0, nd.x1}; return c.s1 + nd.x0; }
+  const uint32_t n0x = x - c.n1x;
+  const uint32_t n0x1 = n0x - n0x0;
+  if (n0x0 && n0x1) { has0 = 1; c0 = Node{s0, n0x0, n0x1}; }
+  const uint32_t n1x1 = nd.x1 - n0x1;
+  const uint32_t n1x0 = c.n1x - n1x1;
+  if (n1x0 && n1x1) { has1 = 1; c1 = Node{zi + c.s1, n1x0, n1x1}; }
+  return c.s1 + n1x0;
+}
+
+// MODE 0: count the queries of each tile.  1: write them.  2: count the children.  3: write children and ranks.
+template <int MODE>
+__global__ __launch_bounds__(K3_T) void dec_tiles_kernel(DecArgs a) {
+  __shared__ uint32_t tp[9];
+  __shared__ uint32_t lds_cnt[K3_NPT][4][3];
+  if (a.ctl->err) return;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) dec_tile_prefix(a, tp);
+  __syncthreads();
+  const uint32_t T = tp[8];
+  for (uint32_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
+    uint32_t p = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) p += (tile >= tp[k]) ? 1u : 0u;
+    const uint32_t ti = tile - tp[p];
+    const uint32_t c0n = a.ctl->cnt[a.par][p][0], M = c0n + a.ctl->cnt[a.par][p][1];
+    const Node *src = dec_nodes(a, a.par, p);
+    uint32_t *R = a.R + (size_t)p * ((size_t)a.n + 1);
+    const uint32_t zi = a.zeros[p];
+    Node nd[K3_NPT];
+    DCls cl[K3_NPT];
+    uint32_t valid[K3_NPT], isq[K3_NPT], zero[K3_NPT];
+    uint32_t bad = 0;
+#pragma unroll
+    for (int it = 0; it < K3_NPT; ++it) {
+      const uint32_t q = ti * K3_TILE + (uint32_t)it * K3_T + tid;
+      valid[it] = q < M ? 1u : 0u;
+      const uint32_t qq = valid[it] ? q : ti * K3_TILE;
+      nd[it] = src[qq < c0n ? qq : (a.capP - 1u - (qq - c0n))];
+    }
+#pragma unroll
+    for (int it = 0; it < K3_NPT; ++it) {
+      cl[it] = dec_classify(nd[it], R, a.n);
+      bad |= cl[it].bad & valid[it];
+      isq[it] = (valid[it] && cl[it].kind == 3u) ? 1u : 0u;
+      zero[it] = 0;
+    }
+    uint32_t qr[K3_NPT], d1[K3_NPT], d2[K3_NPT], tot[3];
+    tile_ranks(isq, zero, zero, lds_cnt, qr, d1, d2, tot);
+    if (bad) a.ctl->err = 1;
+    if (MODE == 0) {
+      if (tid == 0) a.tilecnt[(size_t)tile * 4 + 2] = tot[0];
+      continue;
+    }
+    const uint32_t qb = a.ctl->qbase[p] + a.tileoff[(size_t)tile * 4 + 2];
+    if (MODE == 1) {
+#pragma unroll
+      for (int it = 0; it < K3_NPT; ++it)
+        if (isq[it]) {
+          // get(k, _0x, _x1, _x) :1304; the context of get_context (:671-677) is resolved here when k needs no escape
+          const uint32_t x = nd[it].x0 + nd[it].x1, k = cl[it].mx - cl[it].mn + 1u, c1 = x - cl[it].n1x, c2 = nd[it].x1;
+          if (k <= (uint32_t)kMaxK) {
+            const uint32_t b = a.cfg[p].bits[k];
+            const uint32_t ctxv = (small_quotient((uint32_t)(c1 << b), x) << b) | small_quotient((uint32_t)(c2 << b), x);
+            a.Q[qb + qr[it]] = make_uint4(k, ctxv, 0u, 0u);
+          } else {
+            a.Q[qb + qr[it]] = make_uint4(k, c1, c2, x);
+          }
+        }
+      continue;
+    }
+    uint32_t has0[K3_NPT], has1[K3_NPT], rval[K3_NPT];
+    Node c0[K3_NPT], c1[K3_NPT];
+#pragma unroll
+    for (int it = 0; it < K3_NPT; ++it) {
+      uint32_t v = cl[it].mn;
+      if (isq[it]) v += a.res[qb + qr[it]];
+      if (valid[it] && cl[it].kind >= 2u && v > cl[it].mx) { bad = 1; v = cl[it].mn; }
+      rval[it] = dec_children(nd[it], cl[it], v, zi, has0[it], c0[it], has1[it], c1[it]);
+      has0[it] &= valid[it];
+      has1[it] &= valid[it];
+    }
+    if (bad) a.ctl->err = 1;
+    uint32_t r0[K3_NPT], r1[K3_NPT];
+    tile_ranks(has0, has1, zero, lds_cnt, r0, r1, d2, tot);
+    if (MODE == 2) {
+      if (tid == 0) { a.tilecnt[(size_t)tile * 4 + 0] = tot[0]; a.tilecnt[(size_t)tile * 4 + 1] = tot[1]; }
+      continue;
+    }
+    const uint32_t o0 = a.tileoff[(size_t)tile * 4 + 0], o1 = a.tileoff[(size_t)tile * 4 + 1];
+    Node *dst = dec_nodes(a, a.par ^ 1u, (p + 1u) & 7u);
+#pragma unroll
+    for (int it = 0; it < K3_NPT; ++it) {
+      if (has0[it]) dst[o0 + r0[it]] = c0[it];
+      if (has1[it]) dst[a.capP - 1u - (o1 + r1[it])] = c1[it];
+      if (valid[it] && !cl[it].bad) R[nd[it].s + nd[it].x0] = rval[it];        // ranks[i].set(s + _x0, s1 + _1x0) :1277,1285,1350
+    }
+  }
+}
+
+// Per-plane exclusive scan of the tile counts (block p = plane p) and the round's bookkeeping by the block that
+// finishes last.  QUERY: queries -> tileoff[.][2], query bases, DecInfo for the host.  !QUERY: children ->
+// tileoff[.][0..1], next round's list sizes.
+template <bool QUERY>
+__global__ __launch_bounds__(1024) void dec_scan_kernel(DecArgs a) {
+  __shared__ uint32_t tp[9];
+  __shared__ uint32_t s_last;
+  DecCtl *ctl = a.ctl;
+  const uint32_t tid = threadIdx.x, p = blockIdx.x;
+  if (tid == 0) dec_tile_prefix(a, tp);
+  __syncthreads();
+  uint32_t r0 = 0, r1 = 0;
+  if (!ctl->err) {
+    for (uint32_t base = tp[p]; base < tp[p + 1]; base += 1024) {
+      const uint32_t t = base + tid;
+      const bool valid = t < tp[p + 1];
+      if (QUERY) {
+        const uint32_t v = valid ? a.tilecnt[(size_t)t * 4 + 2] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_sum<1024>(v, &tot);
+        if (valid) a.tileoff[(size_t)t * 4 + 2] = r0 + ex;
+        r0 += tot;
+      } else {
+        const uint32_t v0 = valid ? a.tilecnt[(size_t)t * 4 + 0] : 0u, v1 = valid ? a.tilecnt[(size_t)t * 4 + 1] : 0u;
+        uint64_t tot;
+        const uint64_t ex = block_excl_scan_sum64<1024>((uint64_t)v0 | ((uint64_t)v1 << 32), &tot);
+        if (valid) {
+          a.tileoff[(size_t)t * 4 + 0] = r0 + (uint32_t)ex;
+          a.tileoff[(size_t)t * 4 + 1] = r1 + (uint32_t)(ex >> 32);
+        }
+        r0 += (uint32_t)tot; r1 += (uint32_t)(tot >> 32);
+      }
+    }
+  }
+  if (tid == 0) {
+    if (QUERY) ctl->ptot[p][2] = r0; else { ctl->ptot[p][0] = r0; ctl->ptot[p][1] = r1; }
+    __threadfence();
+    s_last = atomicAdd(&ctl->ticket, 1u) == 7u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last || tid != 0) return;
+  __threadfence();
+  ctl->ticket = 0;
+  const volatile uint32_t (*pt)[3] = ctl->ptot;
+  uint64_t curn = 0;
+  for (int q = 0; q < 8; ++q) curn += (uint64_t)ctl->cnt[a.par][q][0] + ctl->cnt[a.par][q][1];
+  if (QUERY) {
+    uint32_t acc = 0;
+    for (int q = 0; q < 8; ++q) {
+      ctl->qbase[q] = acc;
+      a.info->qbase[q] = acc;
+      a.info->qtot[q] = pt[q][2];
+      acc += pt[q][2];
+    }
+    a.info->cur_nodes = (uint32_t)curn;
+    a.info->nodes_total = ctl->nodes_total;
+    __threadfence_system();
+    a.info->err = ctl->err;
+  } else {
+    uint64_t nextn = 0;
+    bool ovf = false;
+    for (uint32_t q = 0; q < 8; ++q) {
+      const uint32_t qn = (q + 1u) & 7u;
+      ctl->cnt[a.par ^ 1u][qn][0] = pt[q][0];
+      ctl->cnt[a.par ^ 1u][qn][1] = pt[q][1];
+      nextn += (uint64_t)pt[q][0] + pt[q][1];
+      if ((uint64_t)pt[q][0] + pt[q][1] > a.capP) ovf = true;
+    }
+    if (ovf && !ctl->err) ctl->err = 2;
+    ctl->nodes_total += curn;
+    ctl->next_nodes = (uint32_t)nextn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// After the last round: R -> plane bits -> rank granules.  Between two known boundaries a < b a plane is
+// constant: all ones iff R[b] - R[a] == b - a, all zeros iff R[b] == R[a] (anything else: inconsistent archive).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int FG_T = 256;
+constexpr uint32_t FG_PER = 32;                        // positions per thread = one 32-bit word of the plane
+constexpr uint32_t FG_CHUNK = FG_T * FG_PER;           // 8192 positions per block
+
+struct FillArgs {
+  const uint32_t *R;        // [8][n + 1]
+  uint32_t *cmax;           // [8][chunks]: last known index + 1 inside the chunk (0 = none), then its exclusive prefix max
+  uint8_t *type;            // [8][n + 1]: at a known index a: 1 if the gap that starts at a is all ones
+  uint32_t *words;          // [8][nwords] plane bits, LSB first
+  uint32_t *rankw;          // [8][nwords] rank1 at the first position of each word
+  uint32_t n, chunks, nwords;
+  uint32_t *err;
+};
+
+__global__ __launch_bounds__(FG_T) void fill_chunkmax_kernel(FillArgs a) {
+  const uint32_t p = blockIdx.y, c = blockIdx.x;
+  const uint32_t *R = a.R + (size_t)p * ((size_t)a.n + 1);
+  uint32_t best = 0;
+  const uint64_t base = (uint64_t)c * FG_CHUNK;
+  for (uint32_t i = threadIdx.x; i < FG_CHUNK; i += FG_T) {
+    const uint64_t q = base + i;
+    if (q <= a.n && R[q] != kUnknown) best = (uint32_t)q + 1u;
+  }
+  uint32_t tot;
+  (void)block_incl_scan_max<FG_T>(best, &tot);
+  if (threadIdx.x == 0) a.cmax[(size_t)p * a.chunks + c] = tot;
+}
+
+// exclusive prefix max over the chunks of one plane (block = plane)
+__global__ __launch_bounds__(1024) void fill_chunkscan_kernel(FillArgs a) {
+  uint32_t *cm = a.cmax + (size_t)blockIdx.x * a.chunks;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < a.chunks; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < a.chunks ? cm[i] : 0u;
+    uint32_t tot;
+    const uint32_t inc = block_incl_scan_max<1024>(v, &tot);
+    __shared__ uint32_t sh[1024];
+    sh[threadIdx.x] = inc;
+    __syncthreads();
+    uint32_t ex = threadIdx.x ? sh[threadIdx.x - 1] : 0u;
+    ex = ex > carry ? ex : carry;
+    __syncthreads();
+    if (i < a.chunks) cm[i] = ex;
+    carry = carry > tot ? carry : tot;
+  }
+}
+
+// PASS 0: gap types at the known indices.  PASS 1: plane words + word ranks.
+template <int PASS>
+__global__ __launch_bounds__(FG_T) void fill_kernel(FillArgs a) {
+  __shared__ uint32_t sh[FG_T];
+  const uint32_t p = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+  const uint32_t *R = a.R + (size_t)p * ((size_t)a.n + 1);
+  uint8_t *type = a.type + (size_t)p * ((size_t)a.n + 1);
+  const uint64_t q0 = (uint64_t)c * FG_CHUNK + (uint64_t)tid * FG_PER;
+  // last known index + 1 among my positions, then the same for everything before me
+  uint32_t r[FG_PER];
+  uint32_t mine = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < FG_PER; ++i) {
+    const uint64_t q = q0 + i;
+    r[i] = q <= a.n ? R[q] : kUnknown;
+    if (r[i] != kUnknown) mine = (uint32_t)q + 1u;
+  }
+  uint32_t tot;
+  const uint32_t inc = block_incl_scan_max<FG_T>(mine, &tot);
+  sh[tid] = inc;
+  __syncthreads();
+  uint32_t last = tid ? sh[tid - 1] : 0u;                     // known index + 1 before my range, inside the chunk
+  const uint32_t carry = a.cmax[(size_t)p * a.chunks + c];
+  last = last > carry ? last : carry;                         // ... or in an earlier chunk (index 0 is always known)
+  if (PASS == 0) {
+    uint32_t a_idx = last ? last - 1u : 0u;
+    uint32_t ra = last ? R[a_idx] : 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < FG_PER; ++i) {
+      const uint64_t q = q0 + i;
+      if (q == 0 || q > a.n || r[i] == kUnknown) { if (q == 0 && r[i] != kUnknown) { a_idx = 0; ra = r[i]; } continue; }
+      const uint32_t ones = r[i] - ra, wdt = (uint32_t)q - a_idx;
+      if (r[i] < ra || (ones != 0 && ones != wdt)) *a.err = 1;   // a mixed gap that was never split
+      type[a_idx] = ones == wdt ? 1 : 0;
+      a_idx = (uint32_t)q; ra = r[i];
+    }
+  } else {
+    uint32_t a_idx = last ? last - 1u : 0u;
+    uint32_t ra = R[a_idx];
+    uint32_t ty = type[a_idx];
+    uint32_t word = 0;
+    const uint32_t rank_first = ra + ty * ((uint32_t)q0 - a_idx);   // valid when q0 <= n (checked below)
+    uint32_t rank0 = rank_first;
+#pragma unroll
+    for (uint32_t i = 0; i < FG_PER; ++i) {
+      const uint64_t q = q0 + i;
+      if (q >= a.n) break;
+      if (r[i] != kUnknown) { a_idx = (uint32_t)q; ra = r[i]; ty = type[a_idx]; if (i == 0) rank0 = ra; }
+      word |= ty << i;
+    }
+    const uint64_t w = q0 / 32;
+    if (w < a.nwords) {
+      a.words[(size_t)p * a.nwords + w] = word;
+      a.rankw[(size_t)p * a.nwords + w] = q0 <= a.n ? rank0 : 0u;
+    }
+  }
+}
+
+__global__ void gran_from_words_kernel(FillArgs a, Granule *gran, uint32_t ngran) {
+  const uint32_t p = blockIdx.y;
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngran; g += gridDim.x * blockDim.x) {
+    const uint32_t *W = a.words + (size_t)p * a.nwords, *RW = a.rankw + (size_t)p * a.nwords;
+    const uint64_t w = (uint64_t)g * 3;
+    Granule G;
+    G.w0 = w < a.nwords ? W[w] : 0u;
+    G.w1 = w + 1 < a.nwords ? W[w + 1] : 0u;
+    G.w2 = w + 2 < a.nwords ? W[w + 2] : 0u;
+    G.cum = w < a.nwords ? RW[w] : 0u;
+    gran[(size_t)p * ngran + g] = G;
+  }
+}
+
+// unbwt::bytewise (bce.cpp:1043-1085) as wavelet-matrix access: byte i = the bits met while following position
+// i through the eight stable partitions (the reference's cursor heap D does the same walk for all i in order).
+__global__ void access_kernel(const Granule *__restrict__ gran, uint32_t ngran, uint32_t n, const uint32_t *zeros8,
+                              uint8_t *__restrict__ bwt) {
+  uint32_t zeros[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) zeros[j] = zeros8[j];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    uint32_t pos = i, chr = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t g = div96(pos), o = pos - g * 96u;
+      const Granule G = gran[(size_t)j * ngran + g];
+      const uint32_t r1 = granule_rank1(G, o);
+      const uint32_t wsel = o >> 5, word = wsel == 0 ? G.w0 : (wsel == 1 ? G.w1 : G.w2);
+      const uint32_t b = (word >> (o & 31u)) & 1u;
+      chr |= b << j;
+      pos = b ? zeros[j] + r1 : pos - r1;
+    }
+    bwt[i] = (uint8_t)chr;
+  }
+}
+
+// ---- inverse BWT: LF by one stable radix pass on the byte, then concurrent walkers between marked rows ----
+__global__ void lf_keys_kernel(const uint8_t *__restrict__ bwt, uint32_t n, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { keys[i] = bwt[i]; vals[i] = i; }
+}
+__global__ void lf_scatter_kernel(const uint32_t *__restrict__ sorted_rows, uint32_t n, uint32_t *__restrict__ lf) {
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) lf[sorted_rows[k]] = k;
+}
+// walker j starts at row j << sh and stops in front of the next row that is a multiple of 2^sh
+__global__ void walk_len_kernel(const uint32_t *__restrict__ lf, uint32_t m, uint32_t sh, uint32_t *__restrict__ len,
+                                uint32_t *__restrict__ endrow) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const uint32_t mask = (1u << sh) - 1u;
+  uint32_t row = j << sh, l = 0;
+  do { row = lf[row]; ++l; } while (row & mask);
+  len[j] = l; endrow[j] = row;
+}
+// text[i] = bwt[row_i] along the walk; text position i lands at out[(i + off) % n]  (std::rotate, bce.cpp:1093)
+__global__ void walk_write_kernel(const uint32_t *__restrict__ lf, const uint8_t *__restrict__ bwt, uint32_t m, uint32_t sh,
+                                  const uint32_t *__restrict__ len, const uint32_t *__restrict__ dest_end, uint32_t n,
+                                  uint32_t off, uint8_t *__restrict__ out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  uint32_t row = j << sh;
+  const uint32_t l = len[j];
+  uint64_t i = dest_end[j];                                   // one past my last text position
+  for (uint32_t t = 0; t < l; ++t) {
+    --i;
+    uint64_t o = i + off;
+    if (o >= n) o -= n;
+    out[o] = bwt[row];
+    row = lf[row];
+  }
+}
+
+// ---- the host's part of a round: the eight plane decoders answer their queries, in parallel ----
+struct QueryPool {
+  std::vector<Decoder> *dec = nullptr;
+  const uint4 *Q = nullptr;
+  uint32_t *res = nullptr;
+  DecInfo info;
+  std::thread th[8];
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  uint64_t epoch = 0;
+  int pending = 0;
+  bool stop = false;
+
+  static void answer(Decoder &d, const uint4 *q, uint32_t *r, uint32_t cnt) {
+    for (uint32_t i = 0; i < cnt; ++i) {
+      if (i + 8 < cnt && !q[i + 8].w) d.prefetch_slot(q[i + 8].x, q[i + 8].y);     // the counters of a query soon to come
+      r[i] = q[i].w ? d.get_adaptive(q[i].x, q[i].y, q[i].z, q[i].w) : d.get_slot(q[i].x, q[i].y);
+    }
+  }
+  void worker(int p) {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_go.wait(lk, [&] { return stop || epoch != seen; });
+        if (stop) return;
+        seen = epoch;
+      }
+      answer((*dec)[p], Q + info.qbase[p], res + info.qbase[p], info.qtot[p]);
+      {
+        std::lock_guard<std::mutex> g(mu);
+        if (--pending == 0) cv_done.notify_all();
+      }
+    }
+  }
+  void start() { for (int p = 0; p < 8; ++p) th[p] = std::thread([this, p] { worker(p); }); }
+  void run(const DecInfo &in) {
+    info = in;
+    uint64_t total = 0;
+    for (int p = 0; p < 8; ++p) total += in.qtot[p];
+    if (total < 2048) {                                          // not worth waking anybody
+      for (int p = 0; p < 8; ++p) answer((*dec)[p], Q + in.qbase[p], res + in.qbase[p], in.qtot[p]);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> g(mu);
+      pending = 8;
+      ++epoch;
+    }
+    cv_go.notify_all();
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+  ~QueryPool() {
+    { std::lock_guard<std::mutex> g(mu); stop = true; }
+    cv_go.notify_all();
+    for (int p = 0; p < 8; ++p) if (th[p].joinable()) th[p].join();
+  }
+};
+
+struct Pinned {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(bce_hip_ctx *c, size_t bytes) {
+    if (bytes <= cap) return BCE_HIP_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = bytes + bytes / 2;
+    BCE_HIP_TRY(c, hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return BCE_HIP_OK;
+  }
+  ~Pinned() { if (p) (void)hipHostFree(p); }
+};
+
+uint32_t dec_capP(uint32_t n) {
+  const uint64_t worst = (uint64_t)n / 2 + 2, soft = (uint64_t)192 << 20;
+  return (uint32_t)(worst < soft ? worst : soft);
+}
+
+}  // namespace
+
+}  // namespace bce
+
+using namespace bce;
+
+// `bce -d` on the GPU: archive -> original bytes (see the header of this file).  The context is only used for its
+// device, stream and scratch buffers; any compression state in it is dropped.
+extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive, size_t len, uint8_t *out, size_t cap,
+                                         size_t *out_len) {
+  if (!c || !archive || !out_len) return BCE_HIP_E_ARG;
+  ArchiveHead hd;
+  if (parse_archive(archive, len, hd, /*header_only=*/true) != 0) return BCE_HIP_E_ARG;
+  *out_len = hd.n;
+  if (!out) return BCE_HIP_OK;
+  if (cap < hd.n) return BCE_HIP_E_OVERFLOW;
+  if (parse_archive(archive, len, hd, false) != 0) return BCE_HIP_E_ARG;
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  c->coder->drain();
+  c->stage = 0; c->enum_active = false; c->k1_valid = false;   // the scratch buffers below belong to the decoder now
+  const uint32_t n = hd.n;
+  const bool timing = getenv("BCE_DEC_TIMING") != nullptr;
+  double tp0 = now_s();
+
+  // ---- buffers ----
+  const size_t rstride = (size_t)n + 1;
+  c->capP = dec_capP(n);
+  BCE_TRY(ensure(c, c->nodes, (size_t)16 * c->capP * sizeof(Node)));
+  BCE_TRY(ensure(c, c->ctl, sizeof(DecCtl) > sizeof(EnumCtl) ? sizeof(DecCtl) : sizeof(EnumCtl)));
+  const size_t max_tiles = (size_t)8 * ((c->capP + K3_TILE - 1) / K3_TILE + 1);
+  BCE_TRY(ensure(c, c->tilecnt, max_tiles * 16));
+  BCE_TRY(ensure(c, c->tileoff, max_tiles * 16));
+  DevBuf &Rbuf = c->dfs;                                        // 8 x (n + 1) boundary ranks
+  BCE_TRY(ensure(c, Rbuf, 8 * rstride * 4));
+  uint32_t *R = Rbuf.as<uint32_t>();
+  BCE_HIP_TRY(c, hipMemsetAsync(R, 0xFF, 8 * rstride * 4, c->stream));
+  DecCtl ctl;
+  memset(&ctl, 0, sizeof ctl);
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t zero = 0, ones = n - hd.C[i];               // R[p][0] = 0, R[(i+7)&7][n] = n - C[i]  (:1207-1211)
+    BCE_HIP_TRY(c, hipMemcpyAsync(R + (size_t)i * rstride, &zero, 4, hipMemcpyHostToDevice, c->stream));
+    BCE_HIP_TRY(c, hipMemcpyAsync(R + (size_t)((i + 7) & 7) * rstride + n, &ones, 4, hipMemcpyHostToDevice, c->stream));
+    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));            // stack temporaries
+    if (hd.C[i] && n - hd.C[i]) {                               // :1214-1216
+      const Node root = {0u, hd.C[i], n - hd.C[i]};
+      BCE_HIP_TRY(c, hipMemcpyAsync(c->nodes.as<Node>() + (size_t)i * c->capP, &root, sizeof root, hipMemcpyHostToDevice, c->stream));
+      BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      ctl.cnt[0][i][0] = 1;
+    }
+  }
+  BCE_HIP_TRY(c, hipMemcpyAsync(c->ctl.p, &ctl, sizeof ctl, hipMemcpyHostToDevice, c->stream));
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  Pinned pin_info, pin_q, pin_res;
+  BCE_TRY(pin_info.ensure(c, sizeof(DecInfo)));
+  DecInfo *info = static_cast<DecInfo *>(pin_info.p);
+  memset(info, 0, sizeof *info);
+
+  DecArgs a;
+  a.ctl = c->ctl.as<DecCtl>();
+  a.info = info;                                                // pinned host memory is device-accessible at the same address
+  a.nodes = c->nodes.as<Node>();
+  a.R = R;
+  a.tilecnt = c->tilecnt.as<uint32_t>();
+  a.tileoff = c->tileoff.as<uint32_t>();
+  a.capP = c->capP; a.n = n;
+  for (int p = 0; p < 8; ++p) a.zeros[p] = hd.C[(p + 1) & 7];
+  {
+    PlaneCfg hcfg[8];
+    for (int p = 0; p < 8; ++p) hcfg[p] = hd.dec[p].cfg;
+    BCE_TRY(ensure(c, c->dcfg, sizeof hcfg));
+    BCE_HIP_TRY(c, hipMemcpy(c->dcfg.p, hcfg, sizeof hcfg, hipMemcpyHostToDevice));
+    a.cfg = c->dcfg.as<PlaneCfg>();
+  }
+  DevBuf &Qbuf = c->skey[0], &Rsbuf = c->sesc;                  // queries / answers of a round (device side)
+  QueryPool pool;
+  pool.dec = &hd.dec;
+  pool.start();
+
+  if (timing) { fprintf(stderr, "gpu decode: setup %.3f s\n", now_s() - tp0); tp0 = now_s(); }
+  // ---- the rounds (BCE::code mode 0, :1246-1371) ----
+  uint64_t cur_nodes = 0;
+  for (int i = 0; i < 8; ++i) cur_nodes += ctl.cnt[0][i][0];
+  uint32_t round = 0;
+  uint64_t nodes_total = 0, queries_total = 0;
+  double t_q = 0, t_copy = 0, t_host = 0, t_c = 0;
+  while (cur_nodes) {
+    double t0 = now_s();
+    a.par = round & 1u;
+    BCE_TRY(ensure(c, Qbuf, (size_t)(cur_nodes + 16) * sizeof(uint4)));
+    BCE_TRY(ensure(c, Rsbuf, (size_t)(cur_nodes + 16) * 4));
+    a.Q = Qbuf.as<uint4>();
+    a.res = Rsbuf.as<uint32_t>();
+    uint64_t want = (cur_nodes + K3_TILE - 1) / K3_TILE + 8;
+    const uint32_t grid = (uint32_t)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL((dec_tiles_kernel<0>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+    hipLaunchKernelGGL((dec_scan_kernel<true>), dim3(8), dim3(1024), 0, c->stream, a);
+    hipLaunchKernelGGL((dec_tiles_kernel<1>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    BCE_HIP_TRY(c, hipGetLastError());
+    const DecInfo in = *info;
+    { const double t1 = now_s(); t_q += t1 - t0; t0 = t1; }
+    if (in.err) { snprintf(c->err, sizeof c->err, "decode: inconsistent archive (round %u)", round); return BCE_HIP_E_INTERNAL; }
+    uint64_t qtotal = 0;
+    for (int p = 0; p < 8; ++p) qtotal += in.qtot[p];
+    if (qtotal) {
+      BCE_TRY(pin_q.ensure(c, qtotal * sizeof(uint4)));
+      BCE_TRY(pin_res.ensure(c, qtotal * 4));
+      BCE_HIP_TRY(c, hipMemcpyAsync(pin_q.p, a.Q, qtotal * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
+      BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      { const double t1 = now_s(); t_copy += t1 - t0; t0 = t1; }
+      pool.Q = static_cast<const uint4 *>(pin_q.p);
+      pool.res = static_cast<uint32_t *>(pin_res.p);
+      pool.run(in);
+      { const double t1 = now_s(); t_host += t1 - t0; t0 = t1; }
+      BCE_HIP_TRY(c, hipMemcpyAsync(Rsbuf.p, pin_res.p, qtotal * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    hipLaunchKernelGGL((dec_tiles_kernel<2>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+    hipLaunchKernelGGL((dec_scan_kernel<false>), dim3(8), dim3(1024), 0, c->stream, a);
+    hipLaunchKernelGGL((dec_tiles_kernel<3>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+    // the next round's size: read the control block (the query pass of the next round would tell, but its grid needs it)
+    BCE_HIP_TRY(c, hipMemcpyAsync(&ctl, c->ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
+    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    BCE_HIP_TRY(c, hipGetLastError());
+    if (ctl.err) {
+      snprintf(c->err, sizeof c->err, ctl.err == 2 ? "decode: node list overflow (capP=%u)" : "decode: inconsistent archive (round %u)",
+               ctl.err == 2 ? c->capP : round);
+      return ctl.err == 2 ? BCE_HIP_E_OVERFLOW : BCE_HIP_E_INTERNAL;
+    }
+    t_c += now_s() - t0;
+    cur_nodes = ctl.next_nodes;
+    nodes_total = ctl.nodes_total;
+    queries_total += qtotal;
+    ++round;
+  }
+  if (timing) { fprintf(stderr, "gpu decode: %u rounds, %llu nodes, %llu queries: %.3f s (query pass %.3f, copy out %.3f, host decoders %.3f, children pass %.3f)\n",
+                        round, (unsigned long long)nodes_total, (unsigned long long)queries_total, now_s() - tp0, t_q, t_copy, t_host, t_c); tp0 = now_s(); }
+
+  // ---- R -> planes -> granules -> BWT bytes ----
+  FillArgs f;
+  f.R = R; f.n = n;
+  f.chunks = (uint32_t)(((uint64_t)n + 1 + FG_CHUNK - 1) / FG_CHUNK);
+  f.nwords = (uint32_t)(((uint64_t)n + 31) / 32) + 3;
+  const uint32_t ngran = (uint32_t)((uint64_t)n / 96) + 2;
+  BCE_TRY(ensure(c, c->blk, (size_t)8 * f.chunks * 4 + 64));
+  f.cmax = c->blk.as<uint32_t>();
+  f.err = f.cmax + (size_t)8 * f.chunks;
+  BCE_TRY(ensure(c, c->sa[0], 8 * rstride));                   // gap types
+  f.type = c->sa[0].as<uint8_t>();
+  BCE_TRY(ensure(c, c->key[0], (size_t)8 * f.nwords * 4));
+  BCE_TRY(ensure(c, c->key[1], (size_t)8 * f.nwords * 4));
+  f.words = c->key[0].as<uint32_t>();
+  f.rankw = c->key[1].as<uint32_t>();
+  BCE_TRY(ensure(c, c->gran, (size_t)8 * ngran * sizeof(Granule)));
+  BCE_HIP_TRY(c, hipMemsetAsync(f.err, 0, 4, c->stream));
+  BCE_HIP_TRY(c, hipMemsetAsync(f.words, 0, (size_t)8 * f.nwords * 4, c->stream));
+  BCE_HIP_TRY(c, hipMemsetAsync(f.rankw, 0, (size_t)8 * f.nwords * 4, c->stream));
+  hipLaunchKernelGGL(fill_chunkmax_kernel, dim3(f.chunks, 8), dim3(FG_T), 0, c->stream, f);
+  hipLaunchKernelGGL(fill_chunkscan_kernel, dim3(8), dim3(1024), 0, c->stream, f);
+  hipLaunchKernelGGL((fill_kernel<0>), dim3(f.chunks, 8), dim3(FG_T), 0, c->stream, f);
+  hipLaunchKernelGGL((fill_kernel<1>), dim3(f.chunks, 8), dim3(FG_T), 0, c->stream, f);
+  {
+    uint32_t gb = (ngran + 255) / 256;
+    hipLaunchKernelGGL(gran_from_words_kernel, dim3(gb < 4096 ? gb : 4096, 8), dim3(256), 0, c->stream, f, c->gran.as<Granule>(), ngran);
+  }
+  uint32_t ferr = 0;
+  BCE_HIP_TRY(c, hipMemcpyAsync(&ferr, f.err, 4, hipMemcpyDeviceToHost, c->stream));
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  BCE_HIP_TRY(c, hipGetLastError());
+  if (ferr) { snprintf(c->err, sizeof c->err, "decode: a mixed gap was never split"); return BCE_HIP_E_INTERNAL; }
+  BCE_TRY(ensure(c, c->bwt, n));
+  BCE_TRY(ensure(c, c->text, n));
+  BCE_TRY(ensure(c, c->stat, 64));
+  uint32_t *dz = c->stat.as<uint32_t>();
+  BCE_HIP_TRY(c, hipMemcpyAsync(dz, a.zeros, 32, hipMemcpyHostToDevice, c->stream));
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const uint32_t gn = (uint32_t)((((uint64_t)n + 255) / 256) < 8192 ? (((uint64_t)n + 255) / 256) : 8192);
+  hipLaunchKernelGGL(access_kernel, dim3(gn), dim3(256), 0, c->stream, c->gran.as<Granule>(), ngran, n, dz, c->bwt.as<uint8_t>());
+  if (timing) { BCE_HIP_TRY(c, hipStreamSynchronize(c->stream)); fprintf(stderr, "gpu decode: planes + unbwt %.3f s\n", now_s() - tp0); tp0 = now_s(); }
+
+  // ---- inverse BWT ----
+  const size_t b4 = (size_t)n * 4;
+  for (int i = 0; i < 2; ++i) { BCE_TRY(ensure(c, c->sa[i], b4)); BCE_TRY(ensure(c, c->key[i], b4)); }
+  BCE_TRY(ensure(c, c->rank, b4));
+  uint32_t *key[2] = {c->key[0].as<uint32_t>(), c->key[1].as<uint32_t>()};
+  uint32_t *val[2] = {c->sa[0].as<uint32_t>(), c->sa[1].as<uint32_t>()};
+  uint32_t *lf = c->rank.as<uint32_t>();
+  hipLaunchKernelGGL(lf_keys_kernel, dim3(gn), dim3(256), 0, c->stream, c->bwt.as<uint8_t>(), n, key[0], val[0]);
+  int res = 0;
+  BCE_TRY(radix_sort_pairs(c, key, val, n, 0, 8, &res, 8));
+  hipLaunchKernelGGL(lf_scatter_kernel, dim3(gn), dim3(256), 0, c->stream, val[res], n, lf);
+  uint32_t sh = 0;
+  while (((uint64_t)n >> sh) > (1u << 19)) ++sh;                // at most 2^19 walkers
+  const uint32_t m = (uint32_t)((((uint64_t)n - 1) >> sh) + 1);
+  BCE_TRY(ensure(c, c->key[0], (size_t)3 * m * 4 + 16));         // the sort's key buffers are free again
+  uint32_t *d_len = c->key[0].as<uint32_t>(), *d_end = d_len + m, *d_dest = d_len + 2 * (size_t)m;
+  hipLaunchKernelGGL(walk_len_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, lf, m, sh, d_len, d_end);
+  std::vector<uint32_t> h_len(m), h_end(m), h_dest(m, 0);
+  BCE_HIP_TRY(c, hipMemcpyAsync(h_len.data(), d_len, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+  BCE_HIP_TRY(c, hipMemcpyAsync(h_end.data(), d_end, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  BCE_HIP_TRY(c, hipGetLastError());
+  // chain the segments from row 0 (= the last text position): one cycle through all of them, or the input is periodic
+  bool single_cycle = true;
+  {
+    uint64_t pos = n;
+    uint32_t cur = 0, seen = 0;
+    std::vector<uint8_t> visited(m, 0);
+    while (pos > 0) {
+      const uint32_t j = cur >> sh;
+      if (visited[j] || h_len[j] > pos) { single_cycle = false; break; }
+      visited[j] = 1; ++seen;
+      h_dest[j] = (uint32_t)pos;
+      pos -= h_len[j];
+      cur = h_end[j];
+    }
+    if (single_cycle && (seen != m || cur != 0)) single_cycle = false;
+  }
+  const uint32_t off = hd.offset % n;
+  if (single_cycle) {
+    BCE_HIP_TRY(c, hipMemcpyAsync(d_dest, h_dest.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(walk_write_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, lf, c->bwt.as<uint8_t>(), m, sh, d_len, d_dest,
+                       n, off, c->text.as<uint8_t>());
+    BCE_HIP_TRY(c, hipMemcpyAsync(out, c->text.p, n, hipMemcpyDeviceToHost, c->stream));
+    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    BCE_HIP_TRY(c, hipGetLastError());
+  } else {
+    // periodic input: the LF mapping has several cycles; the reference's walk from row 0 goes round one of them
+    // n steps (decoder.cpp does the same) -- sequential, on the host
+    std::vector<uint8_t> bwt(n);
+    std::vector<uint32_t> hlf(n);
+    BCE_HIP_TRY(c, hipMemcpy(bwt.data(), c->bwt.p, n, hipMemcpyDeviceToHost));
+    BCE_HIP_TRY(c, hipMemcpy(hlf.data(), lf, b4, hipMemcpyDeviceToHost));
+    uint32_t row = 0;
+    for (uint32_t i = n; i-- > 0;) {
+      uint64_t o = (uint64_t)i + off;
+      if (o >= n) o -= n;
+      out[o] = bwt[row];
+      row = hlf[row];
+    }
+  }
+  if (timing) fprintf(stderr, "gpu decode: inverse BWT (%s, %u walkers) %.3f s\n", single_cycle ? "gpu" : "host walk", m, now_s() - tp0);
+  return BCE_HIP_OK;
+}

@@ -115,6 +115,11 @@ int bce_hip_scan(bce_hip_ctx *ctx, uint8_t config288[BCE_HIP_CONFIG_BYTES], doub
 /* BCE::decode + unbwt::bytewise + inverse BWT + rotate (bce.cpp:1169-1233, 1043-1102): archive -> original bytes.
  * out == NULL: only report the decoded size in *out_len.  Needs no context and no GPU. */
 int bce_hip_decompress(const uint8_t *archive, size_t len, uint8_t *out, size_t cap, size_t *out_len);
+/* Same result with the GPU doing everything but the eight sequential range decoders + adaptive models (kd_decode.hip):
+ * node classification, children and boundary ranks per round on the device, the decoders' answers on 8 host threads,
+ * then plane fill, unbwt::bytewise as wavelet-matrix access and the inverse BWT on the device.  Uses the context's
+ * device, stream and scratch buffers; a compression in progress in the same context is dropped. */
+int bce_hip_decompress_device(bce_hip_ctx *ctx, const uint8_t *archive, size_t len, uint8_t *out, size_t cap, size_t *out_len);
 
 /* ---- statistics of the last bce_hip_encode / bce_hip_compress ------------------------------------ */
 typedef struct bce_hip_stats {

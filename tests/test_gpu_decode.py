@@ -1,0 +1,75 @@
+"""GPU: the GPU-assisted decoder (kd_decode.hip) -- decode(reference archive) == input.
+
+Archives come from the oracle (the reference's `-c`), so this is parity with the reference's `-d` on the reference's
+own output; the host decoder (decoder.cpp, CPU-tested against the same archives) must agree byte for byte."""
+import numpy as np
+import pytest
+
+import bce_amd
+import oracle
+from conftest import edge_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    rs = np.random.RandomState(5)
+    cases = list(edge_inputs())
+    cases += [
+        ("text-300k", oracle.synth_text(3, 300000)),
+        ("rand-100k", oracle.synth_rand(4, 100000)),
+        ("text-2M", oracle.synth_text(1, 2 << 20)),
+        ("binary-low-planes", (rs.randint(0, 4, 70000).astype(np.uint8) << 3).tobytes()),
+        ("runs", np.repeat(rs.randint(0, 256, 3000).astype(np.uint8), rs.randint(1, 60, 3000)).tobytes()),
+        ("repeat-20k", oracle.synth_text(8, 150000) + oracle.synth_text(8, 150000)[40000:60000] + b"#"),
+    ]
+    return cases
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize("name,data", CASES, ids=[c[0] for c in CASES])
+def test_gpu_decoder_inverts_reference_archives(name, data):
+    data = bytes(data)
+    arch = oracle.compress(data)
+    assert bce_amd.decompress_device(arch) == data
+    if len(data) <= 400000:
+        assert bce_amd.decompress(arch) == data          # the host decoder agrees
+
+
+def test_periodic_inputs_take_the_host_walk():
+    """Several LF cycles (the reference's decoder returns zeros here): the walk from row 0 goes round
+    one cycle n times; decoder.cpp and the GPU path fall back to the same sequential walk."""
+    for data in (b"ab" * 500, b"abcabcabd" * 3000, oracle.synth_text(2, 5000) * 7):
+        arch = oracle.compress(data)
+        assert bce_amd.decompress_device(arch) == data
+
+
+def test_custom_config_archives_decode():
+    data = oracle.synth_text(12, 200000)
+    cfg, _ = oracle.scan(data)
+    arch = oracle.compress(data, bytes(cfg))
+    assert bce_amd.decompress_device(arch) == data
+
+
+def test_one_context_many_archives_and_roundtrip_with_the_gpu_encoder():
+    ctx = bce_amd.api._Ctx(0)
+    try:
+        for seed, n in ((1, 50000), (2, 700000), (3, 1000), (4, 1 << 20)):
+            data = oracle.synth_text(seed, n)
+            arch = bce_amd.compress(data)
+            assert bce_amd.decompress_device(arch, ctx=ctx) == data
+    finally:
+        ctx.close()
+
+
+def test_corrupt_archive_is_rejected_or_differs():
+    data = oracle.synth_text(5, 100000)
+    arch = bytearray(oracle.compress(data))
+    arch[len(arch) // 2] ^= 0x55
+    try:
+        out = bce_amd.decompress_device(bytes(arch))
+    except bce_amd.BceError:
+        return
+    assert out != data
