@@ -39,8 +39,9 @@ namespace {
 
 struct DecCtl {
   uint32_t cnt[2][8][2];     // [parity][plane][seg] node counts, as EnumCtl
-  uint32_t ptot[8][3];       // per plane totals of the scan in flight: child0, child1, queries
+  uint32_t ptot[8][4];       // per plane totals of the scan in flight: child0, child1, queries, escape queries
   uint32_t qbase[8];         // first query of each plane in this round's query buffer
+  uint32_t ebase[8];         // first escape record (k > 31) of each plane
   uint32_t ticket, err;      // err: 1 inconsistent archive, 2 node list overflow
   uint32_t next_nodes, pad;
   uint64_t nodes_total;
@@ -48,17 +49,21 @@ struct DecCtl {
 
 struct DecInfo {             // what the host needs after the query pass (pinned host memory)
   uint32_t qbase[8], qtot[8];
+  uint32_t ebase[8], etot[8];
   uint32_t cur_nodes, err;
   uint64_t nodes_total;
 };
+
+constexpr uint32_t kEscape = 0x80000000u;
 
 struct DecArgs {
   DecCtl *ctl;
   DecInfo *info;             // device pointer of the pinned DecInfo
   Node *nodes;               // [2][8][capP]
   uint32_t *R;               // [8][n + 1] boundary ranks, kUnknown where not learnt yet
-  uint32_t *tilecnt, *tileoff;   // [tiles][4]: 0 child0, 1 child1, 2 queries
-  uint4 *Q;                  // queries of the round: (k, ctx, 0, 0) with the context resolved, or (k, c1, c2, cs) for k > 31
+  uint32_t *tilecnt, *tileoff;   // [tiles][4]: 0 child0, 1 child1, 2 queries, 3 escape queries
+  uint32_t *Q;               // queries of the round: k | ctx << 5 with the context resolved (k <= 31), or kEscape
+  uint4 *E;                  // escape queries (k > 31) in the same order: (k, c1, c2, cs)
   const PlaneCfg *cfg;       // [8] the archive's context-bit tables (the preamble of each stream)
   const uint32_t *res;       // answers, same indexing
   uint32_t capP, n, par;
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(K3_T) void dec_tiles_kernel(DecArgs a) {
     const uint32_t zi = a.zeros[p];
     Node nd[K3_NPT];
     DCls cl[K3_NPT];
-    uint32_t valid[K3_NPT], isq[K3_NPT], zero[K3_NPT];
+    uint32_t valid[K3_NPT], isq[K3_NPT], ise[K3_NPT], zero[K3_NPT];
     uint32_t bad = 0;
 #pragma unroll
     for (int it = 0; it < K3_NPT; ++it) {
@@ -191,17 +196,19 @@ __global__ __launch_bounds__(K3_T) void dec_tiles_kernel(DecArgs a) {
       cl[it] = dec_classify(nd[it], R, a.n);
       bad |= cl[it].bad & valid[it];
       isq[it] = (valid[it] && cl[it].kind == 3u) ? 1u : 0u;
+      ise[it] = (isq[it] && cl[it].mx - cl[it].mn + 1u > (uint32_t)kMaxK) ? 1u : 0u;
       zero[it] = 0;
     }
-    uint32_t qr[K3_NPT], d1[K3_NPT], d2[K3_NPT], tot[3];
-    tile_ranks(isq, zero, zero, lds_cnt, qr, d1, d2, tot);
+    uint32_t qr[K3_NPT], er[K3_NPT], d2[K3_NPT], tot[3];
+    tile_ranks(isq, ise, zero, lds_cnt, qr, er, d2, tot);
     if (bad) a.ctl->err = 1;
     if (MODE == 0) {
-      if (tid == 0) a.tilecnt[(size_t)tile * 4 + 2] = tot[0];
+      if (tid == 0) { a.tilecnt[(size_t)tile * 4 + 2] = tot[0]; a.tilecnt[(size_t)tile * 4 + 3] = tot[1]; }
       continue;
     }
     const uint32_t qb = a.ctl->qbase[p] + a.tileoff[(size_t)tile * 4 + 2];
     if (MODE == 1) {
+      const uint32_t eb = a.ctl->ebase[p] + a.tileoff[(size_t)tile * 4 + 3];
 #pragma unroll
       for (int it = 0; it < K3_NPT; ++it)
         if (isq[it]) {
@@ -210,9 +217,10 @@ __global__ __launch_bounds__(K3_T) void dec_tiles_kernel(DecArgs a) {
           if (k <= (uint32_t)kMaxK) {
             const uint32_t b = a.cfg[p].bits[k];
             const uint32_t ctxv = (small_quotient((uint32_t)(c1 << b), x) << b) | small_quotient((uint32_t)(c2 << b), x);
-            a.Q[qb + qr[it]] = make_uint4(k, ctxv, 0u, 0u);
+            a.Q[qb + qr[it]] = k | (ctxv << 5);
           } else {
-            a.Q[qb + qr[it]] = make_uint4(k, c1, c2, x);
+            a.Q[qb + qr[it]] = kEscape;
+            a.E[eb + er[it]] = make_uint4(k, c1, c2, x);
           }
         }
       continue;
@@ -263,11 +271,14 @@ __global__ __launch_bounds__(1024) void dec_scan_kernel(DecArgs a) {
       const uint32_t t = base + tid;
       const bool valid = t < tp[p + 1];
       if (QUERY) {
-        const uint32_t v = valid ? a.tilecnt[(size_t)t * 4 + 2] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan_sum<1024>(v, &tot);
-        if (valid) a.tileoff[(size_t)t * 4 + 2] = r0 + ex;
-        r0 += tot;
+        const uint32_t v2 = valid ? a.tilecnt[(size_t)t * 4 + 2] : 0u, v3 = valid ? a.tilecnt[(size_t)t * 4 + 3] : 0u;
+        uint64_t tot;
+        const uint64_t ex = block_excl_scan_sum64<1024>((uint64_t)v2 | ((uint64_t)v3 << 32), &tot);
+        if (valid) {
+          a.tileoff[(size_t)t * 4 + 2] = r0 + (uint32_t)ex;
+          a.tileoff[(size_t)t * 4 + 3] = r1 + (uint32_t)(ex >> 32);
+        }
+        r0 += (uint32_t)tot; r1 += (uint32_t)(tot >> 32);
       } else {
         const uint32_t v0 = valid ? a.tilecnt[(size_t)t * 4 + 0] : 0u, v1 = valid ? a.tilecnt[(size_t)t * 4 + 1] : 0u;
         uint64_t tot;
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(1024) void dec_scan_kernel(DecArgs a) {
     }
   }
   if (tid == 0) {
-    if (QUERY) ctl->ptot[p][2] = r0; else { ctl->ptot[p][0] = r0; ctl->ptot[p][1] = r1; }
+    if (QUERY) { ctl->ptot[p][2] = r0; ctl->ptot[p][3] = r1; } else { ctl->ptot[p][0] = r0; ctl->ptot[p][1] = r1; }
     __threadfence();
     s_last = atomicAdd(&ctl->ticket, 1u) == 7u ? 1u : 0u;
   }
@@ -289,16 +300,20 @@ __global__ __launch_bounds__(1024) void dec_scan_kernel(DecArgs a) {
   if (!s_last || tid != 0) return;
   __threadfence();
   ctl->ticket = 0;
-  const volatile uint32_t (*pt)[3] = ctl->ptot;
+  const volatile uint32_t (*pt)[4] = ctl->ptot;
   uint64_t curn = 0;
   for (int q = 0; q < 8; ++q) curn += (uint64_t)ctl->cnt[a.par][q][0] + ctl->cnt[a.par][q][1];
   if (QUERY) {
-    uint32_t acc = 0;
+    uint32_t acc = 0, eacc = 0;
     for (int q = 0; q < 8; ++q) {
       ctl->qbase[q] = acc;
+      ctl->ebase[q] = eacc;
       a.info->qbase[q] = acc;
       a.info->qtot[q] = pt[q][2];
+      a.info->ebase[q] = eacc;
+      a.info->etot[q] = pt[q][3];
       acc += pt[q][2];
+      eacc += pt[q][3];
     }
     a.info->cur_nodes = (uint32_t)curn;
     a.info->nodes_total = ctl->nodes_total;
@@ -317,6 +332,148 @@ __global__ __launch_bounds__(1024) void dec_scan_kernel(DecArgs a) {
     if (ovf && !ctl->err) ctl->err = 2;
     ctl->nodes_total += curn;
     ctl->next_nodes = (uint32_t)nextn;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Deep tails.  A long repeat is a chain of forced nodes (all zeros / all ones / forced split): thousands to
+// millions of rounds in which no decoder is asked anything.  One persistent workgroup keeps the lists in LDS and
+// runs those rounds on the device (classify from R, children, the new ranks), and stops IN FRONT of the first
+// round that holds a query, does not fit, or is empty; the host then runs that round the normal way.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DT_T = 256;
+constexpr int DT_NPT = 4;
+constexpr uint32_t DT_CAP = DT_T * DT_NPT;      // nodes of all planes together
+constexpr uint32_t DT_ENTER = 512;              // the host tries the tail kernel at or below this many nodes
+
+__global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_rounds, uint32_t *rounds_done) {
+  __shared__ Node buf[2][DT_CAP];
+  __shared__ uint32_t cnt[2][8][2];
+  __shared__ uint32_t off[9], noff[9];
+  __shared__ uint64_t ws[DT_T / 64];
+  __shared__ uint64_t pstart[9];
+  DecCtl *ctl = a.ctl;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+  uint32_t par = a.par, cur = 0, executed = 0;
+  if (tid < 16) cnt[par][tid >> 1][tid & 1] = ctl->cnt[par][tid >> 1][tid & 1];
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t acc = 0;
+    for (int p = 0; p < 8; ++p) { off[p] = acc; acc += cnt[par][p][0] + cnt[par][p][1]; }
+    off[8] = acc;
+  }
+  __syncthreads();
+  uint32_t total = off[8];
+  if (total > DT_CAP || total == 0 || ctl->err) { if (tid == 0) *rounds_done = 0; return; }
+  for (uint32_t q = tid; q < total; q += DT_T) {
+    uint32_t p = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) p += (q >= off[k]) ? 1u : 0u;
+    const uint32_t i = q - off[p], c0 = cnt[par][p][0];
+    buf[0][q] = dec_nodes(a, par, p)[i < c0 ? i : (a.capP - 1u - (i - c0))];
+  }
+  uint64_t nodes_total = ctl->nodes_total;
+  uint32_t err = 0;
+  __syncthreads();
+  for (;;) {
+    if (total == 0 || executed >= max_rounds) break;
+    Node nd[DT_NPT];
+    DCls cl[DT_NPT];
+    uint32_t pl[DT_NPT];
+    bool valid[DT_NPT];
+    int stop = 0;
+#pragma unroll
+    for (int it = 0; it < DT_NPT; ++it) {
+      const uint32_t q = tid * DT_NPT + (uint32_t)it;
+      valid[it] = q < total;
+      nd[it] = valid[it] ? buf[cur][q] : Node{0u, 1u, 1u};
+      uint32_t p = 0;
+#pragma unroll
+      for (int k = 1; k < 8; ++k) p += (q >= off[k]) ? 1u : 0u;
+      pl[it] = valid[it] ? p : 0u;
+      cl[it] = dec_classify(nd[it], a.R + (size_t)pl[it] * ((size_t)a.n + 1), a.n);
+      if (valid[it] && (cl[it].kind == 3u || cl[it].bad)) stop = 1;
+    }
+    if (__syncthreads_or(stop)) break;                       // a query (or an error): this round is the host's
+    uint32_t has0[DT_NPT], has1[DT_NPT], rval[DT_NPT];
+    Node c0[DT_NPT], c1[DT_NPT];
+    uint64_t mine = 0;
+#pragma unroll
+    for (int it = 0; it < DT_NPT; ++it) {
+      rval[it] = dec_children(nd[it], cl[it], cl[it].mn, a.zeros[pl[it]], has0[it], c0[it], has1[it], c1[it]);
+      if (!valid[it]) has0[it] = has1[it] = 0;
+      mine += (uint64_t)has0[it] | ((uint64_t)has1[it] << 32);
+    }
+    // block exclusive scan of (child0 | child1 << 32) in list order
+    uint64_t inc = wave_incl_sum64(mine);
+    if (lane == 63) ws[wid] = inc;
+    __syncthreads();
+    uint64_t wbase = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < DT_T / 64; ++i) { const uint64_t t = ws[i]; if ((uint32_t)i < wid) wbase += t; tot += t; }
+    const uint64_t ex = wbase + inc - mine;
+    if (tid < 9) pstart[tid] = tot;
+    __syncthreads();
+    {
+      uint64_t run = ex;
+#pragma unroll
+      for (int it = 0; it < DT_NPT; ++it) {
+        const uint32_t q = tid * DT_NPT + (uint32_t)it;
+        if (valid[it] && q == off[pl[it]]) pstart[pl[it]] = run;
+        run += (uint64_t)has0[it] | ((uint64_t)has1[it] << 32);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int p = 7; p >= 0; --p) if (off[p] == off[p + 1]) pstart[p] = pstart[p + 1];
+      uint32_t acc = 0;
+      for (int pn = 0; pn < 8; ++pn) {
+        const int p = (pn + 7) & 7;
+        const uint64_t d = pstart[p + 1] - pstart[p];
+        cnt[par ^ 1u][pn][0] = (uint32_t)d;
+        cnt[par ^ 1u][pn][1] = (uint32_t)(d >> 32);
+        noff[pn] = acc;
+        acc += (uint32_t)d + (uint32_t)(d >> 32);
+      }
+      noff[8] = acc;
+    }
+    __syncthreads();
+    if (noff[8] > DT_CAP) break;                            // nothing of this round has been written yet
+    {
+      uint64_t run = ex;
+#pragma unroll
+      for (int it = 0; it < DT_NPT; ++it) {
+        if (valid[it]) {
+          const uint32_t p = pl[it], pn = (p + 1u) & 7u;
+          const uint64_t rel = run - pstart[p];
+          if (has0[it]) buf[cur ^ 1u][noff[pn] + (uint32_t)rel] = c0[it];
+          if (has1[it]) buf[cur ^ 1u][noff[pn] + cnt[par ^ 1u][pn][0] + (uint32_t)(rel >> 32)] = c1[it];
+          (a.R + (size_t)p * ((size_t)a.n + 1))[nd[it].s + nd[it].x0] = rval[it];
+        }
+        run += (uint64_t)has0[it] | ((uint64_t)has1[it] << 32);
+      }
+    }
+    nodes_total += total;
+    __syncthreads();                                         // also orders the R stores before the next round's loads
+    if (tid < 9) off[tid] = noff[tid];
+    __syncthreads();
+    total = off[8];
+    par ^= 1u; cur ^= 1u; ++executed;
+  }
+  (void)err;
+  __syncthreads();
+  for (uint32_t q = tid; q < total; q += DT_T) {
+    uint32_t p = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) p += (q >= off[k]) ? 1u : 0u;
+    const uint32_t i = q - off[p], c0 = cnt[par][p][0];
+    dec_nodes(a, par, p)[i < c0 ? i : (a.capP - 1u - (i - c0))] = buf[cur][q];
+  }
+  if (tid < 16) ctl->cnt[par][tid >> 1][tid & 1] = cnt[par][tid >> 1][tid & 1];
+  if (tid == 0) {
+    ctl->nodes_total = nodes_total;
+    ctl->next_nodes = total;
+    *rounds_done = executed;
   }
 }
 
@@ -505,7 +662,8 @@ __global__ void walk_write_kernel(const uint32_t *__restrict__ lf, const uint8_t
 // ---- the host's part of a round: the eight plane decoders answer their queries, in parallel ----
 struct QueryPool {
   std::vector<Decoder> *dec = nullptr;
-  const uint4 *Q = nullptr;
+  const uint32_t *Q = nullptr;
+  const uint4 *E = nullptr;
   uint32_t *res = nullptr;
   DecInfo info;
   std::thread th[8];
@@ -515,10 +673,11 @@ struct QueryPool {
   int pending = 0;
   bool stop = false;
 
-  static void answer(Decoder &d, const uint4 *q, uint32_t *r, uint32_t cnt) {
+  static void answer(Decoder &d, const uint32_t *q, const uint4 *e, uint32_t *r, uint32_t cnt) {
     for (uint32_t i = 0; i < cnt; ++i) {
-      if (i + 8 < cnt && !q[i + 8].w) d.prefetch_slot(q[i + 8].x, q[i + 8].y);     // the counters of a query soon to come
-      r[i] = q[i].w ? d.get_adaptive(q[i].x, q[i].y, q[i].z, q[i].w) : d.get_slot(q[i].x, q[i].y);
+      if (i + 8 < cnt && !(q[i + 8] & kEscape)) d.prefetch_slot(q[i + 8] & 31u, q[i + 8] >> 5);   // the counters of a query soon to come
+      if (q[i] & kEscape) { r[i] = d.get_adaptive(e->x, e->y, e->z, e->w); ++e; }
+      else r[i] = d.get_slot(q[i] & 31u, q[i] >> 5);
     }
   }
   void worker(int p) {
@@ -530,7 +689,7 @@ struct QueryPool {
         if (stop) return;
         seen = epoch;
       }
-      answer((*dec)[p], Q + info.qbase[p], res + info.qbase[p], info.qtot[p]);
+      answer((*dec)[p], Q + info.qbase[p], E + info.ebase[p], res + info.qbase[p], info.qtot[p]);
       {
         std::lock_guard<std::mutex> g(mu);
         if (--pending == 0) cv_done.notify_all();
@@ -543,7 +702,7 @@ struct QueryPool {
     uint64_t total = 0;
     for (int p = 0; p < 8; ++p) total += in.qtot[p];
     if (total < 2048) {                                          // not worth waking anybody
-      for (int p = 0; p < 8; ++p) answer((*dec)[p], Q + in.qbase[p], res + in.qbase[p], in.qtot[p]);
+      for (int p = 0; p < 8; ++p) answer((*dec)[p], Q + in.qbase[p], E + in.ebase[p], res + in.qbase[p], in.qtot[p]);
       return;
     }
     {
@@ -569,7 +728,8 @@ struct Pinned {
     if (bytes <= cap) return BCE_HIP_OK;
     if (p) (void)hipHostFree(p);
     p = nullptr; cap = 0;
-    const size_t want = bytes + bytes / 2;
+    size_t want = 2 * cap > bytes ? 2 * cap : bytes;          // pinning is slow: grow geometrically
+    if (want < ((size_t)16 << 20)) want = (size_t)16 << 20;
     BCE_HIP_TRY(c, hipHostMalloc(&p, want, hipHostMallocDefault));
     cap = want;
     return BCE_HIP_OK;
@@ -634,7 +794,7 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
   }
   BCE_HIP_TRY(c, hipMemcpyAsync(c->ctl.p, &ctl, sizeof ctl, hipMemcpyHostToDevice, c->stream));
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  Pinned pin_info, pin_q, pin_res;
+  Pinned pin_info, pin_q, pin_e, pin_res;
   BCE_TRY(pin_info.ensure(c, sizeof(DecInfo)));
   DecInfo *info = static_cast<DecInfo *>(pin_info.p);
   memset(info, 0, sizeof *info);
@@ -655,7 +815,7 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
     BCE_HIP_TRY(c, hipMemcpy(c->dcfg.p, hcfg, sizeof hcfg, hipMemcpyHostToDevice));
     a.cfg = c->dcfg.as<PlaneCfg>();
   }
-  DevBuf &Qbuf = c->skey[0], &Rsbuf = c->sesc;                  // queries / answers of a round (device side)
+  DevBuf &Qbuf = c->skey[0], &Ebuf = c->skey[1], &Rsbuf = c->sesc;   // queries / escape queries / answers of a round (device side)
   QueryPool pool;
   pool.dec = &hd.dec;
   pool.start();
@@ -667,12 +827,33 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
   uint32_t round = 0;
   uint64_t nodes_total = 0, queries_total = 0;
   double t_q = 0, t_copy = 0, t_host = 0, t_c = 0;
+  uint64_t tail_rounds = 0;
+  BCE_TRY(ensure(c, c->runs, 64));
+  uint32_t *d_rounds = c->runs.as<uint32_t>();
   while (cur_nodes) {
     double t0 = now_s();
     a.par = round & 1u;
-    BCE_TRY(ensure(c, Qbuf, (size_t)(cur_nodes + 16) * sizeof(uint4)));
+    if (cur_nodes <= DT_ENTER && !getenv("BCE_DEC_NO_TAIL")) {
+      // forced rounds on the device; stops in front of the first round that needs the decoders
+      uint32_t done = 0;
+      hipLaunchKernelGGL(dec_tail_kernel, dim3(1), dim3(DT_T), 0, c->stream, a, 1u << 30, d_rounds);
+      BCE_HIP_TRY(c, hipMemcpyAsync(&done, d_rounds, 4, hipMemcpyDeviceToHost, c->stream));
+      BCE_HIP_TRY(c, hipMemcpyAsync(&ctl, c->ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
+      BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      BCE_HIP_TRY(c, hipGetLastError());
+      if (done) {
+        round += done; tail_rounds += done;
+        cur_nodes = ctl.next_nodes;
+        nodes_total = ctl.nodes_total;
+        t_c += now_s() - t0;
+        continue;
+      }
+    }
+    BCE_TRY(ensure(c, Qbuf, (size_t)(cur_nodes + 16) * 4));
+    BCE_TRY(ensure(c, Ebuf, (size_t)(cur_nodes + 16) * sizeof(uint4)));
     BCE_TRY(ensure(c, Rsbuf, (size_t)(cur_nodes + 16) * 4));
-    a.Q = Qbuf.as<uint4>();
+    a.Q = Qbuf.as<uint32_t>();
+    a.E = Ebuf.as<uint4>();
     a.res = Rsbuf.as<uint32_t>();
     uint64_t want = (cur_nodes + K3_TILE - 1) / K3_TILE + 8;
     const uint32_t grid = (uint32_t)(want < 2048 ? want : 2048);
@@ -684,15 +865,18 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
     const DecInfo in = *info;
     { const double t1 = now_s(); t_q += t1 - t0; t0 = t1; }
     if (in.err) { snprintf(c->err, sizeof c->err, "decode: inconsistent archive (round %u)", round); return BCE_HIP_E_INTERNAL; }
-    uint64_t qtotal = 0;
-    for (int p = 0; p < 8; ++p) qtotal += in.qtot[p];
+    uint64_t qtotal = 0, etotal = 0;
+    for (int p = 0; p < 8; ++p) { qtotal += in.qtot[p]; etotal += in.etot[p]; }
     if (qtotal) {
-      BCE_TRY(pin_q.ensure(c, qtotal * sizeof(uint4)));
+      BCE_TRY(pin_q.ensure(c, qtotal * 4));
+      BCE_TRY(pin_e.ensure(c, (etotal + 1) * sizeof(uint4)));
       BCE_TRY(pin_res.ensure(c, qtotal * 4));
-      BCE_HIP_TRY(c, hipMemcpyAsync(pin_q.p, a.Q, qtotal * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
+      BCE_HIP_TRY(c, hipMemcpyAsync(pin_q.p, a.Q, qtotal * 4, hipMemcpyDeviceToHost, c->stream));
+      if (etotal) BCE_HIP_TRY(c, hipMemcpyAsync(pin_e.p, a.E, etotal * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
       BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
       { const double t1 = now_s(); t_copy += t1 - t0; t0 = t1; }
-      pool.Q = static_cast<const uint4 *>(pin_q.p);
+      pool.Q = static_cast<const uint32_t *>(pin_q.p);
+      pool.E = static_cast<const uint4 *>(pin_e.p);
       pool.res = static_cast<uint32_t *>(pin_res.p);
       pool.run(in);
       { const double t1 = now_s(); t_host += t1 - t0; t0 = t1; }
@@ -716,8 +900,8 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
     queries_total += qtotal;
     ++round;
   }
-  if (timing) { fprintf(stderr, "gpu decode: %u rounds, %llu nodes, %llu queries: %.3f s (query pass %.3f, copy out %.3f, host decoders %.3f, children pass %.3f)\n",
-                        round, (unsigned long long)nodes_total, (unsigned long long)queries_total, now_s() - tp0, t_q, t_copy, t_host, t_c); tp0 = now_s(); }
+  if (timing) { fprintf(stderr, "gpu decode: %u rounds (%llu of them in the tail kernel), %llu nodes, %llu queries: %.3f s (query pass %.3f, copy out %.3f, host decoders %.3f, children pass %.3f)\n",
+                        round, (unsigned long long)tail_rounds, (unsigned long long)nodes_total, (unsigned long long)queries_total, now_s() - tp0, t_q, t_copy, t_host, t_c); tp0 = now_s(); }
 
   // ---- R -> planes -> granules -> BWT bytes ----
   FillArgs f;

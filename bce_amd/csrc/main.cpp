@@ -1,7 +1,7 @@
 // main.cpp -- the `bce` command line, mirroring the reference's main() (bce.cpp:1376-1484):
 //   bce -c archive.bce file [config.bcc]    compress on the MI355X through libbcehip.so
 // Banner, usage text, summary line, argument detection and exit codes follow the reference
-// (banner :1377-1379, -c :1403-1427, -d :1428-1472, usage :1473-1483).  -d uses the host decoder (decoder.cpp);
+// (banner :1377-1379, -c :1403-1427, -d :1428-1472, usage :1473-1483).  -d uses the GPU-assisted decoder (kd_decode.hip), -ds the host decoder (decoder.cpp);
 // -s runs the enumeration on the GPU in scan mode and the ScanCoder optimisation on the host (scan_coder.cpp).
 #include <stdint.h>
 #include <stdio.h>
@@ -83,8 +83,7 @@ int main(int argc, char **argv) {
     bce_hip_destroy(ctx);
     return 0;
   } else if (argc == 4 && argv[1][0] == '-' && argv[1][1] == 'd') {
-    // Decompress (bce.cpp:1428-1472).  `-ds` selected the low-memory bitwise unbwt in the reference (:1466); the
-    // host decoder here has one inverse transform, so both spellings give the same output.
+    // Decompress (bce.cpp:1428-1472).
     auto start = std::chrono::high_resolution_clock::now();
     std::ifstream archive(std::string(argv[3]), std::ios::binary | std::ios::ate);
     std::streamoff size = archive ? (std::streamoff)archive.tellg() : -1;
@@ -92,10 +91,22 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> adata((size_t)size);
     archive.seekg(0, std::ios::beg);
     if (size == 0 || !archive.read(reinterpret_cast<char *>(adata.data()), size)) { printf("Could not read Archive.\n"); return -2; }
+    // -d: GPU-assisted decoder (kd_decode.hip); -ds (the reference's low-memory unbwt, :1466) and machines without a
+    // GPU: the host decoder (decoder.cpp).  Same output either way.
     size_t n = 0;
-    int rc = bce_hip_decompress(adata.data(), adata.size(), nullptr, 0, &n);
-    std::vector<uint8_t> out(n);
-    if (rc == 0) rc = bce_hip_decompress(adata.data(), adata.size(), out.data(), out.size(), &n);
+    int rc;
+    std::vector<uint8_t> out;
+    bce_hip_ctx *ctx = nullptr;
+    const bool want_gpu = argv[1][2] != 's';
+    if (want_gpu && bce_hip_create(&ctx, 0) == 0) {
+      rc = bce_hip_decompress_device(ctx, adata.data(), adata.size(), nullptr, 0, &n);
+      if (rc == 0) { out.resize(n); rc = bce_hip_decompress_device(ctx, adata.data(), adata.size(), out.data(), out.size(), &n); }
+      if (rc != 0) printf("%s\n", bce_hip_last_error(ctx));
+      bce_hip_destroy(ctx);
+    } else {
+      rc = bce_hip_decompress(adata.data(), adata.size(), nullptr, 0, &n);
+      if (rc == 0) { out.resize(n); rc = bce_hip_decompress(adata.data(), adata.size(), out.data(), out.size(), &n); }
+    }
     if (rc != 0) { printf("Decompression failed: %s\n", bce_hip_strerror(rc)); return -4; }
     auto end = std::chrono::high_resolution_clock::now();
     std::chrono::duration<double> duration = end - start;

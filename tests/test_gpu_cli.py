@@ -43,3 +43,19 @@ def test_cli_config_and_errors(tmp_path):
     (tmp_path / "empty").write_bytes(b"")
     r = subprocess.run([EXE, "-c", str(dst), str(tmp_path / "empty")], capture_output=True, text=True)
     assert r.returncode == 255 and "Error loading file" in r.stdout
+
+
+def test_cli_decompress_gpu_and_host_paths(tmp_path):
+    """`bce -d file archive` (GPU-assisted decoder) and `bce -ds` (host decoder) on a reference archive
+    (bce.cpp:1428-1472): same bytes, the reference's summary line and exit codes."""
+    data = oracle.synth_text(14, 400000) + oracle.synth_rand(14, 30000)
+    arc, out1, out2 = tmp_path / "a.bce", tmp_path / "o1", tmp_path / "o2"
+    arc.write_bytes(oracle.compress(data))
+    r = subprocess.run([EXE, "-d", str(out1), str(arc)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Decompressed from %d B -> %d B in " % (arc.stat().st_size, len(data)) in r.stdout
+    assert out1.read_bytes() == data
+    r = subprocess.run([EXE, "-ds", str(out2), str(arc)], capture_output=True, text=True)
+    assert r.returncode == 0 and out2.read_bytes() == data
+    r = subprocess.run([EXE, "-d", str(out1), str(tmp_path / "nope.bce")], capture_output=True, text=True)
+    assert r.returncode == 255 and "Archive not found." in r.stdout
