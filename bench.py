@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--file", default=os.environ.get("BCE_BENCH_FILE"))
     ap.add_argument("--cpu-sample", type=int, default=48 << 20, help="bytes of the workload the CPU baseline compresses")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the untimed decode-and-compare leg (N=1 only)")
     ap.add_argument("--scan-config", action="store_true",
                     help="BASELINE config 5: run `bce -s` on the input first (untimed), compress with the scanned table")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -178,6 +179,14 @@ def main():
             "breakdown_s": {k: round(st[k], 4) for k in ("t_load", "t_bwt", "t_planes", "t_enum", "t_model", "t_coder", "t_coder_busy")},
             "counts": {"nodes": st["nodes"], "symbols": st["symbols"], "rounds": st["rounds"], "sort_rounds": st["sort_rounds"], "flushes": st["flushes"]},
         }
+        if n_gpus == 1 and not args.no_decode and n <= 1_000_000_000:
+            # untimed: the archive of the last step through the GPU-assisted decoder (`bce -d`), compared with the input
+            t0 = time.perf_counter()
+            back = bce_amd.decompress_device(arch, ctx=ctx)
+            td = time.perf_counter() - t0
+            out["decode"] = {"value": round(n / td / 1e6, 3), "unit": "MB/s", "seconds": round(td, 3),
+                             "roundtrip_identical": bool(len(back) == n and hashlib.sha256(back).digest() == hashlib.sha256(data.tobytes()).digest()),
+                             "note": "bce_hip_decompress_device: GPU passes + 8 host range decoders; not part of `value`"}
         if n_gpus == 1 and not args.no_cpu:
             cb = cpu_baseline(data, min(args.cpu_sample, n))
             out["cpu_baseline"] = cb
