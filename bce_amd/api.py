@@ -47,6 +47,7 @@ SYMBOLS = [
     ("bce_hip_last_error", C.c_char_p, [C.c_void_p]),
     ("bce_hip_set_config", C.c_int, [C.c_void_p, _u8p]),
     ("bce_hip_set_symbol_capacity", C.c_int, [C.c_void_p, C.c_uint64]),
+    ("bce_hip_set_progress", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bce_hip_debug_set", C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     ("bce_hip_load_host", C.c_int, [C.c_void_p, _u8p, C.c_uint32]),
     ("bce_hip_load_device", C.c_int, [C.c_void_p, _vp, C.c_uint32]),

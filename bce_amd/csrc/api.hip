@@ -171,6 +171,13 @@ int bce_hip_debug_set(bce_hip_ctx *c, int knob, uint32_t value) {
   return BCE_HIP_OK;
 }
 
+int bce_hip_set_progress(bce_hip_ctx *c, bce_hip_progress_fn fn, void *user) {
+  if (!c) return BCE_HIP_E_ARG;
+  c->progress = fn;
+  c->progress_user = user;
+  return BCE_HIP_OK;
+}
+
 int bce_hip_set_symbol_capacity(bce_hip_ctx *c, uint64_t records) {
   if (!c || records >= (1ull << 31)) return BCE_HIP_E_ARG;
   c->sym_cap_user = records;
@@ -385,6 +392,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms; }
     if (ctl.overflow) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
     c->round = first + executed;
+    if (c->progress) c->progress(ctl.nodes_total, 8ull * n, c->progress_user);
     decaying = ctl.next_nodes <= cur_nodes && c->round > 16;   // past the ramp-up: the node count no longer doubles
     have_ctl = true;
     cur_nodes = ctl.next_nodes;
@@ -476,6 +484,7 @@ int bce_hip_scan(bce_hip_ctx *c, uint8_t config288[BCE_HIP_CONFIG_BYTES], double
     }
     if (ctl.overflow) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
     c->round = first + executed;
+    if (c->progress) c->progress(ctl.nodes_total, 8ull * n, c->progress_user);
     cur_nodes = ctl.next_nodes;
     if (ctl.need_flush) {
       if (ctl.sym_total == 0) {

@@ -897,6 +897,7 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
     t_c += now_s() - t0;
     cur_nodes = ctl.next_nodes;
     nodes_total = ctl.nodes_total;
+    if (c->progress) c->progress(nodes_total, 8ull * n, c->progress_user);
     queries_total += qtotal;
     ++round;
   }

@@ -14,6 +14,18 @@
 
 #include "../../include/bce_hip.h"
 
+// "Coded: %u.%02u %%\r" as BCE::code prints it (bce.cpp:1354-1358); cleared at the end like :1372
+static void progress(uint64_t done, uint64_t total, void *user) {
+  uint64_t *prev = static_cast<uint64_t *>(user);
+  const uint64_t cur = total ? done * 10000 / total : 0;
+  if (cur > *prev) {
+    printf("Coded: %llu.%02llu %%\r", (unsigned long long)(cur / 100), (unsigned long long)(cur % 100));
+    fflush(stdout);
+    *prev = cur;
+  }
+}
+static void progress_end() { printf("                    \r"); }
+
 static int usage() {
   printf("Usage:\n");
   printf("  bce -c archive.bce file [config.bcc]\n");
@@ -67,7 +79,10 @@ int main(int argc, char **argv) {
       return -1;
     }
     size_t alen = 0;
+    uint64_t prog = 0;
+    bce_hip_set_progress(ctx, progress, &prog);
     rc = bce_hip_compress(ctx, data.data(), (uint32_t)data.size(), nullptr, 0, &alen);
+    progress_end();
     if (rc != 0) {
       printf("Compression failed: %s (%s)\n", bce_hip_strerror(rc), bce_hip_last_error(ctx));
       bce_hip_destroy(ctx);
@@ -98,9 +113,12 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> out;
     bce_hip_ctx *ctx = nullptr;
     const bool want_gpu = argv[1][2] != 's';
+    uint64_t prog = 0;
     if (want_gpu && bce_hip_create(&ctx, 0) == 0) {
+      bce_hip_set_progress(ctx, progress, &prog);
       rc = bce_hip_decompress_device(ctx, adata.data(), adata.size(), nullptr, 0, &n);
       if (rc == 0) { out.resize(n); rc = bce_hip_decompress_device(ctx, adata.data(), adata.size(), out.data(), out.size(), &n); }
+      progress_end();
       if (rc != 0) printf("%s\n", bce_hip_last_error(ctx));
       bce_hip_destroy(ctx);
     } else {
@@ -135,7 +153,10 @@ int main(int argc, char **argv) {
     rc = bce_hip_load_host(ctx, data.data(), (uint32_t)data.size());
     if (rc == 0) rc = bce_hip_bwt(ctx, nullptr);
     if (rc == 0) rc = bce_hip_build_planes(ctx, nullptr);
+    uint64_t prog = 0;
+    bce_hip_set_progress(ctx, progress, &prog);
     if (rc == 0) rc = bce_hip_scan(ctx, cfg, res);
+    progress_end();
     if (rc != 0) { printf("Scan failed: %s (%s)\n", bce_hip_strerror(rc), bce_hip_last_error(ctx)); bce_hip_destroy(ctx); return -4; }
     for (int i = 0; i < 9; ++i) printf("Result size: %.1f B\n", res[i]);            // ScanCoder::flush, :799
     std::ofstream f(std::string(argv[2]), std::ios::binary | std::ios::trunc);     // save_config, :810-813

@@ -46,6 +46,12 @@ int bce_hip_set_config(bce_hip_ctx *ctx, const uint8_t *config288);
 /* capacity (in symbol records) of the device symbol buffer between model flushes; 0 = automatic */
 int bce_hip_set_symbol_capacity(bce_hip_ctx *ctx, uint64_t records);
 
+/* Progress of BCE::code (the reference prints "Coded: %u.%02u %%\r" from it, bce.cpp:1354-1358): called from the calling
+ * thread with the nodes visited so far and the total (8n) whenever the host looks at the enumeration's state, during
+ * bce_hip_encode / _compress / _scan / _decompress_device.  NULL switches it off (default). */
+typedef void (*bce_hip_progress_fn)(uint64_t nodes_done, uint64_t nodes_total, void *user);
+int bce_hip_set_progress(bce_hip_ctx *ctx, bce_hip_progress_fn fn, void *user);
+
 /* test knobs for the enumeration's alternative code paths (all 0 by default): 0 = nodes a depth-first walker
  * classifies per pass, 1 = disable the depth-first tail, 2 = disable the persistent LDS tail kernel, 3 = disable chain skipping, 4 = disable the one-launch kernel for narrow rounds.
  * The archive never depends on them. */
