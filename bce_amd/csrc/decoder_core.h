@@ -4,6 +4,9 @@
 // (bce.cpp:692-705).  Plain host C++.
 #pragma once
 #include <stdint.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <vector>
 
@@ -56,7 +59,7 @@ struct alignas(128) Decoder {
     uint32_t last = 0;
     for (int b = 0; b < 32; ++b) { const uint32_t bit = get(2) ? get(6) : last; bits[b] = (uint8_t)bit; last = bit; }
     plane_cfg_init(cfg, bits);
-    stat.assign(cfg.stat_bytes + 1, 0);
+    stat.assign(cfg.stat_bytes + 1 + 32, 0);                     // + slack: get_slot_avx2 loads 32 bytes at a slot
   }
   uint32_t get_adaptive(uint32_t k, uint32_t c1, uint32_t c2, uint32_t cs) {   // :555-590
     if (k > (uint32_t)kMaxK) {
@@ -83,6 +86,9 @@ struct alignas(128) Decoder {
       shift_in();
       return s;
     }
+#if defined(__x86_64__)
+    if (have_avx2) return get_slot_avx2(ctx, k);
+#endif
     uint32_t tot = k;
     for (uint32_t i = 0; i < k; ++i) tot += ctx[i];
     if (h - l < tot) { for (int i = 0; i < 4; ++i) m = (m << 16) + next(); l = 0; h = ~0ull; }
@@ -98,6 +104,52 @@ struct alignas(128) Decoder {
     shift_in();
     return s;
   }
+#if defined(__x86_64__)
+  // The same step for 3 <= k <= 31 without the two data-dependent loops: cum[i] = sum_{j<=i} (ctx[j] + 1) for all
+  // 32 lanes at once (16-bit prefix sums), then the symbol is the number of i < k with cum[i] < t, where
+  // t = floor((m - l) / step) + 1 (h_i = l - 1 + step cum[i] >= m  <=>  cum[i] >= t), capped at k - 1 as the loop is.
+  __attribute__((target("avx2"))) uint32_t get_slot_avx2(uint8_t *ctx, uint32_t k) {
+    alignas(32) static const int16_t iota[32] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                                 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31};
+    const __m256i kk = _mm256_set1_epi16((short)k);
+    const __m256i m_lo = _mm256_cmpgt_epi16(kk, _mm256_load_si256((const __m256i *)iota));         // lanes i < k
+    const __m256i m_hi = _mm256_cmpgt_epi16(kk, _mm256_load_si256((const __m256i *)(iota + 16)));
+    const __m256i raw = _mm256_loadu_si256((const __m256i *)ctx);                                   // stat has 32 bytes of slack
+    const __m256i one = _mm256_set1_epi16(1);
+    __m256i lo = _mm256_and_si256(_mm256_add_epi16(_mm256_cvtepu8_epi16(_mm256_castsi256_si128(raw)), one), m_lo);
+    __m256i hi = _mm256_and_si256(_mm256_add_epi16(_mm256_cvtepu8_epi16(_mm256_extracti128_si256(raw, 1)), one), m_hi);
+    // inclusive prefix sums of 16 x u16 per register: inside the 128-bit halves, then across them
+    lo = _mm256_add_epi16(lo, _mm256_slli_si256(lo, 2)); hi = _mm256_add_epi16(hi, _mm256_slli_si256(hi, 2));
+    lo = _mm256_add_epi16(lo, _mm256_slli_si256(lo, 4)); hi = _mm256_add_epi16(hi, _mm256_slli_si256(hi, 4));
+    lo = _mm256_add_epi16(lo, _mm256_slli_si256(lo, 8)); hi = _mm256_add_epi16(hi, _mm256_slli_si256(hi, 8));
+    const __m256i bsel = _mm256_set1_epi16(0x0F0E);                                                 // bytes 14,15 = element 7 of each half
+    __m256i carry = _mm256_shuffle_epi8(lo, bsel);                                                  // per half: its own total
+    lo = _mm256_add_epi16(lo, _mm256_permute2x128_si256(carry, carry, 0x08));                       // upper half += total of lower half
+    carry = _mm256_shuffle_epi8(hi, bsel);
+    hi = _mm256_add_epi16(hi, _mm256_permute2x128_si256(carry, carry, 0x08));
+    const __m256i lo_tot = _mm256_permute2x128_si256(_mm256_shuffle_epi8(lo, bsel), _mm256_setzero_si256(), 0x11);   // element 15 of lo, everywhere
+    hi = _mm256_add_epi16(hi, lo_tot);
+    alignas(32) uint16_t cum[32];
+    _mm256_store_si256((__m256i *)cum, lo);
+    _mm256_store_si256((__m256i *)(cum + 16), hi);
+    const uint32_t tot = cum[31];                                  // lanes >= k added nothing
+    if (h - l < tot) { for (int i = 0; i < 4; ++i) m = (m << 16) + next(); l = 0; h = ~0ull; }
+    const uint64_t step = div_small(h - l, tot, recip);
+    const uint64_t tq = (m - l) / step + 1;
+    const __m256i t16 = _mm256_set1_epi16((short)(tq > 16384 ? 16384 : tq));                        // cum <= 8192
+    const uint32_t lt_lo = (uint32_t)_mm256_movemask_epi8(_mm256_and_si256(_mm256_cmpgt_epi16(t16, lo), m_lo));
+    const uint32_t lt_hi = (uint32_t)_mm256_movemask_epi8(_mm256_and_si256(_mm256_cmpgt_epi16(t16, hi), m_hi));
+    uint32_t s = (uint32_t)(__builtin_popcount(lt_lo) + __builtin_popcount(lt_hi)) >> 1;             // two mask bits per lane
+    if (s > k - 1) s = k - 1;
+    const uint64_t l0 = l;
+    l = l0 + step * (s ? cum[s - 1] : 0u);
+    h = l0 - 1 + step * cum[s];
+    if (++ctx[s] == 0xFF) for (uint32_t i = 0; i < k; ++i) ctx[i] >>= 1;
+    shift_in();
+    return s;
+  }
+  bool have_avx2 = __builtin_cpu_supports("avx2") != 0;
+#endif
   void prefetch_slot(uint32_t k, uint32_t ctxv) const { __builtin_prefetch(stat.data() + cfg.off[k] + ctxv * k); }
   const Recip *recip = recip_table();
 };
