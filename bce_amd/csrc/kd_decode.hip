@@ -477,6 +477,96 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
   }
 }
 
+// The same for at most 64 nodes (the very deep tails: a handful of chains): ONE wave, one node per lane, the new
+// order from ballots instead of a block scan -- no workgroup barriers on the round's critical path.
+// rounds_done[1] says why it stopped: 1 query / inconsistent node, 2 more than 64 children, 0 nothing left / max.
+__global__ __launch_bounds__(64) void dec_tail64_kernel(DecArgs a, uint32_t max_rounds, uint32_t *rounds_done) {
+  __shared__ Node nbuf[64];
+  __shared__ uint32_t pbuf[64];
+  DecCtl *ctl = a.ctl;
+  const uint32_t lane = threadIdx.x;
+  const uint64_t below = (1ull << lane) - 1ull;
+  uint32_t par = a.par, executed = 0, why = 0;
+  uint32_t cnt[8][2], total = 0;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) { cnt[p][0] = ctl->cnt[par][p][0]; cnt[p][1] = ctl->cnt[par][p][1]; total += cnt[p][0] + cnt[p][1]; }
+  if (total > 64 || total == 0 || ctl->err) { if (lane == 0) { rounds_done[0] = 0; rounds_done[1] = total > 64 ? 2u : 0u; } return; }
+  Node nd{0u, 1u, 1u};
+  uint32_t pl = 0;
+  {
+    uint32_t acc = 0;
+#pragma unroll
+    for (uint32_t p = 0; p < 8; ++p) {
+      const uint32_t m = cnt[p][0] + cnt[p][1];
+      if (lane >= acc && lane < acc + m) {
+        const uint32_t i = lane - acc;
+        nd = dec_nodes(a, par, p)[i < cnt[p][0] ? i : (a.capP - 1u - (i - cnt[p][0]))];
+        pl = p;
+      }
+      acc += m;
+    }
+  }
+  uint64_t nodes_total = ctl->nodes_total;
+  for (;;) {
+    if (total == 0 || executed >= max_rounds) break;
+    const bool valid = lane < total;
+    const DCls cl = dec_classify(nd, a.R + (size_t)pl * ((size_t)a.n + 1), a.n);
+    if (__ballot(valid && (cl.kind == 3u || cl.bad))) { why = 1; break; }
+    uint32_t has0, has1;
+    Node c0, c1;
+    const uint32_t rval = dec_children(nd, cl, cl.mn, a.zeros[pl], has0, c0, has1, c1);
+    if (!valid) has0 = has1 = 0;
+    const uint64_t m0 = __ballot(has0), m1 = __ballot(has1);
+    if (__popcll(m0) + __popcll(m1) > 64) { why = 2; break; }
+    // next lists: plane pn takes the children of plane pn - 1: child0s in order, then child1s in order
+    uint32_t base = 0, my0 = 0, my1 = 0, ncnt[8][2];
+#pragma unroll
+    for (uint32_t pn = 0; pn < 8; ++pn) {
+      const uint32_t p = (pn + 7u) & 7u;
+      const uint64_t pm = __ballot(valid && pl == p);
+      const uint32_t t0 = (uint32_t)__popcll(m0 & pm), t1 = (uint32_t)__popcll(m1 & pm);
+      if (pl == p) {
+        my0 = base + (uint32_t)__popcll(m0 & pm & below);
+        my1 = base + t0 + (uint32_t)__popcll(m1 & pm & below);
+      }
+      ncnt[pn][0] = t0; ncnt[pn][1] = t1;
+      base += t0 + t1;
+    }
+    if (has0) { nbuf[my0] = c0; pbuf[my0] = (pl + 1u) & 7u; }
+    if (has1) { nbuf[my1] = c1; pbuf[my1] = (pl + 1u) & 7u; }
+    if (valid) (a.R + (size_t)pl * ((size_t)a.n + 1))[nd.s + nd.x0] = rval;
+    nodes_total += total;
+    __syncthreads();                                         // one wave: orders LDS and the R stores before the next loads
+    total = base;
+    nd = lane < total ? nbuf[lane] : Node{0u, 1u, 1u};
+    pl = lane < total ? pbuf[lane] : 0u;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) { cnt[p][0] = ncnt[p][0]; cnt[p][1] = ncnt[p][1]; }
+    __syncthreads();
+    par ^= 1u; ++executed;
+  }
+  // hand the state back
+  {
+    uint32_t acc = 0;
+#pragma unroll
+    for (uint32_t p = 0; p < 8; ++p) {
+      const uint32_t m = cnt[p][0] + cnt[p][1];
+      if (lane >= acc && lane < acc + m && lane < total) {
+        const uint32_t i = lane - acc;
+        dec_nodes(a, par, p)[i < cnt[p][0] ? i : (a.capP - 1u - (i - cnt[p][0]))] = nd;
+      }
+      acc += m;
+    }
+  }
+  if (lane < 16) ctl->cnt[par][lane >> 1][lane & 1] = cnt[lane >> 1][lane & 1];
+  if (lane == 0) {
+    ctl->nodes_total = nodes_total;
+    ctl->next_nodes = total;
+    rounds_done[0] = executed;
+    rounds_done[1] = why;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // After the last round: R -> plane bits -> rank granules.  Between two known boundaries a < b a plane is
 // constant: all ones iff R[b] - R[a] == b - a, all zeros iff R[b] == R[a] (anything else: inconsistent archive).
@@ -835,18 +925,33 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
     a.par = round & 1u;
     if (cur_nodes <= DT_ENTER && !getenv("BCE_DEC_NO_TAIL")) {
       // forced rounds on the device; stops in front of the first round that needs the decoders
-      uint32_t done = 0;
-      hipLaunchKernelGGL(dec_tail_kernel, dim3(1), dim3(DT_T), 0, c->stream, a, 1u << 30, d_rounds);
-      BCE_HIP_TRY(c, hipMemcpyAsync(&done, d_rounds, 4, hipMemcpyDeviceToHost, c->stream));
+      uint32_t done[2] = {0, 0};
+      const bool wave = cur_nodes <= 64;
+      if (wave) hipLaunchKernelGGL(dec_tail64_kernel, dim3(1), dim3(64), 0, c->stream, a, 1u << 30, d_rounds);
+      else hipLaunchKernelGGL(dec_tail_kernel, dim3(1), dim3(DT_T), 0, c->stream, a, 1u << 30, d_rounds);
+      BCE_HIP_TRY(c, hipMemcpyAsync(done, d_rounds, 8, hipMemcpyDeviceToHost, c->stream));
       BCE_HIP_TRY(c, hipMemcpyAsync(&ctl, c->ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
       BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
       BCE_HIP_TRY(c, hipGetLastError());
-      if (done) {
-        round += done; tail_rounds += done;
+      if (done[0]) {
+        round += done[0]; tail_rounds += done[0];
         cur_nodes = ctl.next_nodes;
         nodes_total = ctl.nodes_total;
         t_c += now_s() - t0;
         continue;
+      }
+      if (wave && done[1] == 2) {                               // the children outgrow one wave: the workgroup version
+        hipLaunchKernelGGL(dec_tail_kernel, dim3(1), dim3(DT_T), 0, c->stream, a, 1u << 30, d_rounds);
+        BCE_HIP_TRY(c, hipMemcpyAsync(done, d_rounds, 4, hipMemcpyDeviceToHost, c->stream));
+        BCE_HIP_TRY(c, hipMemcpyAsync(&ctl, c->ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
+        BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (done[0]) {
+          round += done[0]; tail_rounds += done[0];
+          cur_nodes = ctl.next_nodes;
+          nodes_total = ctl.nodes_total;
+          t_c += now_s() - t0;
+          continue;
+        }
       }
     }
     BCE_TRY(ensure(c, Qbuf, (size_t)(cur_nodes + 16) * 4));
