@@ -53,6 +53,9 @@ int flush_symbols(bce_hip_ctx *c, uint64_t nsym) {
     c->stats.t_coder += now_s() - t0;
     account_slot(c, slot);
     BCE_TRY(k4_flush_async(c, nsym, slot));
+    // BCE_HIP_SYNC_FLUSH=1 (profiling): wait for the copy before queuing more rounds.  rocprofv3's kernel trace
+    // serialises the copy stream's blit kernel with the compute stream and charges the 2.4 ms to the K3 kernel behind it.
+    if (c->sync_flush) BCE_HIP_TRY(c, hipEventSynchronize(slot.ev_copy));
     slot.batch.out = slot.h_out;
     for (int p = 0; p < 8; ++p) {
       slot.batch.runs[p].clear();
@@ -92,6 +95,7 @@ int bce_hip_create(bce_hip_ctx **out, int device) {
     delete c;
     return BCE_HIP_E_DEVICE;
   }
+  c->sync_flush = getenv("BCE_HIP_SYNC_FLUSH") != nullptr;
   c->coder = new (std::nothrow) HostCoder();
   if (!c->coder) { bce_hip_destroy(c); return BCE_HIP_E_NOMEM; }
   *out = c;

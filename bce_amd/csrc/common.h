@@ -81,6 +81,7 @@ struct bce_hip_ctx {
   // debug knobs (bce_hip_debug_set): 0 = default
   uint32_t dbg_dfs_budget = 0, dbg_no_dfs = 0, dbg_no_tail = 0, dbg_no_skip = 0, dbg_no_small = 0, dbg_step_small = 0;
   uint64_t sym_cap_user = 0;
+  bool sync_flush = false;                       // BCE_HIP_SYNC_FLUSH: flushes wait for their copy (profiling)
   bce_hip_progress_fn progress = nullptr;        // bce_hip_set_progress
   void *progress_user = nullptr;
 
