@@ -54,5 +54,7 @@ def test_fuzz_archives_match_oracle():
             ref = oracle.compress(raw)
             assert arch == ref, "case %d: n=%d head=%r" % (case, len(raw), raw[:24])
             assert bce_amd.decompress(arch) == raw, "decode case %d" % case
+            # the GPU-assisted decoder through the SAME context the next compression will use (buffers change hands)
+            assert bce_amd.decompress_device(arch, ctx=ctx) == raw, "gpu decode case %d" % case
     finally:
         ctx.close()

@@ -56,8 +56,9 @@ def test_real_file_archives_match_oracle(name):
     got = bce_amd.compress(data)
     assert len(got) == len(want)
     assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest()
-    back = bce_amd.decompress(got)
-    assert back == data
+    assert bce_amd.decompress_device(got) == data
+    if len(data) <= (1 << 20):
+        assert bce_amd.decompress(got) == data
 
 
 def test_real_file_scan_then_compress_matches_oracle():
@@ -71,4 +72,4 @@ def test_real_file_scan_then_compress_matches_oracle():
     want = oracle.compress(data, bytes(cfg_want))
     got = bce_amd.compress(data, bytes(cfg_got))
     assert got == want
-    assert bce_amd.decompress(got) == data
+    assert bce_amd.decompress_device(got) == data
