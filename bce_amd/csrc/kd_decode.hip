@@ -373,7 +373,6 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
     buf[0][q] = dec_nodes(a, par, p)[i < c0 ? i : (a.capP - 1u - (i - c0))];
   }
   uint64_t nodes_total = ctl->nodes_total;
-  uint32_t err = 0;
   __syncthreads();
   for (;;) {
     if (total == 0 || executed >= max_rounds) break;
@@ -460,7 +459,6 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
     total = off[8];
     par ^= 1u; cur ^= 1u; ++executed;
   }
-  (void)err;
   __syncthreads();
   for (uint32_t q = tid; q < total; q += DT_T) {
     uint32_t p = 0;

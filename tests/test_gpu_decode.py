@@ -46,6 +46,16 @@ def test_periodic_inputs_take_the_host_walk():
         assert bce_amd.decompress_device(arch) == data
 
 
+def test_tail_kernels_and_plain_rounds_agree(monkeypatch):
+    """Forced rounds on the device (dec_tail64_kernel / dec_tail_kernel) against the same rounds run one by one."""
+    base = oracle.synth_text(21, 120000)
+    data = base[:60000] + base[1000:3000] + base[60000:] + base[5000:5400] * 3
+    arch = oracle.compress(data)
+    assert bce_amd.decompress_device(arch) == data
+    monkeypatch.setenv("BCE_DEC_NO_TAIL", "1")
+    assert bce_amd.decompress_device(arch) == data
+
+
 def test_custom_config_archives_decode():
     data = oracle.synth_text(12, 200000)
     cfg, _ = oracle.scan(data)
