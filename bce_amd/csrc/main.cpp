@@ -106,15 +106,19 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> adata((size_t)size);
     archive.seekg(0, std::ios::beg);
     if (size == 0 || !archive.read(reinterpret_cast<char *>(adata.data()), size)) { printf("Could not read Archive.\n"); return -2; }
-    // -d: GPU-assisted decoder (kd_decode.hip); -ds (the reference's low-memory unbwt, :1466) and machines without a
-    // GPU: the host decoder (decoder.cpp).  Same output either way.
+    // -d: GPU-assisted decoder (kd_decode.hip), needs the GPU like -c.  -ds (the reference's low-memory unbwt variant,
+    // :1466): the plain host decoder (decoder.cpp), on purpose and by name -- there is no silent fallback.
     size_t n = 0;
     int rc;
     std::vector<uint8_t> out;
-    bce_hip_ctx *ctx = nullptr;
-    const bool want_gpu = argv[1][2] != 's';
     uint64_t prog = 0;
-    if (want_gpu && bce_hip_create(&ctx, 0) == 0) {
+    if (argv[1][2] != 's') {
+      bce_hip_ctx *ctx = nullptr;
+      rc = bce_hip_create(&ctx, 0);
+      if (rc != 0) {
+        printf("No usable HIP device: %s (bce -ds decodes on the host)\n", bce_hip_strerror(rc));
+        return -3;
+      }
       bce_hip_set_progress(ctx, progress, &prog);
       rc = bce_hip_decompress_device(ctx, adata.data(), adata.size(), nullptr, 0, &n);
       if (rc == 0) { out.resize(n); rc = bce_hip_decompress_device(ctx, adata.data(), adata.size(), out.data(), out.size(), &n); }
