@@ -16,8 +16,8 @@
 // 2^18..2^19 concurrent walkers that stop at marked rows (segments are chained on the host, then written in
 // place, rotated by `offset`, bce.cpp:1091-1093).
 // The archive format, the model and the coder arithmetic are the reference's; parity = decode(reference
-// archive) == input (tests/test_gpu_decode.py).  Inputs whose LF mapping is not one cycle (periodic inputs)
-// finish on the host walk of decoder.cpp.
+// archive) == input (tests/test_gpu_decode.py).  Inputs whose LF mapping is not one cycle (periodic inputs, on which
+// the reference's decoder fails) are unrolled from the cycle through row 0.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -747,6 +747,16 @@ __global__ void walk_write_kernel(const uint32_t *__restrict__ lf, const uint8_t
   }
 }
 
+// periodic inputs: the walk from row 0 goes round ONE cycle of the LF mapping (length lc) again and again; V holds that
+// cycle as the last lc text positions would, and text[i] = V[lc - 1 - ((n - 1 - i) mod lc)]
+__global__ void expand_cycle_kernel(const uint8_t *__restrict__ V, uint32_t lc, uint32_t n, uint32_t off, uint8_t *__restrict__ out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    uint64_t o = (uint64_t)i + off;
+    if (o >= n) o -= n;
+    out[o] = V[lc - 1u - ((n - 1u - i) % lc)];
+  }
+}
+
 // ---- the host's part of a round: the eight plane decoders answer their queries, in parallel ----
 struct QueryPool {
   std::vector<Decoder> *dec = nullptr;
@@ -1071,45 +1081,43 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
   BCE_HIP_TRY(c, hipMemcpyAsync(h_end.data(), d_end, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
   BCE_HIP_TRY(c, hipGetLastError());
-  // chain the segments from row 0 (= the last text position): one cycle through all of them, or the input is periodic
-  bool single_cycle = true;
+  // chain the segments from row 0 (= the last text position) until the walk is back at row 0: one cycle through all
+  // n rows for a primitive input; a shorter cycle (length lc, the input's period pattern in BWT terms) otherwise
+  uint64_t lc = 0;
   {
-    uint64_t pos = n;
-    uint32_t cur = 0, seen = 0;
+    uint32_t cur = 0;
     std::vector<uint8_t> visited(m, 0);
-    while (pos > 0) {
+    std::vector<uint32_t> order;
+    do {
       const uint32_t j = cur >> sh;
-      if (visited[j] || h_len[j] > pos) { single_cycle = false; break; }
-      visited[j] = 1; ++seen;
-      h_dest[j] = (uint32_t)pos;
-      pos -= h_len[j];
+      if (visited[j]) return BCE_HIP_E_INTERNAL;                 // cannot happen: LF is a permutation
+      visited[j] = 1;
+      order.push_back(j);
+      lc += h_len[j];
       cur = h_end[j];
-    }
-    if (single_cycle && (seen != m || cur != 0)) single_cycle = false;
+    } while (cur != 0);
+    uint64_t pos = lc;
+    for (uint32_t j : order) { h_dest[j] = (uint32_t)pos; pos -= h_len[j]; }
+    for (uint32_t j = 0; j < m; ++j) if (!visited[j]) h_len[j] = 0;      // rows off the cycle are never written
   }
+  if (lc == 0 || lc > n || n % lc) { snprintf(c->err, sizeof c->err, "decode: LF cycle of length %llu in %u rows", (unsigned long long)lc, n); return BCE_HIP_E_INTERNAL; }
   const uint32_t off = hd.offset % n;
+  const bool single_cycle = lc == n;
+  BCE_HIP_TRY(c, hipMemcpyAsync(d_dest, h_dest.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+  BCE_HIP_TRY(c, hipMemcpyAsync(d_len, h_len.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
   if (single_cycle) {
-    BCE_HIP_TRY(c, hipMemcpyAsync(d_dest, h_dest.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(walk_write_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, lf, c->bwt.as<uint8_t>(), m, sh, d_len, d_dest,
                        n, off, c->text.as<uint8_t>());
-    BCE_HIP_TRY(c, hipMemcpyAsync(out, c->text.p, n, hipMemcpyDeviceToHost, c->stream));
-    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    BCE_HIP_TRY(c, hipGetLastError());
   } else {
-    // periodic input: the LF mapping has several cycles; the reference's walk from row 0 goes round one of them
-    // n steps (decoder.cpp does the same) -- sequential, on the host
-    std::vector<uint8_t> bwt(n);
-    std::vector<uint32_t> hlf(n);
-    BCE_HIP_TRY(c, hipMemcpy(bwt.data(), c->bwt.p, n, hipMemcpyDeviceToHost));
-    BCE_HIP_TRY(c, hipMemcpy(hlf.data(), lf, b4, hipMemcpyDeviceToHost));
-    uint32_t row = 0;
-    for (uint32_t i = n; i-- > 0;) {
-      uint64_t o = (uint64_t)i + off;
-      if (o >= n) o -= n;
-      out[o] = bwt[row];
-      row = hlf[row];
-    }
+    // periodic input (the reference's decoder returns zeros here): write the cycle once, then unroll it
+    uint8_t *V = reinterpret_cast<uint8_t *>(val[0]);            // the sort's value buffers are free again
+    hipLaunchKernelGGL(walk_write_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, lf, c->bwt.as<uint8_t>(), m, sh, d_len, d_dest,
+                       (uint32_t)lc, 0u, V);
+    hipLaunchKernelGGL(expand_cycle_kernel, dim3(gn), dim3(256), 0, c->stream, V, (uint32_t)lc, n, off, c->text.as<uint8_t>());
   }
-  if (timing) fprintf(stderr, "gpu decode: inverse BWT (%s, %u walkers) %.3f s\n", single_cycle ? "gpu" : "host walk", m, now_s() - tp0);
+  BCE_HIP_TRY(c, hipMemcpyAsync(out, c->text.p, n, hipMemcpyDeviceToHost, c->stream));
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  BCE_HIP_TRY(c, hipGetLastError());
+  if (timing) fprintf(stderr, "gpu decode: inverse BWT (%s, %u walkers) %.3f s\n", single_cycle ? "one cycle" : "periodic", m, now_s() - tp0);
   return BCE_HIP_OK;
 }
