@@ -110,7 +110,7 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   DevBuf *bufs[] = {&c->text, &c->bwt, &c->sa[0], &c->sa[1], &c->key[0], &c->key[1], &c->rank, &c->k2, &c->nrk, &c->act[0], &c->act[1],
                     &c->rs_hist, &c->blk, &c->ptmp[0], &c->ptmp[1], &c->gran, &c->nodes, &c->ctl, &c->tilecnt,
-                    &c->tileoff, &c->runs, &c->smwords, &c->truns, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
+                    &c->tileoff, &c->runs, &c->smwords, &c->k3tw, &c->k3grp, &c->truns, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
                     &c->sesc, &c->stat, &c->dcfg, &c->k4w, &c->scanrec, &c->dfs};
   for (DevBuf *b : bufs) release(*b);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
@@ -168,6 +168,7 @@ int bce_hip_debug_set(bce_hip_ctx *c, int knob, uint32_t value) {
     case 1: c->dbg_no_dfs = value; break;
     case 4: c->dbg_no_small = value; break;
     case 5: c->dbg_step_small = value; break;
+    case 6: c->dbg_no_fused = value; break;
     case 2: c->dbg_no_tail = value; break;
     case 3: c->dbg_no_skip = value; break;
     default: return BCE_HIP_E_ARG;

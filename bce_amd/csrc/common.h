@@ -79,7 +79,7 @@ struct bce_hip_ctx {
   bool k1_valid = false;                         // sa[sa_res] / rank hold this input's suffix order (K1 ran; no injected BWT)
   int sa_res = 0;
   // debug knobs (bce_hip_debug_set): 0 = default
-  uint32_t dbg_dfs_budget = 0, dbg_no_dfs = 0, dbg_no_tail = 0, dbg_no_skip = 0, dbg_no_small = 0, dbg_step_small = 0;
+  uint32_t dbg_dfs_budget = 0, dbg_no_dfs = 0, dbg_no_tail = 0, dbg_no_skip = 0, dbg_no_small = 0, dbg_step_small = 0, dbg_no_fused = 0;
   uint64_t sym_cap_user = 0;
   bool sync_flush = false;                       // BCE_HIP_SYNC_FLUSH: flushes wait for their copy (profiling)
   bce_hip_progress_fn progress = nullptr;        // bce_hip_set_progress
@@ -96,6 +96,8 @@ struct bce_hip_ctx {
   uint32_t capP = 0;
   bce::DevBuf ctl, tilecnt, tileoff, runs;       // K3 control
   bce::DevBuf smwords;                           // k3_small_kernel: one published count word per tile
+  size_t k3_groups = 0;
+  bce::DevBuf k3tw, k3grp;                       // k3_count2_kernel: count word per tile; group words, tickets, offsets
   bce::DevBuf dfs;                               // depth-first tail: tagged symbols, sort scratch, walker stacks
   bce::DevBuf truns;                             // run table of the persistent tail kernel [K3_TAIL_MAXROUNDS][8]
   void *h_truns = nullptr;

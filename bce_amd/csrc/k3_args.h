@@ -23,6 +23,10 @@ struct K3Args {
   uint32_t *tilecnt;      // [tiles][4]
   uint32_t *tileoff;      // [tiles][4]
   RunEntry *runs;         // [K3_MAXBATCH][8]
+  // two-launch rounds (k3_count2_kernel): per-tile count words, per-group (256 tiles of a plane) totals / offsets
+  unsigned long long *tw, *gwa, *gwb;
+  uint32_t *goff;         // [groups][4]
+  uint32_t fused;         // the write kernel adds goff to the (group-relative) tile offsets
   uint32_t capP, ngran, n;
   uint32_t zeros[8];
   uint32_t par, round, run_slot;

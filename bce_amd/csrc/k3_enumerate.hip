@@ -37,6 +37,14 @@ __device__ __forceinline__ void tile_prefix(const K3Args &a, uint32_t tp[9]) {
   tp[8] = acc;
 }
 
+// groups = runs of 256 tiles of one plane (two-launch rounds): gp[p] = first group of plane p, gp[8] = all groups
+__device__ __forceinline__ void group_prefix(const uint32_t tp[9], uint32_t gp[9]) {
+  uint32_t acc = 0;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) { gp[p] = acc; acc += (tp[p + 1] - tp[p] + 255u) >> 8; }
+  gp[8] = acc;
+}
+
 // Classify the K3_NPT nodes of one thread in PHASES so that the loads of all its nodes are in flight
 // together: (1) the node triples, (2) the two rank granules of every node, (3) the third granule only for
 // the nodes that code a symbol and whose split point falls in neither of the two granules already loaded.
@@ -141,7 +149,7 @@ __device__ __forceinline__ void k3_place(const K3Args &a, uint32_t p, const Tile
 // Process one tile.  WRITE=false: count children/symbols.  WRITE=true: place them.
 template <bool WRITE, bool SCAN>
 __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t tile_in_plane, uint32_t tile_global,
-                                        uint32_t (*lds_cnt)[4][3]) {
+                                        uint32_t (*lds_cnt)[4][3], uint32_t group_base = 0) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
   TileOut t;
   k3_classify<WRITE, SCAN>(a, p, tile_in_plane, t);
@@ -168,9 +176,13 @@ __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t ti
       a.tilecnt[(size_t)tile_global * 4 + tid] = tt;
     }
   } else {
-    const uint32_t o0 = a.tileoff[(size_t)tile_global * 4 + 0];
-    const uint32_t o1 = a.tileoff[(size_t)tile_global * 4 + 1];
-    const uint64_t os = a.ctl->symbase[p] + a.tileoff[(size_t)tile_global * 4 + 2];
+    uint32_t o0 = a.tileoff[(size_t)tile_global * 4 + 0];
+    uint32_t o1 = a.tileoff[(size_t)tile_global * 4 + 1];
+    uint64_t os = a.ctl->symbase[p] + a.tileoff[(size_t)tile_global * 4 + 2];
+    if (a.fused) {                                            // two-launch rounds: tile offsets are relative to their group
+      const uint32_t *g = a.goff + (size_t)(group_base + (tile_in_plane >> 8)) * 4;
+      o0 += g[0]; o1 += g[1]; os += g[2];
+    }
     k3_place<SCAN>(a, p, t, pre0, pre1, pres, lds_cnt, o0, o1, os);
   }
   __syncthreads();
@@ -178,17 +190,17 @@ __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t ti
 
 template <bool WRITE, bool SCAN>
 __global__ __launch_bounds__(K3_T) void k3_tiles_kernel(K3Args a) {
-  __shared__ uint32_t tp[9];
+  __shared__ uint32_t tp[9], gp[9];
   __shared__ uint32_t lds_cnt[K3_NPT][4][3];
   if (a.ctl->need_flush || a.ctl->overflow) return;
-  if (threadIdx.x == 0) tile_prefix(a, tp);
+  if (threadIdx.x == 0) { tile_prefix(a, tp); group_prefix(tp, gp); }
   __syncthreads();
   const uint32_t T = tp[8];
   for (uint32_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
     uint32_t p = 0;
 #pragma unroll
     for (int k = 1; k < 8; ++k) p += (tile >= tp[k]) ? 1u : 0u;
-    k3_tile<WRITE, SCAN>(a, p, tile - tp[p], tile, lds_cnt);
+    k3_tile<WRITE, SCAN>(a, p, tile - tp[p], tile, lds_cnt, gp[p]);
   }
 }
 
@@ -269,6 +281,158 @@ __global__ __launch_bounds__(1024) void k3_scan_kernel(K3Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Wide rounds in TWO launches: the scan rides on the count kernel.  Every tile publishes its three counts in a
+// round-tagged 64-bit word (a plain store: nothing on the tile's path waits for memory).  The block that handles
+// the LAST tile of a group (256 consecutive tiles of a plane) waits for the group's words, scans them (one per
+// thread) into group-relative tile offsets and publishes the group totals; the block of the round's last tile
+// then waits for the group words of every plane, scans them and runs the epilogue k3_scan_kernel runs (flush /
+// overflow decision, symbol bases, next list sizes, run table).  Words carry the round number, so nothing is
+// reset and a reader that comes early spins instead of reading stale counts.  A waiter only waits for tiles
+// with smaller indices, i.e. for blocks that were dispatched no later than itself and wait, if at all, for
+// still smaller ones: no cycle.  (A ticket per tile -- an atomic with a return value on every tile's path --
+// made the kernel 70 % slower.)  The write kernel adds the group offset to the tile offset.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ld_word(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_word(unsigned long long *p, uint64_t v) {
+  __hip_atomic_store(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool SCAN>
+__global__ __launch_bounds__(K3_T) void k3_count2_kernel(K3Args a) {
+  __shared__ uint32_t tp[9], gp[9];
+  __shared__ uint32_t lds_cnt[K3_NPT][4][3];
+  __shared__ uint32_t s_pt[8][3];
+  EnumCtl *ctl = a.ctl;
+  if (ctl->need_flush || ctl->overflow) return;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) { tile_prefix(a, tp); group_prefix(tp, gp); }
+  __syncthreads();
+  const uint32_t T = tp[8];
+  if (T == 0) {
+    // a queued round after the end: what the epilogue would do with nothing -- an empty run-table row and EMPTY
+    // lists for the next round (its parity still holds the lists of two rounds ago)
+    if (blockIdx.x == 0 && tid < 8) { RunEntry e; e.start = ctl->sym_total; e.count = 0; e.round = a.round; a.runs[(size_t)a.run_slot * 8 + tid] = e; }
+    if (blockIdx.x == 0 && tid < 16) ctl->cnt[a.par ^ 1u][tid >> 1][tid & 1] = 0;
+    if (blockIdx.x == 0 && tid == 0) ctl->next_nodes = 0;
+    return;
+  }
+  const uint64_t epoch = (uint64_t)((a.round + 1u) & 0x3FFFFFFu);   // 26 bits: the group words keep 38 for their payload
+  for (uint32_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
+    uint32_t p = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) p += (tile >= tp[k]) ? 1u : 0u;
+    const uint32_t ti = tile - tp[p], Tp = tp[p + 1] - tp[p];
+    const uint32_t lane = tid & 63u, w = tid >> 6;
+    {
+      TileOut t;
+      k3_classify<false, SCAN>(a, p, ti, t);
+#pragma unroll
+      for (int it = 0; it < K3_NPT; ++it) {
+        const uint64_t b0 = __ballot(t.has0[it]), b1 = __ballot(t.has1[it]), bs = __ballot(t.hassym[it]);
+        if (lane == 0) {
+          lds_cnt[it][w][0] = (uint32_t)__popcll(b0);
+          lds_cnt[it][w][1] = (uint32_t)__popcll(b1);
+          lds_cnt[it][w][2] = (uint32_t)__popcll(bs);
+        }
+      }
+    }
+    __syncthreads();
+    if (w == 0) {                                              // lanes 0..2 add up one count each, lane 0 publishes
+      uint32_t tt = 0;
+      if (lane < 3)
+        for (int it = 0; it < K3_NPT; ++it)
+          for (int ww = 0; ww < 4; ++ww) tt += lds_cnt[it][ww][lane];
+      const uint64_t t1 = (uint32_t)__shfl((int)tt, 1), t2 = (uint32_t)__shfl((int)tt, 2);
+      // [10:0] child0, [21:11] child1, [32:22] symbols (<= 1024 each), [58:33] round tag.  Fire and forget.
+      if (lane == 0) st_word(&a.tw[tile], (epoch << 33) | (t2 << 22) | (t1 << 11) | (uint64_t)tt);
+    }
+    const uint32_t g = ti >> 8, gidx = gp[p] + g, gfirst = g << 8, nin = Tp - gfirst < 256u ? Tp - gfirst : 256u;
+    if (ti == gfirst + nin - 1u) {
+      // ---- the block of a group's LAST tile scans the group (K3_T = 256 threads, one tile each).  Its tiles are
+      // in flight in blocks that started no later than this one and wait for nothing: spinning is safe. ----
+      const uint32_t j = tp[p] + gfirst + tid;
+      const bool valid = tid < nin;
+      uint64_t wv = 0;
+      if (valid) while (((wv = ld_word(&a.tw[j])) >> 33) != epoch) __builtin_amdgcn_s_sleep(1);
+      const uint64_t v = valid ? ((wv & 0x7FFu) | (((wv >> 11) & 0x7FFu) << 21) | (((wv >> 22) & 0x7FFu) << 42)) : 0ull;
+      uint64_t tot;
+      const uint64_t ex = block_excl_scan_sum64<K3_T>(v, &tot);
+      if (valid) {
+        a.tileoff[(size_t)j * 4 + 0] = (uint32_t)(ex & 0x1FFFFFu);
+        a.tileoff[(size_t)j * 4 + 1] = (uint32_t)((ex >> 21) & 0x1FFFFFu);
+        a.tileoff[(size_t)j * 4 + 2] = (uint32_t)(ex >> 42);
+      }
+      if (tid == 0) {
+        // group totals < 2^19 each: word a = tag | child1 << 19 | child0, word b = tag | symbols
+        st_word(&a.gwa[gidx], (epoch << 38) | (((tot >> 21) & 0x1FFFFFu) << 19) | (tot & 0x1FFFFFu));
+        st_word(&a.gwb[gidx], (epoch << 38) | (tot >> 42));
+      }
+      if (tile == T - 1u) {
+        // ---- the block of the round's last tile: scan the groups of every plane, then the round's bookkeeping ----
+        for (uint32_t q = 0; q < 8; ++q) {
+          uint32_t c0 = 0, c1 = 0, cs = 0;
+          for (uint32_t base = gp[q]; base < gp[q + 1]; base += K3_T) {
+            const uint32_t i = base + tid;
+            const bool ok = i < gp[q + 1];
+            uint64_t wa = 0, wb = 0;
+            if (ok) {
+              while (((wa = ld_word(&a.gwa[i])) >> 38) != epoch) __builtin_amdgcn_s_sleep(1);
+              while (((wb = ld_word(&a.gwb[i])) >> 38) != epoch) __builtin_amdgcn_s_sleep(1);
+            }
+            const uint64_t v01 = ok ? ((wa & 0x7FFFFu) | (((wa >> 19) & 0x7FFFFu) << 32)) : 0ull;
+            const uint32_t vs = ok ? (uint32_t)(wb & 0x7FFFFu) : 0u;
+            uint64_t t01;
+            uint32_t ts;
+            const uint64_t e01 = block_excl_scan_sum64<K3_T>(v01, &t01);
+            const uint32_t es = block_excl_scan_sum<K3_T>(vs, &ts);
+            if (ok) {
+              a.goff[(size_t)i * 4 + 0] = c0 + (uint32_t)e01;
+              a.goff[(size_t)i * 4 + 1] = c1 + (uint32_t)(e01 >> 32);
+              a.goff[(size_t)i * 4 + 2] = cs + es;
+            }
+            c0 += (uint32_t)t01; c1 += (uint32_t)(t01 >> 32); cs += ts;
+          }
+          if (tid == 0) { s_pt[q][0] = c0; s_pt[q][1] = c1; s_pt[q][2] = cs; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+          uint64_t symsum = 0, nextn = 0, curn = 0;
+          bool ovf = false;
+          for (int q = 0; q < 8; ++q) {
+            symsum += s_pt[q][2];
+            nextn += (uint64_t)s_pt[q][0] + s_pt[q][1];
+            curn += (uint64_t)ctl->cnt[a.par][q][0] + ctl->cnt[a.par][q][1];
+            if ((uint64_t)s_pt[q][0] + s_pt[q][1] > a.capP) ovf = true;
+          }
+          const uint64_t sym0 = ctl->sym_total;
+          if (ovf) ctl->overflow = 1;
+          else if (sym0 + symsum > ctl->sym_cap) { ctl->need_flush = 1; ctl->skip_round = a.round; ctl->want_syms = symsum; }
+          else {
+            uint64_t acc = sym0;
+            for (uint32_t q = 0; q < 8; ++q) {
+              const uint32_t qn = (q + 1u) & 7u;
+              ctl->symbase[q] = acc;
+              ctl->cnt[a.par ^ 1u][qn][0] = s_pt[q][0];
+              ctl->cnt[a.par ^ 1u][qn][1] = s_pt[q][1];
+              RunEntry e; e.start = acc; e.count = s_pt[q][2]; e.round = a.round;
+              a.runs[(size_t)a.run_slot * 8 + q] = e;
+              acc += s_pt[q][2];
+            }
+            ctl->sym_total = acc;
+            atomicAdd((unsigned long long *)&ctl->nodes_total, (unsigned long long)curn);
+            ctl->next_nodes = (uint32_t)nextn;
+            if (nextn == 0 && ctl->done_round == 0xFFFFFFFFu) ctl->done_round = a.round + 1u;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Narrow rounds in ONE launch.  A dependent kernel costs ~8 us on this GPU whatever it does, so count / scan /
 // write spend ~30 us on a round of a few thousand nodes.  Here every block takes one tile (dynamic ticket =
 // look-back order), classifies it once, publishes its three counts in one 64-bit word tagged with the round
@@ -279,10 +443,6 @@ __global__ __launch_bounds__(1024) void k3_scan_kernel(K3Args a) {
 // up front from the node count (a node codes at most one symbol), identically in every block; a round that does
 // not fit the grid or the tile table sets small_bail and is run again by the wide kernels.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t ld_word(const unsigned long long *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 template <bool SCAN>
 __global__ __launch_bounds__(K3_T) void k3_small_kernel(K3Args a, unsigned long long *words) {
   __shared__ uint32_t tp[9];
@@ -614,6 +774,16 @@ K3Args k3_make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot) {
   a.tilecnt = c->tilecnt.as<uint32_t>();
   a.tileoff = c->tileoff.as<uint32_t>();
   a.runs = c->runs.as<RunEntry>();
+  a.tw = c->k3tw.as<unsigned long long>();
+  {
+    // group arrays carved from one buffer: words a | words b | offsets[4]
+    const size_t ng = c->k3_groups;
+    uint8_t *base = c->k3grp.as<uint8_t>();
+    a.gwa = reinterpret_cast<unsigned long long *>(base);
+    a.gwb = reinterpret_cast<unsigned long long *>(base + ng * 8);
+    a.goff = reinterpret_cast<uint32_t *>(base + ng * 16);
+  }
+  a.fused = 0;
   a.capP = c->capP; a.ngran = c->ngran; a.n = c->n;
   for (int i = 0; i < 8; ++i) a.zeros[i] = c->zeros[i];
   a.par = round & 1u; a.round = round; a.run_slot = run_slot;
@@ -634,6 +804,12 @@ int k3_begin(bce_hip_ctx *c) {
   const size_t tiles = (size_t)8 * ((c->capP + K3_TILE - 1) / K3_TILE) + 8;
   BCE_TRY(ensure(c, c->tilecnt, tiles * 16));
   BCE_TRY(ensure(c, c->tileoff, tiles * 16));
+  // two-launch rounds: a count word per tile; per group of 256 tiles: two words and four offsets (32 B)
+  c->k3_groups = tiles / 256 + 16;
+  BCE_TRY(ensure(c, c->k3tw, tiles * 8));
+  BCE_TRY(ensure(c, c->k3grp, c->k3_groups * 32 + 64));
+  BCE_HIP_TRY(c, hipMemsetAsync(c->k3tw.p, 0, tiles * 8, c->stream));               // round tags of an earlier compression
+  BCE_HIP_TRY(c, hipMemsetAsync(c->k3grp.p, 0, c->k3_groups * 32 + 64, c->stream));
   BCE_TRY(ensure(c, c->ctl, sizeof(EnumCtl)));
   BCE_TRY(ensure(c, c->runs, (size_t)K3_MAXBATCH * 8 * sizeof(RunEntry)));
   if (!c->h_ctl) BCE_HIP_TRY(c, hipHostMalloc(&c->h_ctl, sizeof(EnumCtl), hipHostMallocDefault));
@@ -685,15 +861,22 @@ int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint) {
   // idle blocks per launch (tiles are grid-strided: the size only affects speed).
   uint64_t want = nodes_hint ? (nodes_hint * 2 + K3_TILE - 1) / K3_TILE + 16 : 2048;
   const uint32_t grid = (uint32_t)(want < 2048 ? want : 2048);
+  const bool fused = !c->dbg_no_fused;
   for (uint32_t i = 0; i < count; ++i) {
-    const K3Args a = k3_make_args(c, c->round + i, i);
-    hipLaunchKernelGGL((k3_tiles_kernel<false, false>), dim3(grid), dim3(K3_T), 0, c->stream, a);
-    hipLaunchKernelGGL(k3_scan_kernel, dim3(8), dim3(1024), 0, c->stream, a);
+    K3Args a = k3_make_args(c, c->round + i, i);
+    a.fused = fused ? 1u : 0u;
+    if (fused) {
+      if (c->scan_mode) hipLaunchKernelGGL((k3_count2_kernel<true>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+      else hipLaunchKernelGGL((k3_count2_kernel<false>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+    } else {
+      hipLaunchKernelGGL((k3_tiles_kernel<false, false>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+      hipLaunchKernelGGL(k3_scan_kernel, dim3(8), dim3(1024), 0, c->stream, a);
+    }
     if (c->scan_mode) hipLaunchKernelGGL((k3_tiles_kernel<true, true>), dim3(grid), dim3(K3_T), 0, c->stream, a);
     else hipLaunchKernelGGL((k3_tiles_kernel<true, false>), dim3(grid), dim3(K3_T), 0, c->stream, a);
   }
   BCE_HIP_TRY(c, hipGetLastError());
-  c->stats.k3_launches += 3.0 * count;
+  c->stats.k3_launches += (fused ? 2.0 : 3.0) * count;
   return BCE_HIP_OK;
 }
 

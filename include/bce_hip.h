@@ -53,7 +53,7 @@ typedef void (*bce_hip_progress_fn)(uint64_t nodes_done, uint64_t nodes_total, v
 int bce_hip_set_progress(bce_hip_ctx *ctx, bce_hip_progress_fn fn, void *user);
 
 /* test knobs for the enumeration's alternative code paths (all 0 by default): 0 = nodes a depth-first walker
- * classifies per pass, 1 = disable the depth-first tail, 2 = disable the persistent LDS tail kernel, 3 = disable chain skipping, 4 = disable the one-launch kernel for narrow rounds.
+ * classifies per pass, 1 = disable the depth-first tail, 2 = disable the persistent LDS tail kernel, 3 = disable chain skipping, 4 = disable the one-launch kernel for narrow rounds, 6 = three launches per wide round (separate scan kernel) instead of two.
  * The archive never depends on them. */
 int bce_hip_debug_set(bce_hip_ctx *ctx, int knob, uint32_t value);
 
