@@ -51,9 +51,15 @@ def test_cli_decompress(tmp_path):
     arc, out = tmp_path / "a.bce", tmp_path / "out.txt"
     arc.write_bytes(oracle.compress(data))
     exe = os.path.join(ROOT, "bce_amd", "bin", "bce")
-    for flag in ("-d", "-ds"):
-        r = subprocess.run([exe, flag, str(out), str(arc)], capture_output=True, text=True)
-        assert r.returncode == 0 and "Decompressed from %d B -> 20000 B in " % arc.stat().st_size in r.stdout
-        assert out.read_bytes() == data
-    r = subprocess.run([exe, "-d", str(out), str(tmp_path / "missing")], capture_output=True, text=True)
+    # -ds = the host decoder by name: works without a GPU
+    r = subprocess.run([exe, "-ds", str(out), str(arc)], capture_output=True, text=True)
+    assert r.returncode == 0 and "Decompressed from %d B -> 20000 B in " % arc.stat().st_size in r.stdout
+    assert out.read_bytes() == data
+    r = subprocess.run([exe, "-ds", str(out), str(tmp_path / "missing")], capture_output=True, text=True)
     assert r.returncode == 255 and "Archive not found." in r.stdout
+    # -d = the GPU-assisted decoder: on a machine without a GPU it fails loudly, it never falls back to the host
+    import torch
+    if not torch.cuda.is_available():
+        out.unlink()
+        r = subprocess.run([exe, "-d", str(out), str(arc)], capture_output=True, text=True)
+        assert r.returncode == 253 and "No usable HIP device" in r.stdout and not out.exists()
