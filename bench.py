@@ -151,12 +151,12 @@ def main():
         alg_bytes = 384.0 * n + 16.0 * st["symbols"]     # 48 B/node x 8n nodes + 16 B/symbol
         traffic = None    # HBM bytes from PMC counters: measured offline (rocprofv3 --pmc passes), see profiles/
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_d_k3_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_e_k3_traffic.json")))
             if tj["bytes_per_gpu"] == n and not args.file and args.workload == "synth-text":
                 traffic = tj["traffic_bytes_corrected"]
         except Exception:
             pass
-        roof = {"bound": "hbm", "kernel": "K3 interval-count (k3_tiles_kernel<count> + k3_scan_kernel + k3_tiles_kernel<write> + k3_tail_kernel, all rounds of one compression = one launch unit)",
+        roof = {"bound": "hbm", "kernel": "K3 interval-count (k3_count2_kernel + k3_tiles_kernel<write> for wide rounds, k3_small_kernel for narrow ones, k3_tail_kernel / k3_dfs_kernel for the ends; all rounds of one compression = one launch unit)",
                 "achieved": round(alg_bytes / k3_s / 1e9, 2) if k3_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(alg_bytes / k3_s / 1e9 / HBM_PEAK_GBS, 5) if k3_s > 0 else None,
                 "traffic": traffic, "algorithmic_bytes": alg_bytes, "k3_ms_per_step": round(k3_s * 1e3, 3),
