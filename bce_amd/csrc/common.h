@@ -97,6 +97,7 @@ struct bce_hip_ctx {
   bce::DevBuf ctl, tilecnt, tileoff, runs;       // K3 control
   bce::DevBuf smwords;                           // k3_small_kernel: one published count word per tile
   size_t k3_groups = 0;
+  uint32_t k3_count2_grid = 0;                   // blocks of k3_count2_kernel that are resident together
   bce::DevBuf k3tw, k3grp;                       // k3_count2_kernel: count word per tile; group words, tickets, offsets
   bce::DevBuf dfs;                               // depth-first tail: tagged symbols, sort scratch, walker stacks
   bce::DevBuf truns;                             // run table of the persistent tail kernel [K3_TAIL_MAXROUNDS][8]

@@ -862,12 +862,21 @@ int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint) {
   uint64_t want = nodes_hint ? (nodes_hint * 2 + K3_TILE - 1) / K3_TILE + 16 : 2048;
   const uint32_t grid = (uint32_t)(want < 2048 ? want : 2048);
   const bool fused = !c->dbg_no_fused;
+  // k3_count2_kernel's group owners wait for tiles of other blocks: keep every block resident (a block that is not
+  // yet running would only start when a running one EXITS, and an owner waiting for it idles until then)
+  if (fused && !c->k3_count2_grid) {
+    int per_cu = 0, cus = 0;
+    BCE_HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_count2_kernel<false>, K3_T, 0));
+    BCE_HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    c->k3_count2_grid = (uint32_t)(per_cu > 0 && cus > 0 ? per_cu * cus : 1024);
+  }
+  const uint32_t grid2 = fused ? (grid < c->k3_count2_grid ? grid : c->k3_count2_grid) : grid;
   for (uint32_t i = 0; i < count; ++i) {
     K3Args a = k3_make_args(c, c->round + i, i);
     a.fused = fused ? 1u : 0u;
     if (fused) {
-      if (c->scan_mode) hipLaunchKernelGGL((k3_count2_kernel<true>), dim3(grid), dim3(K3_T), 0, c->stream, a);
-      else hipLaunchKernelGGL((k3_count2_kernel<false>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+      if (c->scan_mode) hipLaunchKernelGGL((k3_count2_kernel<true>), dim3(grid2), dim3(K3_T), 0, c->stream, a);
+      else hipLaunchKernelGGL((k3_count2_kernel<false>), dim3(grid2), dim3(K3_T), 0, c->stream, a);
     } else {
       hipLaunchKernelGGL((k3_tiles_kernel<false, false>), dim3(grid), dim3(K3_T), 0, c->stream, a);
       hipLaunchKernelGGL(k3_scan_kernel, dim3(8), dim3(1024), 0, c->stream, a);
