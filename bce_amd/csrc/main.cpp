@@ -5,6 +5,7 @@
 // -s runs the enumeration on the GPU in scan mode and the ScanCoder optimisation on the host (scan_coder.cpp).
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -52,6 +53,11 @@ int main(int argc, char **argv) {
       printf("No usable HIP device: %s\n", bce_hip_strerror(rc));
       return -3;
     }
+    const bool cli_timing = getenv("BCE_CLI_TIMING") != nullptr;
+    auto lap = [&](const char *what) {
+      if (cli_timing) fprintf(stderr, "cli: %-10s %.3f s\n", what, std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - start).count());
+    };
+    lap("create");
     if (argc == 5) {   // load_config, bce.cpp:626-641
       std::ifstream cfg(argv[4], std::ios::binary | std::ios::ate);
       std::streamoff size = cfg ? (std::streamoff)cfg.tellg() : -1;
@@ -78,11 +84,13 @@ int main(int argc, char **argv) {
       bce_hip_destroy(ctx);
       return -1;
     }
+    lap("file read");
     size_t alen = 0;
     uint64_t prog = 0;
     bce_hip_set_progress(ctx, progress, &prog);
     rc = bce_hip_compress(ctx, data.data(), (uint32_t)data.size(), nullptr, 0, &alen);
     progress_end();
+    lap("compress");
     if (rc != 0) {
       printf("Compression failed: %s (%s)\n", bce_hip_strerror(rc), bce_hip_last_error(ctx));
       bce_hip_destroy(ctx);
