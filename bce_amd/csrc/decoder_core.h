@@ -18,9 +18,16 @@ namespace bce {
 constexpr uint32_t kUnknown = 0xFFFFFFFFu;
 
 // AdaptiveCoder<31>, decode side.  One per plane, each driven by its own thread in the GPU-assisted decoder: own cache
-// lines (l, h, m and the read position change with every symbol).
+// lines (the state and the read position change with every symbol).
+//
+// State: the reference keeps (l, h, m) -- range bounds and the 64 archive bits under the cursor (bce.cpp:495-504).  Here
+// it is (l, R = h - l + 1, D = m - l): the same numbers, but a symbol's dependency chain is then R -> step -> R'
+// and D -> D' (one single-multiply division, one multiply, one compare each), with l updated off the chain --
+// the form the encoder's host coder uses.  R == 0 stands for the full range (h - l = 2^64 - 1).  shift_in
+// (:663-669) becomes l <<= 16, R <<= 16, D = (D << 16) + next word.  Every quotient and product below is the one
+// the reference computes.
 struct alignas(128) Decoder {
-  uint64_t l = 0, h = ~0ull, m = 0;
+  uint64_t l = 0, R = 0, D = 0;
   const uint16_t *data = nullptr;
   size_t size = 0, o = 0;
   PlaneCfg cfg;
@@ -30,22 +37,24 @@ struct alignas(128) Decoder {
 
   uint16_t next() { const uint16_t v = o < size ? data[o] : 0; ++o; return v; }   // reads past the end give 0 (:568)
   void open(const uint16_t *d, size_t n) {                       // ctor :495-504: the first 4 words, missing ones as 0
-    data = d; size = n; o = 0; l = 0; h = ~0ull; m = 0;
-    for (int i = 0; i < 4; ++i) m = (m << 16) + next();
+    data = d; size = n; o = 0; l = 0; R = 0; D = 0;
+    for (int i = 0; i < 4; ++i) D = (D << 16) + next();
   }
+  void reset() { for (int i = 0; i < 4; ++i) D = (D << 16) + next(); l = 0; R = 0; }   // :565-570: m = 4 fresh words, l = 0, h = ~0
   void shift_in() {                                              // :663-669
-    while (!((h ^ l) >> 48)) {
-      m = (m << 16) + next();
-      l = (l << 16) + 0x0000;
-      h = (h << 16) + 0xFFFF;
+    while (!(((l + R - 1) ^ l) >> 48)) {
+      D = (D << 16) + next();
+      l <<= 16;
+      R <<= 16;
     }
   }
   uint32_t get(uint32_t k) {                                     // :592-608
-    if (h - l < k) { for (int i = 0; i < 4; ++i) m = (m << 16) + next(); l = 0; h = ~0ull; }
-    const uint64_t step = (h - l) / k;
-    const uint32_t s = (uint32_t)((m - l) / step);
+    if (R - 1 < k) reset();                                      // h - l < k (never with the full range: R - 1 wraps to 2^64 - 1)
+    const uint64_t step = (R - 1) / k;
+    const uint32_t s = (uint32_t)(D / step);
     l += step * s;
-    h = step + l - 1;
+    D -= step * s;
+    R = step;                                                    // h = step + l - 1
     shift_in();
     return s;
   }
@@ -70,44 +79,138 @@ struct alignas(128) Decoder {
     const uint32_t ctxv = (((uint32_t)(c1 << b) / cs) << b) | ((uint32_t)(c2 << b) / cs);   // :671-677
     return get_slot(k, ctxv);
   }
-  // the same with the context already resolved (k <= 31): the GPU-assisted decoder computes ctxv on the device
-  uint32_t get_slot(uint32_t k, uint32_t ctxv) {
-    uint8_t *ctx = stat.data() + cfg.off[k] + ctxv * k;
+  // the same with the context already resolved (k <= 31): the GPU-assisted decoder computes ctxv on the device.
+  // The reference walks s = 0, 1, ... with h_s = l - 1 + step cum_s until h_s >= m or s = k - 1 (:577-583);
+  // h_s >= m  <=>  step cum_s > D.
+  // The hot state as a plain local struct: a loop that keeps it in registers (answer_batch) runs the chain without a
+  // store-to-load round trip through the Decoder object on every link.
+  struct St { uint64_t l, R, D; size_t o; };
+  St save() const { return St{l, R, D, o}; }
+  void restore(const St &t) { l = t.l; R = t.R; D = t.D; o = t.o; }
+  static __attribute__((always_inline)) inline uint64_t word_at(const uint16_t *data, size_t size, St &t) {
+    const uint64_t v = t.o < size ? data[t.o] : 0; ++t.o; return v;
+  }
+  static __attribute__((always_inline)) inline void st_reset(const uint16_t *data, size_t size, St &t) {
+    for (int i = 0; i < 4; ++i) t.D = (t.D << 16) + word_at(data, size, t);
+    t.l = 0; t.R = 0;
+  }
+  static __attribute__((always_inline)) inline void st_shift_in(const uint16_t *data, size_t size, St &t) {
+    while (__builtin_expect(!(((t.l + t.R - 1) ^ t.l) >> 48), 0)) {
+      t.D = (t.D << 16) + word_at(data, size, t);
+      t.l <<= 16;
+      t.R <<= 16;
+    }
+  }
+  // one adaptive symbol with k <= 8 or without AVX2 (scalar), on a local state
+  static __attribute__((always_inline)) inline uint32_t st_slot(const uint16_t *data, size_t size, const Recip *recip, St &t,
+                                                              uint8_t *ctx, uint32_t k) {
     if (k == 2) {
-      // binary contexts (most symbols): the same arithmetic without the data-dependent loop branch
+      // binary contexts (most symbols), branch-free
       const uint32_t c0 = ctx[0], c1 = ctx[1], tot = c0 + c1 + 2u;
-      if (h - l < tot) { for (int i = 0; i < 4; ++i) m = (m << 16) + next(); l = 0; h = ~0ull; }
-      const uint64_t step = div_small(h - l, tot, recip);
-      const uint64_t h0 = l + step * ((uint64_t)c0 + 1) - 1;       // last value of symbol 0
-      const uint32_t s = h0 < m ? 1u : 0u;
-      l = s ? h0 + 1 : l;
-      h = s ? h0 + step * ((uint64_t)c1 + 1) : h0;
-      if (++ctx[s] == 0xFF) { ctx[0] >>= 1; ctx[1] >>= 1; }
-      shift_in();
+      if (__builtin_expect(t.R - 1 < tot, 0)) st_reset(data, size, t);
+      const uint64_t step = div_small(t.R - 1, tot, recip);       // tot < 8192: exact single-multiply division
+      const uint64_t x0 = step * ((uint64_t)c0 + 1), x1 = step * ((uint64_t)c1 + 1);
+      const uint32_t s = t.D >= x0 ? 1u : 0u;
+      const uint64_t mask = 0ull - (uint64_t)s;                  // explicit masks: the symbol is a coin flip, no branch on it
+      const uint64_t lo = x0 & mask;
+      t.l += lo;
+      t.D -= lo;
+      t.R = x0 ^ ((x0 ^ x1) & mask);
+      if (__builtin_expect(++ctx[s] == 0xFF, 0)) { ctx[0] >>= 1; ctx[1] >>= 1; }
+      st_shift_in(data, size, t);
       return s;
     }
-#if defined(__x86_64__)
-    if (have_avx2) return get_slot_avx2(ctx, k);
-#endif
+    if (k <= 8) {
+      // small alphabets: a fixed seven-step walk with masks instead of a loop that ends where the data says.
+      // The eight counter bytes come in one load (the slot's neighbours / the array's slack beyond k are masked).
+      uint64_t x;
+      __builtin_memcpy(&x, ctx, 8);
+      x &= ~0ull >> (64 - 8 * k);
+      const uint64_t ev = x & 0x00FF00FF00FF00FFull, od = (x >> 8) & 0x00FF00FF00FF00FFull;
+      const uint32_t tot = k + (uint32_t)(((ev + od) * 0x0001000100010001ull) >> 48);
+      if (__builtin_expect(t.R - 1 < tot, 0)) st_reset(data, size, t);
+      const uint64_t step = div_small(t.R - 1, tot, recip);
+      uint64_t acc = 0, lo = 0;
+      uint32_t s = 0;
+#pragma GCC unroll 7
+      for (uint32_t i = 0; i < 7; ++i) {
+        acc += step * (((x >> (8 * i)) & 0xFFu) + 1);            // step * cum_i, increasing in i
+        const uint64_t adv = 0ull - (uint64_t)((i + 1 < k) & (acc <= t.D));   // all ones while the walk goes on (monotone)
+        lo = (acc & adv) | (lo & ~adv);
+        s += (uint32_t)(adv & 1u);
+      }
+      t.l += lo;
+      t.D -= lo;
+      t.R = step * ((uint64_t)ctx[s] + 1);
+      if (__builtin_expect(++ctx[s] == 0xFF, 0)) for (uint32_t i = 0; i < k; ++i) ctx[i] >>= 1;
+      st_shift_in(data, size, t);
+      return s;
+    }
     uint32_t tot = k;
     for (uint32_t i = 0; i < k; ++i) tot += ctx[i];
-    if (h - l < tot) { for (int i = 0; i < 4; ++i) m = (m << 16) + next(); l = 0; h = ~0ull; }
-    const uint64_t step = div_small(h - l, tot, recip);           // tot < 8192: exact single-multiply division
-    h = l - 1;
-    uint32_t s = ~0u;
-    do {
+    if (__builtin_expect(t.R - 1 < tot, 0)) st_reset(data, size, t);
+    const uint64_t step = div_small(t.R - 1, tot, recip);
+    uint64_t lo = 0, hi = step * ((uint64_t)ctx[0] + 1);
+    uint32_t s = 0;
+    while (hi <= t.D && s + 1 < k) {
       ++s;
-      l = h + 1;
-      h += step * ((uint64_t)ctx[s] + 1);
-    } while (h < m && s + 1 < k);
-    if (++ctx[s] == 0xFF) for (uint32_t i = 0; i < k; ++i) ctx[i] >>= 1;
-    shift_in();
+      lo = hi;
+      hi += step * ((uint64_t)ctx[s] + 1);
+    }
+    t.l += lo;
+    t.D -= lo;
+    t.R = hi - lo;
+    if (__builtin_expect(++ctx[s] == 0xFF, 0)) for (uint32_t i = 0; i < k; ++i) ctx[i] >>= 1;
+    st_shift_in(data, size, t);
     return s;
   }
+  uint32_t get_slot(uint32_t k, uint32_t ctxv) {
+    uint8_t *ctx = stat.data() + cfg.off[k] + ctxv * k;
 #if defined(__x86_64__)
-  // The same step for 3 <= k <= 31 without the two data-dependent loops: cum[i] = sum_{j<=i} (ctx[j] + 1) for all
-  // 32 lanes at once (16-bit prefix sums), then the symbol is the number of i < k with cum[i] < t, where
-  // t = floor((m - l) / step) + 1 (h_i = l - 1 + step cum[i] >= m  <=>  cum[i] >= t), capped at k - 1 as the loop is.
+    if (have_avx2 && k > 8) return get_slot_avx2(ctx, k);
+#endif
+    St t = save();
+    const uint32_t s = st_slot(data, size, recip, t, ctx, k);
+    restore(t);
+    return s;
+  }
+  // A run of queries of one plane in stream order (the GPU-assisted decoder's rounds): q[i] = k | ctx << 5, or
+  // kEscapeQuery with the next record of e = (k, c1, c2, cs).  The state stays in registers across the run.
+  static constexpr uint32_t kEscapeQuery = 0x80000000u;
+  struct Esc { uint32_t k, c1, c2, cs; };
+  void answer_batch(const uint32_t *q, const Esc *e, uint32_t *r, uint32_t cnt) {
+    St t = save();
+    uint8_t *const sbase = stat.data();
+    const uint16_t *const dat = data;
+    const size_t sz = size;
+    const Recip *const rc = recip;
+    for (uint32_t i = 0; i < cnt; ++i) {
+      if (i + 8 < cnt) {                                         // the counters of a query soon to come
+        const uint32_t qn = q[i + 8];
+        if (!(qn & kEscapeQuery)) __builtin_prefetch(sbase + cfg.off[qn & 31u] + (qn >> 5) * (qn & 31u));
+      }
+      const uint32_t qi = q[i];
+      const uint32_t k = qi & 31u;
+#if defined(__x86_64__)
+      const bool wide = have_avx2 && k > 8;
+#else
+      const bool wide = false;
+#endif
+      if (__builtin_expect((qi & kEscapeQuery) || wide, 0)) {    // rare paths work on the object
+        restore(t);
+        if (qi & kEscapeQuery) { r[i] = get_adaptive(e->k, e->c1, e->c2, e->cs); ++e; }
+        else r[i] = get_slot(k, qi >> 5);
+        t = save();
+        continue;
+      }
+      r[i] = st_slot(dat, sz, rc, t, sbase + cfg.off[k] + (qi >> 5) * k, k);
+    }
+    restore(t);
+  }
+#if defined(__x86_64__)
+  // The same step for larger k without the two data-dependent loops: cum[i] = sum_{j<=i} (ctx[j] + 1) for all 32
+  // lanes at once (16-bit prefix sums), then the symbol is the number of i < k with cum[i] < t, where
+  // t = floor(D / step) + 1 (step cum[i] > D  <=>  cum[i] >= t), capped at k - 1 as the loop is.
   __attribute__((target("avx2"))) uint32_t get_slot_avx2(uint8_t *ctx, uint32_t k) {
     alignas(32) static const int16_t iota[32] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
                                                  16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31};
@@ -133,17 +236,18 @@ struct alignas(128) Decoder {
     _mm256_store_si256((__m256i *)cum, lo);
     _mm256_store_si256((__m256i *)(cum + 16), hi);
     const uint32_t tot = cum[31];                                  // lanes >= k added nothing
-    if (h - l < tot) { for (int i = 0; i < 4; ++i) m = (m << 16) + next(); l = 0; h = ~0ull; }
-    const uint64_t step = div_small(h - l, tot, recip);
-    const uint64_t tq = (m - l) / step + 1;
+    if (R - 1 < tot) reset();
+    const uint64_t step = div_small(R - 1, tot, recip);
+    const uint64_t tq = D / step + 1;
     const __m256i t16 = _mm256_set1_epi16((short)(tq > 16384 ? 16384 : tq));                        // cum <= 8192
     const uint32_t lt_lo = (uint32_t)_mm256_movemask_epi8(_mm256_and_si256(_mm256_cmpgt_epi16(t16, lo), m_lo));
     const uint32_t lt_hi = (uint32_t)_mm256_movemask_epi8(_mm256_and_si256(_mm256_cmpgt_epi16(t16, hi), m_hi));
     uint32_t s = (uint32_t)(__builtin_popcount(lt_lo) + __builtin_popcount(lt_hi)) >> 1;             // two mask bits per lane
     if (s > k - 1) s = k - 1;
-    const uint64_t l0 = l;
-    l = l0 + step * (s ? cum[s - 1] : 0u);
-    h = l0 - 1 + step * cum[s];
+    const uint64_t below = step * (uint64_t)(cum[(s + 31u) & 31u] & (0u - (uint32_t)(s != 0)));   // cum[s - 1], 0 for s = 0
+    l += below;
+    D -= below;
+    R = step * ((uint64_t)ctx[s] + 1);
     if (++ctx[s] == 0xFF) for (uint32_t i = 0; i < k; ++i) ctx[i] >>= 1;
     shift_in();
     return s;

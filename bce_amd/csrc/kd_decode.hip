@@ -772,11 +772,8 @@ struct QueryPool {
   bool stop = false;
 
   static void answer(Decoder &d, const uint32_t *q, const uint4 *e, uint32_t *r, uint32_t cnt) {
-    for (uint32_t i = 0; i < cnt; ++i) {
-      if (i + 8 < cnt && !(q[i + 8] & kEscape)) d.prefetch_slot(q[i + 8] & 31u, q[i + 8] >> 5);   // the counters of a query soon to come
-      if (q[i] & kEscape) { r[i] = d.get_adaptive(e->x, e->y, e->z, e->w); ++e; }
-      else r[i] = d.get_slot(q[i] & 31u, q[i] >> 5);
-    }
+    static_assert(sizeof(Decoder::Esc) == sizeof(uint4) && Decoder::kEscapeQuery == kEscape, "query formats");
+    d.answer_batch(q, reinterpret_cast<const Decoder::Esc *>(e), r, cnt);
   }
   void worker(int p) {
     uint64_t seen = 0;
