@@ -121,8 +121,9 @@ struct alignas(128) Decoder {
       return s;
     }
     if (k <= 8) {
-      // small alphabets: a fixed seven-step walk with masks instead of a loop that ends where the data says.
-      // The eight counter bytes come in one load (the slot's neighbours / the array's slack beyond k are masked).
+      // small alphabets: a fixed walk (3 steps for k <= 4, 7 for k <= 8) with masks instead of a loop that ends where
+      // the data says.  The counter bytes come in one load (the slot's neighbours / the array's slack beyond k are
+      // masked off).
       uint64_t x;
       __builtin_memcpy(&x, ctx, 8);
       x &= ~0ull >> (64 - 8 * k);
@@ -132,16 +133,19 @@ struct alignas(128) Decoder {
       const uint64_t step = div_small(t.R - 1, tot, recip);
       uint64_t acc = 0, lo = 0;
       uint32_t s = 0;
-#pragma GCC unroll 7
-      for (uint32_t i = 0; i < 7; ++i) {
-        acc += step * (((x >> (8 * i)) & 0xFFu) + 1);            // step * cum_i, increasing in i
-        const uint64_t adv = 0ull - (uint64_t)((i + 1 < k) & (acc <= t.D));   // all ones while the walk goes on (monotone)
-        lo = (acc & adv) | (lo & ~adv);
-        s += (uint32_t)(adv & 1u);
+#define BCE_WALK_STEP(i)                                                                                      \
+      {                                                                                                        \
+        acc += step * (((x >> (8 * (i))) & 0xFFu) + 1);          /* step * cum_i, increasing in i */           \
+        const uint64_t adv = 0ull - (uint64_t)(((i) + 1u < k) & (acc <= t.D));   /* all ones while the walk goes on */ \
+        lo = (acc & adv) | (lo & ~adv);                                                                        \
+        s += (uint32_t)(adv & 1u);                                                                             \
       }
+      BCE_WALK_STEP(0) BCE_WALK_STEP(1) BCE_WALK_STEP(2)
+      if (k > 4) { BCE_WALK_STEP(3) BCE_WALK_STEP(4) BCE_WALK_STEP(5) BCE_WALK_STEP(6) }
+#undef BCE_WALK_STEP
       t.l += lo;
       t.D -= lo;
-      t.R = step * ((uint64_t)ctx[s] + 1);
+      t.R = step * (((x >> (8 * s)) & 0xFFu) + 1);
       if (__builtin_expect(++ctx[s] == 0xFF, 0)) for (uint32_t i = 0; i < k; ++i) ctx[i] >>= 1;
       st_shift_in(data, size, t);
       return s;
