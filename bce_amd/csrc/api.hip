@@ -334,6 +334,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
   EnumCtl ctl;
   bool decaying = false;
   bool have_ctl = false, wide_once = false;
+  const uint32_t early_max = 4;                   // early small flushes: 1M, 2M, 4M, 8M records (0..5 measured: +3 % on text, neutral on random data)
   // depth-first tail: first attempt when the live set is small, a second one (if the first ran out of room) when tiny
   uint32_t kDfsEnter[2] = {65536u, 2048u};
   if (const char *e = getenv("BCE_HIP_DFS_ENTER")) kDfsEnter[0] = (uint32_t)strtoul(e, nullptr, 10);
@@ -377,6 +378,13 @@ int bce_hip_encode(bce_hip_ctx *c) {
       if (!decaying) {
         batch = 1;
         while (batch < 16 && (cur_nodes << (batch + 1)) <= 2ull * K3_SMALL_NODES) ++batch;
+        if (have_ctl && c->stats.flushes < early_max) {          // see the wide branch: stop at the next early-flush size
+          const uint64_t want = (uint64_t)1 << (20 + c->stats.flushes);
+          uint64_t est = ctl.sym_total, nn = cur_nodes;
+          uint32_t b = 0;
+          while (b < batch && est < want) { est += nn; nn *= 2; ++b; }
+          batch = b ? b : 1u;
+        }
       }
       BCE_TRY(k3_rounds_small(c, batch, cur_nodes, !decaying));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -387,7 +395,16 @@ int bce_hip_encode(bce_hip_ctx *c) {
     } else {
       // wide rounds: sync often (the round dominates); medium rounds: queue many per sync
       wide_once = false;
-      const uint32_t batch = cur_nodes > (1u << 20) ? 4u : (cur_nodes > (1u << 14) ? 16u : 64u);
+      uint32_t batch = cur_nodes > (1u << 20) ? 4u : (cur_nodes > (1u << 14) ? 16u : 64u);
+      // ramp-up: the node count doubles per round; once a round or two reach the next early-flush size, stop there so
+      // that the coders get their first (small) batches as early as possible
+      if (!decaying && have_ctl && c->stats.flushes < early_max) {
+        const uint64_t want = (uint64_t)1 << (20 + c->stats.flushes);
+        uint64_t est = ctl.sym_total, nn = cur_nodes;
+        uint32_t b = 0;
+        while (b < batch && est < want) { est += nn; nn *= 2; ++b; }
+        batch = b ? b : 1u;
+      }
       BCE_TRY(k3_rounds(c, batch, decaying ? cur_nodes : 0));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
       BCE_TRY(k3_sync_ctl(c, &ctl));
@@ -417,9 +434,10 @@ int bce_hip_encode(bce_hip_ctx *c) {
       BCE_TRY(flush_symbols(c, ctl.sym_total));
       break;
     }
-    // The host coders are the critical path from the first batch on: hand them a small first batch early
-    // instead of waiting for the symbol buffer to fill.
-    if (c->stats.flushes == 0 && ctl.sym_total >= (1u << 20)) {
+    // The host coders are the critical path from the first batch on: hand them small batches early (1M, 2M, 4M, 8M
+    // records) instead of waiting for the symbol buffer to fill, so that they are never idle while the GPU works on
+    // the next 16M.
+    if (c->stats.flushes < early_max && ctl.sym_total >= ((uint64_t)1 << (20 + c->stats.flushes))) {
       BCE_TRY(flush_symbols(c, ctl.sym_total));
       ctl.sym_total = 0;                         // the host copy is consulted again at the top of the loop
     }
