@@ -227,9 +227,13 @@ class BCE:
         rf._c.check(lib.bce_hip_encode(h), "bce_hip_encode")
         n = C.c_size_t()
         rf._c.check(lib.bce_hip_archive_size(h, C.byref(n)), "bce_hip_archive_size")
-        out = np.empty(n.value, dtype=np.uint8)
-        rf._c.check(lib.bce_hip_archive_copy(h, out.ctypes.data, n.value), "bce_hip_archive_copy")
-        return out.tobytes()
+        # the library lays the archive out straight into this buffer (one copy of the coded streams, none in Python):
+        # a bytearray compares, hashes, slices and writes like bytes
+        out = bytearray(n.value)
+        view = (C.c_uint8 * n.value).from_buffer(out)
+        rf._c.check(lib.bce_hip_archive_copy(h, C.addressof(view), n.value), "bce_hip_archive_copy")
+        del view
+        return out
 
     # --- BCE::code one round at a time (parity tests) ---
     def code_begin(self, rf: RankFile):

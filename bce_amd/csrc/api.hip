@@ -26,7 +26,6 @@ int set_input(bce_hip_ctx *c, const void *src, uint32_t n, hipMemcpyKind kind) {
   c->n = n;
   c->stage = 1;
   c->enum_active = false;
-  c->archive.clear();
   memset(&c->stats, 0, sizeof c->stats);
   c->stats.n = n;
   c->stats.t_load = now_s() - t0;
@@ -210,7 +209,6 @@ int bce_hip_set_bwt(bce_hip_ctx *c, const uint8_t *bwt, uint32_t n, uint32_t off
   BCE_HIP_TRY(c, hipMemcpy(c->bwt.p, bwt, n, hipMemcpyHostToDevice));
   c->n = n; c->offset = offset; c->stage = 2; c->enum_active = false;
   c->k1_unique = false; c->k1_valid = false;     // no suffix array behind an injected BWT
-  c->archive.clear();
   memset(&c->stats, 0, sizeof c->stats);
   c->stats.n = n;
   return BCE_HIP_OK;
@@ -451,7 +449,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
   c->stats.t_coder_busy = c->coder->busy_seconds();
   c->stats.rounds = ctl.done_round;
   c->stats.nodes = ctl.nodes_total;
-  c->coder->finish(c->config, n, c->offset, c->archive);
+  c->coder->finish(c->config, n, c->offset);     // the archive is laid out by bce_hip_archive_copy, straight into the caller's buffer
   c->enum_active = false;
   c->stage = 4;
   c->stats.t_enum = c->stats.k3_ms * 1e-3;      // GPU time of the enumeration; K4, copies and coding overlap it and each other
@@ -538,15 +536,15 @@ int bce_hip_scan(bce_hip_ctx *c, uint8_t config288[BCE_HIP_CONFIG_BYTES], double
 int bce_hip_archive_size(bce_hip_ctx *c, size_t *bytes) {
   BCE_TRY(check_stage(c, 4));
   if (!bytes) return BCE_HIP_E_ARG;
-  *bytes = c->archive.size() * 2;
+  *bytes = c->coder->archive_words() * 2;
   return BCE_HIP_OK;
 }
 
 int bce_hip_archive_copy(bce_hip_ctx *c, uint8_t *out, size_t cap) {
   BCE_TRY(check_stage(c, 4));
   if (!out) return BCE_HIP_E_ARG;
-  if (cap < c->archive.size() * 2) return BCE_HIP_E_OVERFLOW;
-  memcpy(out, c->archive.data(), c->archive.size() * 2);
+  if (cap < c->coder->archive_words() * 2) return BCE_HIP_E_OVERFLOW;
+  c->coder->assemble(reinterpret_cast<uint16_t *>(out));
   return BCE_HIP_OK;
 }
 
@@ -556,7 +554,7 @@ static int compress_loaded(bce_hip_ctx *c, uint8_t *out, size_t cap, size_t *out
   BCE_TRY(bce_hip_build_planes(c, nullptr));
   BCE_TRY(bce_hip_encode(c));
   c->stats.t_total = now_s() - t0 + c->stats.t_load;
-  if (out_len) *out_len = c->archive.size() * 2;
+  if (out_len) *out_len = c->coder->archive_words() * 2;
   if (out) return bce_hip_archive_copy(c, out, cap);
   return BCE_HIP_OK;
 }

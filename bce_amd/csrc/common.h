@@ -120,7 +120,6 @@ struct bce_hip_ctx {
   std::vector<bce::RunEntry> run_log[8];         // runs since the last flush, per plane
 
   bce::HostCoder *coder = nullptr;
-  std::vector<uint16_t> archive;
   bce_hip_stats stats;
 };
 

@@ -205,7 +205,10 @@ double HostCoder::busy_seconds() {
   return m;
 }
 
-void HostCoder::finish(const uint8_t config[9][32], uint32_t n, uint32_t offset, std::vector<uint16_t> &archive) {
+// BCE::encode :1134-1150: flush the plane coders and code the header (n, offset, stream sizes).  The archive itself
+// -- header length, header, the eight streams (:1152-1157) -- is only laid out when somebody asks for it (assemble):
+// 23 MB at 10^8 B of text are then copied once, straight into the caller's buffer.
+void HostCoder::finish(const uint8_t config[9][32], uint32_t n, uint32_t offset) {
   if (getenv("BCE_HIP_CODER_DEBUG"))
     for (int p = 0; p < 8; ++p) fprintf(stderr, "coder %d: busy %.1f ms, %llu symbols, %zu words\n", p, w_[p].busy * 1e3, (unsigned long long)w_[p].nsym, plane[p].data().size());
   unsigned size = 0u;                                   // :1134-1138
@@ -221,10 +224,37 @@ void HostCoder::finish(const uint8_t config[9][32], uint32_t n, uint32_t offset,
     s -= (int)plane[i].data().size();
   }
   mainc.flush();
-  archive.clear();                                      // :1152-1157
-  archive.push_back((uint16_t)mainc.data().size());
-  archive.insert(archive.end(), mainc.data().begin(), mainc.data().end());
-  for (int i = 0; i < 8; ++i) archive.insert(archive.end(), plane[i].data().begin(), plane[i].data().end());
+  header_ = mainc.data();
+}
+
+size_t HostCoder::archive_words() const {
+  size_t w = 1 + header_.size();
+  for (int i = 0; i < 8; ++i) w += plane[i].data().size();
+  return w;
+}
+
+void HostCoder::assemble(uint16_t *dst) const {          // :1152-1157
+  *dst++ = (uint16_t)header_.size();
+  memcpy(dst, header_.data(), header_.size() * 2);
+  dst += header_.size();
+  // the streams are tens of MB: copy them with a few threads
+  uint16_t *at[8];
+  for (int i = 0; i < 8; ++i) { at[i] = dst; dst += plane[i].data().size(); }
+  size_t total = 0;
+  for (int i = 0; i < 8; ++i) total += plane[i].data().size();
+  if (total < (1u << 20)) {
+    for (int i = 0; i < 8; ++i) memcpy(at[i], plane[i].data().data(), plane[i].data().size() * 2);
+    return;
+  }
+  std::thread th[8];
+  for (int i = 0; i < 8; ++i) th[i] = std::thread([this, i, &at] { memcpy(at[i], plane[i].data().data(), plane[i].data().size() * 2); });
+  for (int i = 0; i < 8; ++i) th[i].join();
+}
+
+void HostCoder::finish(const uint8_t config[9][32], uint32_t n, uint32_t offset, std::vector<uint16_t> &archive) {
+  finish(config, n, offset);
+  archive.resize(archive_words());
+  assemble(archive.data());
 }
 
 }  // namespace bce

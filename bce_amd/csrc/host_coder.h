@@ -78,7 +78,10 @@ struct HostCoder {
   void wait(CoderBatch *b);          // until every plane has finished batch b
   void drain();                      // until every submitted batch is finished
   // BCE::encode :1134-1157: flush, header coder main(-1) (config row 8), concatenate.
-  void finish(const uint8_t config[9][32], uint32_t n, uint32_t offset, std::vector<uint16_t> &archive);
+  void finish(const uint8_t config[9][32], uint32_t n, uint32_t offset);      // flush + header; archive_words / assemble lay it out
+  size_t archive_words() const;
+  void assemble(uint16_t *dst) const;
+  void finish(const uint8_t config[9][32], uint32_t n, uint32_t offset, std::vector<uint16_t> &archive);   // all in one (tests)
   double busy_seconds();             // max over planes of the time spent coding since begin()
 
  private:
@@ -94,6 +97,7 @@ struct HostCoder {
   Worker w_[8];
   std::mutex done_mu_;
   std::condition_variable done_cv_;
+  std::vector<uint16_t> header_;             // the coded header of the last finish()
   uint64_t submitted_ = 0, completed_ = 0;   // in units of (batch, plane); guarded by done_mu_
   void run(int p);
 };
