@@ -24,6 +24,10 @@
 
 namespace bce {
 
+#ifndef K1_ACT_TENTHS
+#define K1_ACT_TENTHS 6   // switch to the active-set rounds below this many tenths of n (4, 6, 8 measured: 6 is best on repetitive text)
+#endif
+
 constexpr int K1_T = 256;
 
 struct K1Plan { uint32_t nb, per_block; };
@@ -319,14 +323,14 @@ int k1_bwt(bce_hip_ctx *c) {
     return BCE_HIP_OK;
   };
   while (groups < n && h < n) {
-    if (!have_list && (uint64_t)(n - groups) * 5 < (uint64_t)n * 2 + 5) {
+    if (!have_list && (uint64_t)(n - groups) * 10 < (uint64_t)n * K1_ACT_TENTHS + 10) {
       // few elements can still be in non-singleton groups (at most 2 per missing group... bound: n - groups < 0.4 n
       // means at most 0.8 n active): build the explicit list and check its real size
       BCE_TRY(build_active(nrk, nullptr, n, act[0]));
       have_list = true;
       if (m == 0) break;
     }
-    if (have_list && (uint64_t)m * 5 < (uint64_t)n * 2) {
+    if (have_list && (uint64_t)m * 10 < (uint64_t)n * K1_ACT_TENTHS) {
       // ---- active round on m elements ----
       const uint32_t *A = act[0];
       uint32_t *ki[2] = {key[0], key[1]};
