@@ -11,6 +11,7 @@
 #include <chrono>
 #include <fstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bce_hip.h"
@@ -27,6 +28,54 @@ static void progress(uint64_t done, uint64_t total, void *user) {
 }
 static void progress_end() { printf("                    \r"); }
 
+// ---- multi-block container (an extension; the reference has one block per archive, bce.cpp:1151-1157) ----
+// b"BCEM" | u32 version = 1 | u32 nblocks | nblocks x (u64 raw_bytes, u64 archive_bytes) | the archives.  Every
+// embedded archive is exactly what `bce -c` writes for that block alone.  Same layout as bce_amd/container.py
+// (the 8-GPU path of bench.py gathers its blocks into it).  A plain archive cannot start with "BCEM": that would
+// be a header of 0x4342 words.
+static bool is_container(const std::vector<uint8_t> &a) { return a.size() >= 12 && memcmp(a.data(), "BCEM", 4) == 0; }
+static void put_u32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+static void put_u64(std::vector<uint8_t> &v, uint64_t x) { for (int i = 0; i < 8; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
+static uint64_t get_le(const uint8_t *p, int bytes) { uint64_t x = 0; for (int i = 0; i < bytes; ++i) x |= (uint64_t)p[i] << (8 * i); return x; }
+
+// `bce -cN`: N contiguous blocks, block b on device b mod (number of GPUs), one host thread per device.
+static int compress_blocks(const std::vector<uint8_t> &data, uint32_t nblocks, const uint8_t *config, std::vector<uint8_t> &out) {
+  std::vector<bce_hip_ctx *> ctx;
+  for (int dev = 0; dev < 64 && ctx.size() < nblocks; ++dev) {
+    bce_hip_ctx *c = nullptr;
+    if (bce_hip_create(&c, dev) != 0) break;
+    if (config) bce_hip_set_config(c, config);
+    ctx.push_back(c);
+  }
+  if (ctx.empty()) return -3;
+  const size_t n = data.size(), base = n / nblocks, rem = n % nblocks;
+  std::vector<std::vector<uint8_t>> arch(nblocks);
+  std::vector<size_t> lo(nblocks + 1);
+  for (uint32_t b = 0; b <= nblocks; ++b) lo[b] = b * base + (b < rem ? b : rem);
+  std::vector<int> rcs(ctx.size(), 0);
+  std::vector<std::thread> th;
+  for (size_t d = 0; d < ctx.size(); ++d)
+    th.emplace_back([&, d] {
+      for (uint32_t b = (uint32_t)d; b < nblocks && rcs[d] == 0; b += (uint32_t)ctx.size()) {
+        size_t alen = 0;
+        int rc = bce_hip_compress(ctx[d], data.data() + lo[b], (uint32_t)(lo[b + 1] - lo[b]), nullptr, 0, &alen);
+        if (rc == 0) { arch[b].resize(alen); rc = bce_hip_archive_copy(ctx[d], arch[b].data(), alen); }
+        rcs[d] = rc;
+      }
+    });
+  for (auto &t : th) t.join();
+  int rc = 0;
+  for (size_t d = 0; d < ctx.size(); ++d) { if (rcs[d] && !rc) { rc = rcs[d]; printf("%s\n", bce_hip_last_error(ctx[d])); } bce_hip_destroy(ctx[d]); }
+  if (rc) return rc;
+  out.clear();
+  out.insert(out.end(), {'B', 'C', 'E', 'M'});
+  put_u32(out, 1);
+  put_u32(out, nblocks);
+  for (uint32_t b = 0; b < nblocks; ++b) { put_u64(out, lo[b + 1] - lo[b]); put_u64(out, arch[b].size()); }
+  for (uint32_t b = 0; b < nblocks; ++b) out.insert(out.end(), arch[b].begin(), arch[b].end());
+  return 0;
+}
+
 static int usage() {
   printf("Usage:\n");
   printf("  bce -c archive.bce file [config.bcc]\n");
@@ -37,6 +86,8 @@ static int usage() {
   printf("\n");
   printf("  bce -s config.bcc file\n");
   printf("   Scan \"file\" and generate a config file \"config.bcc\" to improve the AdaptiveCoder (uses a lot of memory)\n");
+  printf("\n");
+  printf("  bce -cN archive.bcem file [config.bcc]      (extension: N = 2..64 blocks, one container, all GPUs of the node)\n");
   return 0;
 }
 
@@ -85,6 +136,25 @@ int main(int argc, char **argv) {
       return -1;
     }
     lap("file read");
+    // `-cN` (N = 2..64, an extension): N blocks in a BCEM container, spread over the GPUs of the node
+    const uint32_t nblocks = (uint32_t)atoi(argv[1] + 2);
+    if (nblocks >= 2 && nblocks <= 64 && data.size() >= nblocks) {
+      uint8_t cfgbuf[BCE_HIP_CONFIG_BYTES];
+      bool have_cfg = false;
+      if (argc == 5) {
+        std::ifstream cf(argv[4], std::ios::binary);
+        have_cfg = (bool)cf.read(reinterpret_cast<char *>(cfgbuf), BCE_HIP_CONFIG_BYTES) && cf.peek() == EOF;
+      }
+      bce_hip_destroy(ctx);
+      std::vector<uint8_t> blob;
+      rc = compress_blocks(data, nblocks, have_cfg ? cfgbuf : nullptr, blob);
+      if (rc != 0) { printf("Compression failed: %s\n", bce_hip_strerror(rc)); return -4; }
+      std::chrono::duration<double> duration = std::chrono::high_resolution_clock::now() - start;
+      printf("Compressed from %zu B -> %zu B in %.1f s\n", data.size(), blob.size(), duration.count());
+      std::ofstream archive(std::string(argv[2]), std::ios::binary | std::ios::trunc);
+      archive.write(reinterpret_cast<const char *>(blob.data()), (std::streamsize)blob.size());
+      return 0;
+    }
     size_t alen = 0;
     uint64_t prog = 0;
     bce_hip_set_progress(ctx, progress, &prog);
@@ -116,26 +186,48 @@ int main(int argc, char **argv) {
     if (size == 0 || !archive.read(reinterpret_cast<char *>(adata.data()), size)) { printf("Could not read Archive.\n"); return -2; }
     // -d: GPU-assisted decoder (kd_decode.hip), needs the GPU like -c.  -ds (the reference's low-memory unbwt variant,
     // :1466): the plain host decoder (decoder.cpp), on purpose and by name -- there is no silent fallback.
-    size_t n = 0;
-    int rc;
+    // A BCEM container (bce -cN, the sharded bench) is decoded block by block.
+    std::vector<std::pair<size_t, size_t>> blocks;               // (offset, length) of each archive inside adata
+    if (is_container(adata)) {
+      const uint32_t ver = (uint32_t)get_le(adata.data() + 4, 4), nb = (uint32_t)get_le(adata.data() + 8, 4);
+      size_t pos = 12 + (size_t)nb * 16;
+      if (ver != 1 || pos > adata.size()) { printf("Could not read Archive.\n"); return -2; }
+      for (uint32_t b = 0; b < nb; ++b) {
+        const size_t alen = (size_t)get_le(adata.data() + 12 + (size_t)b * 16 + 8, 8);
+        if (alen > adata.size() - pos) { printf("Could not read Archive.\n"); return -2; }
+        blocks.emplace_back(pos, alen);
+        pos += alen;
+      }
+    } else {
+      blocks.emplace_back(0, adata.size());
+    }
+    int rc = 0;
     std::vector<uint8_t> out;
     uint64_t prog = 0;
+    bce_hip_ctx *ctx = nullptr;
     if (argv[1][2] != 's') {
-      bce_hip_ctx *ctx = nullptr;
       rc = bce_hip_create(&ctx, 0);
       if (rc != 0) {
         printf("No usable HIP device: %s (bce -ds decodes on the host)\n", bce_hip_strerror(rc));
         return -3;
       }
       bce_hip_set_progress(ctx, progress, &prog);
-      rc = bce_hip_decompress_device(ctx, adata.data(), adata.size(), nullptr, 0, &n);
-      if (rc == 0) { out.resize(n); rc = bce_hip_decompress_device(ctx, adata.data(), adata.size(), out.data(), out.size(), &n); }
+    }
+    for (const auto &blk : blocks) {
+      const uint8_t *ap = adata.data() + blk.first;
+      size_t n = 0;
+      rc = ctx ? bce_hip_decompress_device(ctx, ap, blk.second, nullptr, 0, &n) : bce_hip_decompress(ap, blk.second, nullptr, 0, &n);
+      if (rc != 0) break;
+      const size_t at = out.size();
+      out.resize(at + n);
+      prog = 0;
+      rc = ctx ? bce_hip_decompress_device(ctx, ap, blk.second, out.data() + at, n, &n) : bce_hip_decompress(ap, blk.second, out.data() + at, n, &n);
+      if (rc != 0) break;
+    }
+    if (ctx) {
       progress_end();
       if (rc != 0) printf("%s\n", bce_hip_last_error(ctx));
       bce_hip_destroy(ctx);
-    } else {
-      rc = bce_hip_decompress(adata.data(), adata.size(), nullptr, 0, &n);
-      if (rc == 0) { out.resize(n); rc = bce_hip_decompress(adata.data(), adata.size(), out.data(), out.size(), &n); }
     }
     if (rc != 0) { printf("Decompression failed: %s\n", bce_hip_strerror(rc)); return -4; }
     auto end = std::chrono::high_resolution_clock::now();

@@ -59,3 +59,22 @@ def test_cli_decompress_gpu_and_host_paths(tmp_path):
     assert r.returncode == 0 and out2.read_bytes() == data
     r = subprocess.run([EXE, "-d", str(out1), str(tmp_path / "nope.bce")], capture_output=True, text=True)
     assert r.returncode == 255 and "Archive not found." in r.stdout
+
+
+def test_cli_block_container(tmp_path):
+    """`bce -c3` (an extension): three blocks in a BCEM container, each exactly `bce -c` of that block; `bce -d` and
+    `bce -ds` put the file back together; the Python side of the sharded bench reads the same container."""
+    from bce_amd import container, sharding
+    data = oracle.synth_text(15, 500001)
+    src, arc, out = tmp_path / "in.txt", tmp_path / "a.bcem", tmp_path / "o"
+    src.write_bytes(data)
+    r = subprocess.run([EXE, "-c3", str(arc), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    archives, sizes = container.unpack_blocks(arc.read_bytes())
+    assert len(archives) == 3 and sum(sizes) == len(data)
+    for b in range(3):
+        lo, hi = sharding.block_range(len(data), 3, b)
+        assert sizes[b] == hi - lo and archives[b] == oracle.compress(data[lo:hi])
+    for flag in ("-d", "-ds"):
+        r = subprocess.run([EXE, flag, str(out), str(arc)], capture_output=True, text=True)
+        assert r.returncode == 0 and out.read_bytes() == data
