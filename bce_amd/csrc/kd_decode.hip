@@ -346,7 +346,11 @@ constexpr int DT_NPT = 4;
 constexpr uint32_t DT_CAP = DT_T * DT_NPT;      // nodes of all planes together
 constexpr uint32_t DT_ENTER = 512;              // the host tries the tail kernel at or below this many nodes
 
-__global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_rounds, uint32_t *rounds_done) {
+// `resume` != 0: the first round is the one a previous launch stopped at; its queries were answered by the host
+// (a.res, in the order they were emitted).  When the kernel stops at a round with queries it EMITS them (a.Q / a.E /
+// a.info, all host-visible) so that one launch + one sync is all a query round costs in this regime; rounds_done[1]
+// = 1 then, 2 if the children outgrow the kernel, 3 on an inconsistent node, 0 when nothing is left.
+__global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_rounds, uint32_t *rounds_done, uint32_t resume) {
   __shared__ Node buf[2][DT_CAP];
   __shared__ uint32_t cnt[2][8][2];
   __shared__ uint32_t off[9], noff[9];
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
   }
   __syncthreads();
   uint32_t total = off[8];
-  if (total > DT_CAP || total == 0 || ctl->err) { if (tid == 0) *rounds_done = 0; return; }
+  if (total > DT_CAP || total == 0 || ctl->err) { if (tid == 0) { rounds_done[0] = 0; rounds_done[1] = total > DT_CAP ? 2u : 0u; } return; }
   for (uint32_t q = tid; q < total; q += DT_T) {
     uint32_t p = 0;
 #pragma unroll
@@ -373,14 +377,17 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
     buf[0][q] = dec_nodes(a, par, p)[i < c0 ? i : (a.capP - 1u - (i - c0))];
   }
   uint64_t nodes_total = ctl->nodes_total;
+  uint32_t why = 0;
   __syncthreads();
   for (;;) {
     if (total == 0 || executed >= max_rounds) break;
+    if ((resume & 2u) && executed && total <= 64) break;    // few nodes again: the wave kernel is three times faster per round
     Node nd[DT_NPT];
     DCls cl[DT_NPT];
     uint32_t pl[DT_NPT];
     bool valid[DT_NPT];
-    int stop = 0;
+    int stop = 0, badn = 0;
+    uint64_t qmine = 0;                                       // queries | escape queries << 32 among my nodes
 #pragma unroll
     for (int it = 0; it < DT_NPT; ++it) {
       const uint32_t q = tid * DT_NPT + (uint32_t)it;
@@ -391,18 +398,80 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
       for (int k = 1; k < 8; ++k) p += (q >= off[k]) ? 1u : 0u;
       pl[it] = valid[it] ? p : 0u;
       cl[it] = dec_classify(nd[it], a.R + (size_t)pl[it] * ((size_t)a.n + 1), a.n);
-      if (valid[it] && (cl[it].kind == 3u || cl[it].bad)) stop = 1;
+      if (valid[it] && cl[it].bad) badn = 1;
+      if (valid[it] && cl[it].kind == 3u) {
+        stop = 1;
+        qmine += 1ull | ((cl[it].mx - cl[it].mn + 1u > (uint32_t)kMaxK) ? (1ull << 32) : 0ull);
+      }
     }
-    if (__syncthreads_or(stop)) break;                       // a query (or an error): this round is the host's
+    if (__syncthreads_or(badn)) { why = 3; break; }
+    const bool answered = (resume & 1u) && executed == 0;    // this round's queries came back from the host
+    uint32_t qx = 0;                                         // exclusive query rank of my first node (list order = stream order)
+    if (__syncthreads_or(stop)) {
+      // exclusive scan of (queries | escapes << 32) in list order, and the per-plane starts
+      uint64_t qinc = wave_incl_sum64(qmine);
+      if (lane == 63) ws[wid] = qinc;
+      __syncthreads();
+      uint64_t qbase = 0, qtot = 0;
+#pragma unroll
+      for (int i = 0; i < DT_T / 64; ++i) { const uint64_t t = ws[i]; if ((uint32_t)i < wid) qbase += t; qtot += t; }
+      const uint64_t qex = qbase + qinc - qmine;
+      __syncthreads();
+      qx = (uint32_t)qex;
+      if (!answered) {
+        // emit the round's queries for the host and leave; the lists stay as they are
+        if (tid < 9) pstart[tid] = qtot;
+        __syncthreads();
+        {
+          uint64_t run = qex;
+#pragma unroll
+          for (int it = 0; it < DT_NPT; ++it) {
+            const uint32_t q = tid * DT_NPT + (uint32_t)it;
+            if (valid[it] && q == off[pl[it]]) pstart[pl[it]] = run;
+            if (valid[it] && cl[it].kind == 3u) {
+              const uint32_t x = nd[it].x0 + nd[it].x1, k = cl[it].mx - cl[it].mn + 1u, c1v = x - cl[it].n1x, c2v = nd[it].x1;
+              if (k <= (uint32_t)kMaxK) {
+                const uint32_t b = a.cfg[pl[it]].bits[k];
+                const uint32_t ctxv = (small_quotient((uint32_t)(c1v << b), x) << b) | small_quotient((uint32_t)(c2v << b), x);
+                a.Q[(uint32_t)run] = k | (ctxv << 5);
+                run += 1ull;
+              } else {
+                a.Q[(uint32_t)run] = kEscape;
+                a.E[(uint32_t)(run >> 32)] = make_uint4(k, c1v, c2v, x);
+                run += 1ull | (1ull << 32);
+              }
+            }
+          }
+        }
+        __syncthreads();
+        if (tid == 0) {
+          for (int p = 7; p >= 0; --p) if (off[p] == off[p + 1]) pstart[p] = pstart[p + 1];
+          for (int p = 0; p < 8; ++p) {
+            a.info->qbase[p] = (uint32_t)pstart[p];
+            a.info->qtot[p] = (uint32_t)(pstart[p + 1] - pstart[p]);
+            a.info->ebase[p] = (uint32_t)(pstart[p] >> 32);
+            a.info->etot[p] = (uint32_t)((pstart[p + 1] - pstart[p]) >> 32);
+          }
+          a.info->cur_nodes = total;
+          a.info->err = 0;
+        }
+        why = 1;
+        break;
+      }
+    }
     uint32_t has0[DT_NPT], has1[DT_NPT], rval[DT_NPT];
     Node c0[DT_NPT], c1[DT_NPT];
     uint64_t mine = 0;
+    int over = 0;
 #pragma unroll
     for (int it = 0; it < DT_NPT; ++it) {
-      rval[it] = dec_children(nd[it], cl[it], cl[it].mn, a.zeros[pl[it]], has0[it], c0[it], has1[it], c1[it]);
+      uint32_t v = cl[it].mn;
+      if (valid[it] && cl[it].kind == 3u) { v += a.res[qx]; ++qx; if (v > cl[it].mx) { over = 1; v = cl[it].mn; } }
+      rval[it] = dec_children(nd[it], cl[it], v, a.zeros[pl[it]], has0[it], c0[it], has1[it], c1[it]);
       if (!valid[it]) has0[it] = has1[it] = 0;
       mine += (uint64_t)has0[it] | ((uint64_t)has1[it] << 32);
     }
+    if (__syncthreads_or(over)) { why = 3; break; }          // an answer outside [mn, mx]: inconsistent archive
     // block exclusive scan of (child0 | child1 << 32) in list order
     uint64_t inc = wave_incl_sum64(mine);
     if (lane == 63) ws[wid] = inc;
@@ -437,7 +506,7 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
       noff[8] = acc;
     }
     __syncthreads();
-    if (noff[8] > DT_CAP) break;                            // nothing of this round has been written yet
+    if (noff[8] > DT_CAP) { why = 2; break; }               // nothing of this round has been written yet
     {
       uint64_t run = ex;
 #pragma unroll
@@ -471,14 +540,17 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
   if (tid == 0) {
     ctl->nodes_total = nodes_total;
     ctl->next_nodes = total;
-    *rounds_done = executed;
+    rounds_done[0] = executed;
+    rounds_done[1] = why;
+    __threadfence_system();
   }
 }
 
 // The same for at most 64 nodes (the very deep tails: a handful of chains): ONE wave, one node per lane, the new
 // order from ballots instead of a block scan -- no workgroup barriers on the round's critical path.
 // rounds_done[1] says why it stopped: 1 query / inconsistent node, 2 more than 64 children, 0 nothing left / max.
-__global__ __launch_bounds__(64) void dec_tail64_kernel(DecArgs a, uint32_t max_rounds, uint32_t *rounds_done) {
+// Like dec_tail_kernel it emits the queries of the round it stops at and resumes with the answers (`resume`).
+__global__ __launch_bounds__(64) void dec_tail64_kernel(DecArgs a, uint32_t max_rounds, uint32_t *rounds_done, uint32_t resume) {
   __shared__ Node nbuf[64];
   __shared__ uint32_t pbuf[64];
   DecCtl *ctl = a.ctl;
@@ -509,10 +581,46 @@ __global__ __launch_bounds__(64) void dec_tail64_kernel(DecArgs a, uint32_t max_
     if (total == 0 || executed >= max_rounds) break;
     const bool valid = lane < total;
     const DCls cl = dec_classify(nd, a.R + (size_t)pl * ((size_t)a.n + 1), a.n);
-    if (__ballot(valid && (cl.kind == 3u || cl.bad))) { why = 1; break; }
+    if (__ballot(valid && cl.bad)) { why = 3; break; }
+    const bool isq = valid && cl.kind == 3u;
+    const uint32_t kq = cl.mx - cl.mn + 1u;
+    const bool ise = isq && kq > (uint32_t)kMaxK;
+    const uint64_t mq = __ballot(isq), me = __ballot(ise);
+    const uint32_t qidx = (uint32_t)__popcll(mq & below), eidx = (uint32_t)__popcll(me & below);   // lane order = stream order
+    const bool answered = resume && executed == 0;             // this round's queries came back from the host
+    if (mq && !answered) {
+      // emit the round's queries (host-visible buffers) and leave; the lists stay as they are
+      if (isq) {
+        const uint32_t x = nd.x0 + nd.x1, c1v = x - cl.n1x, c2v = nd.x1;
+        if (!ise) {
+          const uint32_t b = a.cfg[pl].bits[kq];
+          a.Q[qidx] = kq | (((small_quotient((uint32_t)(c1v << b), x) << b) | small_quotient((uint32_t)(c2v << b), x)) << 5);
+        } else {
+          a.Q[qidx] = kEscape;
+          a.E[eidx] = make_uint4(kq, c1v, c2v, x);
+        }
+      }
+#pragma unroll
+      for (uint32_t p = 0; p < 8; ++p) {
+        const uint64_t pm = __ballot(valid && pl == p);
+        const uint64_t lowp = pm ? ((pm & (0ull - pm)) - 1ull) : ~0ull;      // lanes before plane p's first node
+        if (lane == p) {
+          a.info->qbase[p] = (uint32_t)__popcll(mq & lowp & (pm ? ~0ull : 0ull)) + (pm ? 0u : 0u);
+          a.info->qtot[p] = (uint32_t)__popcll(mq & pm);
+          a.info->ebase[p] = (uint32_t)__popcll(me & lowp & (pm ? ~0ull : 0ull));
+          a.info->etot[p] = (uint32_t)__popcll(me & pm);
+        }
+      }
+      if (lane == 0) { a.info->cur_nodes = total; a.info->err = 0; }
+      why = 1;
+      break;
+    }
     uint32_t has0, has1;
     Node c0, c1;
-    const uint32_t rval = dec_children(nd, cl, cl.mn, a.zeros[pl], has0, c0, has1, c1);
+    uint32_t v = cl.mn;
+    if (isq) v += a.res[qidx];
+    if (__ballot(isq && v > cl.mx)) { why = 3; break; }        // an answer outside [mn, mx]: inconsistent archive
+    const uint32_t rval = dec_children(nd, cl, v, a.zeros[pl], has0, c0, has1, c1);
     if (!valid) has0 = has1 = 0;
     const uint64_t m0 = __ballot(has0), m1 = __ballot(has1);
     if (__popcll(m0) + __popcll(m1) > 64) { why = 2; break; }
@@ -562,6 +670,7 @@ __global__ __launch_bounds__(64) void dec_tail64_kernel(DecArgs a, uint32_t max_
     ctl->next_nodes = total;
     rounds_done[0] = executed;
     rounds_done[1] = why;
+    __threadfence_system();
   }
 }
 
@@ -923,41 +1032,69 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
   uint64_t nodes_total = 0, queries_total = 0;
   double t_q = 0, t_copy = 0, t_host = 0, t_c = 0;
   uint64_t tail_rounds = 0;
+  bool answered_pending = false;                              // pin_res holds the answers of the round about to run
   BCE_TRY(ensure(c, c->runs, 64));
   uint32_t *d_rounds = c->runs.as<uint32_t>();
   while (cur_nodes) {
     double t0 = now_s();
     a.par = round & 1u;
     if (cur_nodes <= DT_ENTER && !getenv("BCE_DEC_NO_TAIL")) {
-      // forced rounds on the device; stops in front of the first round that needs the decoders
-      uint32_t done[2] = {0, 0};
-      const bool wave = cur_nodes <= 64;
-      if (wave) hipLaunchKernelGGL(dec_tail64_kernel, dim3(1), dim3(64), 0, c->stream, a, 1u << 30, d_rounds);
-      else hipLaunchKernelGGL(dec_tail_kernel, dim3(1), dim3(DT_T), 0, c->stream, a, 1u << 30, d_rounds);
-      BCE_HIP_TRY(c, hipMemcpyAsync(done, d_rounds, 8, hipMemcpyDeviceToHost, c->stream));
-      BCE_HIP_TRY(c, hipMemcpyAsync(&ctl, c->ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
-      BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
-      BCE_HIP_TRY(c, hipGetLastError());
-      if (done[0]) {
+      // Few nodes: the tail kernels run the forced rounds on the device; at a round with queries the workgroup kernel
+      // emits them straight into pinned memory, the host answers (inline: they are few) and the kernel resumes with
+      // the answers -- one launch and one sync per query round.
+      BCE_TRY(pin_q.ensure(c, (size_t)(DT_CAP + 16) * 4));
+      BCE_TRY(pin_e.ensure(c, (size_t)(DT_CAP + 16) * sizeof(uint4)));
+      BCE_TRY(pin_res.ensure(c, (size_t)(DT_CAP + 16) * 4));
+      DecArgs at = a;
+      at.Q = static_cast<uint32_t *>(pin_q.p);
+      at.E = static_cast<uint4 *>(pin_e.p);
+      at.res = static_cast<const uint32_t *>(pin_res.p);
+      bool resume = false, force_wg = false;
+      answered_pending = false;
+      for (;;) {
+        uint32_t done[2] = {0, 0};
+        const bool wave = !force_wg && cur_nodes <= 64;
+        at.par = round & 1u;
+        if (wave) hipLaunchKernelGGL(dec_tail64_kernel, dim3(1), dim3(64), 0, c->stream, at, 1u << 30, d_rounds, resume ? 1u : 0u);
+        else hipLaunchKernelGGL(dec_tail_kernel, dim3(1), dim3(DT_T), 0, c->stream, at, 1u << 30, d_rounds, (resume ? 1u : 0u) | 2u);
+        BCE_HIP_TRY(c, hipMemcpyAsync(done, d_rounds, 8, hipMemcpyDeviceToHost, c->stream));
+        BCE_HIP_TRY(c, hipMemcpyAsync(&ctl, c->ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
+        BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        BCE_HIP_TRY(c, hipGetLastError());
+        if (getenv("BCE_DEC_TRACE")) fprintf(stderr, "tail: round %u wave %d resume %d -> done %u why %u next %u\n", round, (int)wave, (int)resume, done[0], done[1], ctl.next_nodes);
         round += done[0]; tail_rounds += done[0];
         cur_nodes = ctl.next_nodes;
         nodes_total = ctl.nodes_total;
-        t_c += now_s() - t0;
-        continue;
-      }
-      if (wave && done[1] == 2) {                               // the children outgrow one wave: the workgroup version
-        hipLaunchKernelGGL(dec_tail_kernel, dim3(1), dim3(DT_T), 0, c->stream, a, 1u << 30, d_rounds);
-        BCE_HIP_TRY(c, hipMemcpyAsync(done, d_rounds, 4, hipMemcpyDeviceToHost, c->stream));
-        BCE_HIP_TRY(c, hipMemcpyAsync(&ctl, c->ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
-        BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (done[0]) {
-          round += done[0]; tail_rounds += done[0];
-          cur_nodes = ctl.next_nodes;
-          nodes_total = ctl.nodes_total;
-          t_c += now_s() - t0;
+        // a resumed launch that could not even start its round (children outgrow the kernel, or an inconsistency):
+        // the decoders have ALREADY answered this round's queries -- whoever runs the round must reuse the answers
+        const bool stuck = resume && done[0] == 0 && done[1] >= 2;
+        resume = false;
+        force_wg = false;
+        if (done[1] == 1) {                                      // queries of round `round` are in pin_q / pin_e
+          const DecInfo in = *info;
+          uint64_t qt = 0;
+          for (int p = 0; p < 8; ++p) {
+            QueryPool::answer(hd.dec[p], at.Q + in.qbase[p], at.E + in.ebase[p], static_cast<uint32_t *>(pin_res.p) + in.qbase[p], in.qtot[p]);
+            qt += in.qtot[p];
+          }
+          queries_total += qt;
+          resume = true;
           continue;
         }
+        if (wave && done[1] == 2 && cur_nodes <= DT_CAP) {       // the children outgrow one wave: the workgroup kernel
+          force_wg = true;
+          resume = stuck;                                        // ... with the answers, if this round already has them
+          continue;
+        }
+        answered_pending = stuck;
+        if (done[1] == 0 && done[0] && cur_nodes && cur_nodes <= DT_ENTER) continue;   // handed back (few nodes again) or out of max_rounds
+        break;                                                   // nothing left, too many nodes (2) or an inconsistent node (3)
       }
+      a.par = round & 1u;
+      t_c += now_s() - t0;
+      t0 = now_s();
+      if (c->progress) c->progress(nodes_total, 8ull * n, c->progress_user);
+      if (!cur_nodes) break;
     }
     BCE_TRY(ensure(c, Qbuf, (size_t)(cur_nodes + 16) * 4));
     BCE_TRY(ensure(c, Ebuf, (size_t)(cur_nodes + 16) * sizeof(uint4)));
@@ -977,7 +1114,10 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
     if (in.err) { snprintf(c->err, sizeof c->err, "decode: inconsistent archive (round %u)", round); return BCE_HIP_E_INTERNAL; }
     uint64_t qtotal = 0, etotal = 0;
     for (int p = 0; p < 8; ++p) { qtotal += in.qtot[p]; etotal += in.etot[p]; }
-    if (qtotal) {
+    if (qtotal && answered_pending) {
+      // the tail kernel emitted exactly these queries (same order) and the decoders answered them: do not ask twice
+      BCE_HIP_TRY(c, hipMemcpyAsync(Rsbuf.p, pin_res.p, qtotal * 4, hipMemcpyHostToDevice, c->stream));
+    } else if (qtotal) {
       BCE_TRY(pin_q.ensure(c, qtotal * 4));
       BCE_TRY(pin_e.ensure(c, (etotal + 1) * sizeof(uint4)));
       BCE_TRY(pin_res.ensure(c, qtotal * 4));
@@ -992,6 +1132,7 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
       { const double t1 = now_s(); t_host += t1 - t0; t0 = t1; }
       BCE_HIP_TRY(c, hipMemcpyAsync(Rsbuf.p, pin_res.p, qtotal * 4, hipMemcpyHostToDevice, c->stream));
     }
+    answered_pending = false;
     hipLaunchKernelGGL((dec_tiles_kernel<2>), dim3(grid), dim3(K3_T), 0, c->stream, a);
     hipLaunchKernelGGL((dec_scan_kernel<false>), dim3(8), dim3(1024), 0, c->stream, a);
     hipLaunchKernelGGL((dec_tiles_kernel<3>), dim3(grid), dim3(K3_T), 0, c->stream, a);
