@@ -26,6 +26,8 @@ constexpr uint32_t KD_MAXX = 2048;             // rows compared for a chain skip
 constexpr uint32_t KD_NEAR = 256;              // bytes compared one lane per row before the whole wave takes one pair
 constexpr uint32_t KD_WALKERS = 1u << 17;      // walkers per pass (each takes several queued nodes when more are queued)
 constexpr uint32_t KD_QUEUE = 4u << 20;        // queued nodes between passes
+constexpr uint32_t KD_SBLK = 8;                // tagged-symbol slots a walker reserves at a time (one atomic with return per 8 symbols)
+constexpr uint32_t KD_HOLE = 0x7FFu;           // (plane, round high) of an unused slot: sorts behind every real symbol
 constexpr uint32_t K3_DFS_PASS = 4096;         // nodes one walker classifies per pass before it hands its work on
 
 struct DfsCtl {
@@ -198,10 +200,13 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   uint64_t nodes = 0, maxround = 0;
   uint32_t visited = 0;
   uint32_t quiet = 8;                                         // pass-through nodes in a row (8 = one whole byte)
+  uint32_t sbase = 0, sused = KD_SBLK;                        // my block of tagged-symbol slots (none yet)
+  uint32_t seen_err = 0;
   // All 64 lanes stay in the loop until every walker of the wave is finished: finished lanes help with the
   // cooperative text comparisons.
   while (__any(alive)) {
-    if (alive && (visited >= a.budget || a.dctl->err)) {
+    if ((visited & 31u) == 0) seen_err = a.dctl->err;          // a long chain should not wait for this load on every node
+    if (alive && (visited >= a.budget || seen_err)) {
       // hand on: current node, stack, queued nodes not started
       uint32_t rest = 0;
       if (next < a.in_count) rest = (a.in_count - next + W - 1u) / W;
@@ -253,9 +258,11 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
       maxround = cur.round > maxround ? cur.round : maxround;
       quiet = (nf.need_mid || (has0 && has1)) ? 0u : quiet + 1u;
       if (nf.need_mid) {
-        const uint32_t i = atomicAdd(&a.dctl->nsym, 1u);
-        if (i >= a.symcap) { a.dctl->err = 2; alive = false; }
+        if (sused == KD_SBLK) { sbase = atomicAdd(&a.dctl->nsym, KD_SBLK); sused = 0; }
+        const uint32_t i = sbase + sused;
+        if (sbase + KD_SBLK > a.symcap) { a.dctl->err = 2; alive = false; sused = KD_SBLK; }
         else {
+          ++sused;
           uint32_t kw, ew;
           pack_symbol(k.cfg[p], p, sym, kq, nf.n0x, nd.x1, nd.x0 + nd.x1, kw, ew);
           a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = nd.s;
@@ -285,6 +292,8 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
       else alive = false;
     }
   }
+  // the unused slots of my last block are holes: they sort behind every real symbol and are cut off by the host
+  for (uint32_t j = sused; j < KD_SBLK; ++j) { a.ts[sbase + j] = 0; a.trlo[sbase + j] = 0; a.trhi[sbase + j] = KD_HOLE; }
   if (a.dbg) atomicMax(&a.dctl->dbg_maxvis, visited);
   atomicAdd((unsigned long long *)&a.dctl->nodes, (unsigned long long)nodes);
   atomicMax((unsigned long long *)&a.dctl->maxround, (unsigned long long)maxround);
@@ -378,8 +387,10 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) 
     for (int i = 0; i < 32; ++i) if (h.dbg_hist[i]) fprintf(stderr, "  x in [2^%d, 2^%d): %u nodes\n", i, i + 1, h.dbg_hist[i]);
   }
   if (h.err) return BCE_HIP_OK;                     // fall back to the rounds; nothing was modified
-  const uint32_t m = h.nsym;
-  if (m > c->sym_cap) BCE_TRY(k3_grow_symbols(c, (uint64_t)m + 1024));
+  const uint32_t m = h.nsym;                         // reserved slots (real symbols + holes)
+  uint32_t mv = 0;                                   // real symbols
+  for (int p = 0; p < 8; ++p) mv += h.cntp[p];
+  if (mv > c->sym_cap) BCE_TRY(k3_grow_symbols(c, (uint64_t)mv + 1024));
   if (m) {
     // stream order inside a coder = (round, s); planes are separated: LSD sort by s, round low, (plane, round high)
     const uint32_t g = (m + 255) / 256 < 2048 ? (m + 255) / 256 : 2048;
@@ -392,12 +403,12 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) 
     uint32_t *k3[2] = {k2[r ^ 1], k2[r]}, *v3[2] = {v2[r], v2[r ^ 1]};
     hipLaunchKernelGGL(kd_gather_kernel, dim3(g), dim3(256), 0, c->stream, a.trhi, v3[0], m, k3[0]);
     BCE_TRY(radix_sort_pairs(c, k3, v3, m, 0, 11, &r));
-    hipLaunchKernelGGL(kd_place_kernel, dim3(g), dim3(256), 0, c->stream, a.tkey, a.tesc, v3[r], m,
+    hipLaunchKernelGGL(kd_place_kernel, dim3(g), dim3(256), 0, c->stream, a.tkey, a.tesc, v3[r], mv,   // the holes sorted last
                        c->skey[0].as<uint32_t>(), c->sesc.as<uint32_t>());
   }
   // control block: the enumeration is finished
   EnumCtl *d = c->ctl.as<EnumCtl>();
-  const uint64_t symtot = m, nodes = ctl.nodes_total + h.nodes;
+  const uint64_t symtot = mv, nodes = ctl.nodes_total + h.nodes;
   const uint32_t done_round = (uint32_t)(h.maxround + 1 > 0xFFFFFFFEull ? 0xFFFFFFFEull : h.maxround + 1);
   BCE_HIP_TRY(c, hipMemcpyAsync(&d->sym_total, &symtot, 8, hipMemcpyHostToDevice, c->stream));
   BCE_HIP_TRY(c, hipMemcpyAsync(&d->nodes_total, &nodes, 8, hipMemcpyHostToDevice, c->stream));
