@@ -26,6 +26,7 @@ constexpr uint32_t KD_MAXX = 2048;             // rows compared for a chain skip
 constexpr uint32_t KD_NEAR = 256;              // bytes compared one lane per row before the whole wave takes one pair
 constexpr uint32_t KD_WALKERS = 1u << 17;      // walkers per pass (each takes several queued nodes when more are queued)
 constexpr uint32_t KD_QUEUE = 4u << 20;        // queued nodes between passes
+constexpr uint32_t KD_UNI_MAX = 4096;           // up to this many queued walkers a pass gives every walker a wave of its own
 constexpr uint32_t KD_SBLK = 8;                // tagged-symbol slots a walker reserves at a time (one atomic with return per 8 symbols)
 constexpr uint32_t KD_HOLE = 0x7FFu;           // (plane, round high) of an unused slot: sorts behind every real symbol
 constexpr uint32_t K3_DFS_PASS = 4096;         // nodes one walker classifies per pass before it hands its work on
@@ -165,15 +166,35 @@ __device__ __forceinline__ uint32_t chain_bytes(const DfsArgs &a, uint32_t s, ui
   return kk == n - 1 ? 0u : kk;                               // every row identical: cannot happen for a live node
 }
 
-// One pass of the walkers.  Lane = walker.  A walker takes queued nodes gid, gid + W, ... and walks each subtree
+// One pass of the walkers.  Lane = walker (UNI = false), or WAVE = walker (UNI = true, few walkers left: every value
+// of the walk then depends on blockIdx only, so the compiler keeps it in scalar registers and runs the ~300
+// instructions of a node on the scalar unit instead of issuing them for 64 lanes of which one works; the lanes
+// are still there for the cooperative text comparisons of the chain skip).  A walker takes queued nodes gid, gid + W, ... and walks each subtree
 // depth-first; after a.budget classified nodes it hands everything it still holds (current node, stack, queued
 // nodes not started) to the next pass, where each of those gets a walker of its own: that is the load balancing.
+template <bool UNI>
 __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
+  __shared__ DNode lstack[UNI ? KD_STACK : 1];
   const K3Args &k = a.k;
   const EnumCtl *ctl = k.ctl;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t gid = blockIdx.x * KD_T + threadIdx.x;
-  const uint32_t W = gridDim.x * KD_T;
+  const uint32_t gid = UNI ? blockIdx.x : blockIdx.x * KD_T + threadIdx.x;
+  const uint32_t W = UNI ? gridDim.x : gridDim.x * KD_T;
+  const bool writer = !UNI || lane == 0;                     // side effects of a wave-walker: one lane
+  // A value a vector load returned is "divergent" to the compiler even when every lane loaded the same address:
+  // readfirstlane moves it to a scalar register, and everything computed from it follows.
+  auto uni = [&](uint32_t v) -> uint32_t { return UNI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v) : v; };
+  auto uni_gran = [&](const Granule &g) -> Granule { return Granule{uni(g.cum), uni(g.w0), uni(g.w1), uni(g.w2)}; };
+  auto uni_node = [&](const DNode &d) -> DNode {
+    return DNode{uni(d.s), uni(d.x0), uni(d.x1), uni(d.plane), ((uint64_t)uni((uint32_t)(d.round >> 32)) << 32) | uni((uint32_t)d.round)};
+  };
+  // an atomic whose result every lane of a wave-walker needs
+  auto uni_add = [&](uint32_t *ptr, uint32_t v) -> uint32_t {
+    if (!UNI) return atomicAdd(ptr, v);
+    uint32_t r = 0;
+    if (lane == 0) r = atomicAdd(ptr, v);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+  };
   const uint32_t n = k.n;
   uint32_t pbase[9];
   {
@@ -183,19 +204,19 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
     pbase[8] = acc;
   }
   auto fetch = [&](uint32_t q) -> DNode {                     // queued node q of this pass
-    if (a.in) return a.in[q];
+    if (a.in) return uni_node(a.in[q]);
     uint32_t p = 0;
 #pragma unroll
     for (uint32_t j = 1; j < 8; ++j) p += q >= pbase[j] ? 1u : 0u;
     const uint32_t idx = q - pbase[p], c0 = ctl->cnt[k.par][p][0];
     const Node nd = plane_nodes(k, k.par, p)[idx < c0 ? idx : (k.capP - 1u - (idx - c0))];
-    return DNode{nd.s, nd.x0, nd.x1, p, a.round0};
+    return uni_node(DNode{nd.s, nd.x0, nd.x1, p, a.round0});
   };
   uint32_t next = gid;                                        // my next queued node
   bool alive = next < a.in_count;
   DNode cur{0u, 1u, 1u, 1u, 0ull};
   if (alive) { cur = fetch(next); next += W; }
-  DNode *stack = a.stacks + (size_t)gid * KD_STACK;
+  DNode *stack = UNI ? lstack : a.stacks + (size_t)gid * KD_STACK;     // a wave-walker's stack: LDS, every lane writes the same
   uint32_t sp = 0;
   uint64_t nodes = 0, maxround = 0;
   uint32_t visited = 0;
@@ -205,15 +226,15 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   // All 64 lanes stay in the loop until every walker of the wave is finished: finished lanes help with the
   // cooperative text comparisons.
   while (__any(alive)) {
-    if ((visited & 31u) == 0) seen_err = a.dctl->err;          // a long chain should not wait for this load on every node
+    if ((visited & 31u) == 0) seen_err = uni(a.dctl->err);          // a long chain should not wait for this load on every node
     if (alive && (visited >= a.budget || seen_err)) {
       // hand on: current node, stack, queued nodes not started
       uint32_t rest = 0;
       if (next < a.in_count) rest = (a.in_count - next + W - 1u) / W;
       const uint32_t cnt = 1u + sp + rest;
-      const uint32_t o = atomicAdd(&a.dctl->queued, cnt);
+      const uint32_t o = uni_add(&a.dctl->queued, cnt);
       if (o + cnt > a.out_cap) { a.dctl->err = 4; }
-      else {
+      else if (writer) {
         a.out[o] = cur;
         for (uint32_t j = 0; j < sp; ++j) a.out[o + 1u + j] = stack[j];
         for (uint32_t j = 0; j < rest; ++j) a.out[o + 1u + sp + j] = fetch(next + j * W);
@@ -223,62 +244,65 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
     // ---- chain skip: lanes at plane 0 after a whole byte of pass-through, served one after the other by the wave ----
     const uint32_t x = cur.x0 + cur.x1;
     uint64_t want = __ballot(alive && a.skip_ok && cur.plane == 0 && x <= KD_MAXX && quiet >= 8u);
+    if (UNI) want &= 1ull;                                     // one walker per wave: one request
     uint32_t mykk = 0;
     while (want) {
       const int L = __ffsll((long long)want) - 1;
       want &= want - 1;
       const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)cur.s, L);
       const uint32_t xL = (uint32_t)__builtin_amdgcn_readlane((int)x, L);
-      const uint32_t kk = chain_bytes(a, sL, xL, lane);
-      if ((int)lane == L) { mykk = kk; if (!kk) quiet = 0; }
+      const uint32_t kk = uni(chain_bytes(a, sL, xL, lane));
+      if (UNI || (int)lane == L) { mykk = kk; if (!kk) quiet = 0; }
     }
     if (alive) {
       ++visited;
       if (mykk) {                                    // mykk whole bytes of pass-through: 8*mykk rounds, no symbols
-        const uint32_t pa = a.sa[cur.s];
-        cur.s = a.isa[cyc_back(pa, mykk, n)];
+        const uint32_t pa = uni(a.sa[cur.s]);
+        cur.s = uni(a.isa[cyc_back(pa, mykk, n)]);
         cur.round += 8ull * mykk;
         nodes += 8ull * mykk;
-        if (a.dbg) { atomicAdd(&a.dctl->dbg_skips, 1u); atomicAdd((unsigned long long *)&a.dctl->dbg_skipbytes, (unsigned long long)mykk); }
+        if (a.dbg && writer) { atomicAdd(&a.dctl->dbg_skips, 1u); atomicAdd((unsigned long long *)&a.dctl->dbg_skipbytes, (unsigned long long)mykk); }
       }
       const uint32_t p = cur.plane;
       const Granule *G = k.gran + (size_t)p * k.ngran;
       const Node nd{cur.s, cur.x0, cur.x1};
       const uint32_t ga = div96(nd.s), gb = div96(nd.s + nd.x0 + nd.x1), gm = div96(nd.s + nd.x0);
-      const Granule qa = G[ga], qb = G[gb];
+      const Granule qa = uni_gran(G[ga]), qb = uni_gran(G[gb]);
       NodeFlat nf;
       node_flat_pre(nd, granule_rank1(qa, nd.s - ga * 96u), granule_rank1(qb, nd.s + nd.x0 + nd.x1 - gb * 96u), nf);
       Granule qm = gm == ga ? qa : qb;
-      if (nf.need_mid && gm != ga && gm != gb) qm = G[gm];
+      if (nf.need_mid && gm != ga && gm != gb) qm = uni_gran(G[gm]);
       uint32_t has0, has1, sym, kq;
       Node c0, c1;
       node_flat_post(nd, k.zeros[p], nf, granule_rank1(qm, nd.s + nd.x0 - gm * 96u), has0, c0, has1, c1, sym, kq);
       ++nodes;
-      if (a.dbg) atomicAdd(&a.dctl->dbg_hist[31 - __clz((int)(nd.x0 + nd.x1))], 1u);
+      if (a.dbg && writer) atomicAdd(&a.dctl->dbg_hist[31 - __clz((int)(nd.x0 + nd.x1))], 1u);
       maxround = cur.round > maxround ? cur.round : maxround;
       quiet = (nf.need_mid || (has0 && has1)) ? 0u : quiet + 1u;
       if (nf.need_mid) {
-        if (sused == KD_SBLK) { sbase = atomicAdd(&a.dctl->nsym, KD_SBLK); sused = 0; }
+        if (sused == KD_SBLK) { sbase = uni_add(&a.dctl->nsym, KD_SBLK); sused = 0; }
         const uint32_t i = sbase + sused;
         if (sbase + KD_SBLK > a.symcap) { a.dctl->err = 2; alive = false; sused = KD_SBLK; }
         else {
           ++sused;
           uint32_t kw, ew;
           pack_symbol(k.cfg[p], p, sym, kq, nf.n0x, nd.x1, nd.x0 + nd.x1, kw, ew);
-          a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = nd.s;
-          a.trlo[i] = (uint32_t)cur.round;
-          a.trhi[i] = (uint32_t)(cur.round >> 32) | (p << 8);      // round < 2^40
-          atomicAdd(&a.dctl->cntp[p], 1u);
+          if (writer) {
+            a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = nd.s;
+            a.trlo[i] = (uint32_t)cur.round;
+            a.trhi[i] = (uint32_t)(cur.round >> 32) | (p << 8);      // round < 2^40
+            atomicAdd(&a.dctl->cntp[p], 1u);
+          }
         }
       }
       const uint32_t pn = (p + 1u) & 7u;
       if (has0 && has1) {
         if (sp >= KD_STACK) {                                // full: the older half becomes queued nodes of the next pass
           const uint32_t h = KD_STACK / 2;
-          const uint32_t o = atomicAdd(&a.dctl->queued, h);
+          const uint32_t o = uni_add(&a.dctl->queued, h);
           if (o + h > a.out_cap) { a.dctl->err = 4; alive = false; }
           else {
-            for (uint32_t j = 0; j < h; ++j) a.out[o + j] = stack[j];
+            if (writer) for (uint32_t j = 0; j < h; ++j) a.out[o + j] = stack[j];
             for (uint32_t j = h; j < sp; ++j) stack[j - h] = stack[j];
             sp -= h;
           }
@@ -287,12 +311,13 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
       }
       if (has0) { cur = DNode{c0.s, c0.x0, c0.x1, pn, cur.round + 1}; }
       else if (has1) { cur = DNode{c1.s, c1.x0, c1.x1, pn, cur.round + 1}; }
-      else if (sp) { cur = stack[--sp]; quiet = 8; }
+      else if (sp) { cur = uni_node(stack[--sp]); quiet = 8; }
       else if (next < a.in_count) { cur = fetch(next); next += W; quiet = 8; }
       else alive = false;
     }
   }
   // the unused slots of my last block are holes: they sort behind every real symbol and are cut off by the host
+  if (!writer) return;
   for (uint32_t j = sused; j < KD_SBLK; ++j) { a.ts[sbase + j] = 0; a.trlo[sbase + j] = 0; a.trhi[sbase + j] = KD_HOLE; }
   if (a.dbg) atomicMax(&a.dctl->dbg_maxvis, visited);
   atomicAdd((unsigned long long *)&a.dctl->nodes, (unsigned long long)nodes);
@@ -369,7 +394,10 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) 
   for (;;) {
     a.in = in; a.in_count = count; a.out = queue[passes & 1];
     const uint32_t walkers = count < wmax ? count : wmax;
-    hipLaunchKernelGGL(k3_dfs_kernel, dim3((walkers + KD_T - 1) / KD_T), dim3(KD_T), 0, c->stream, a);
+    if (passes > 0 && count <= KD_UNI_MAX && !getenv("BCE_HIP_DFS_NO_UNI"))   // few walkers left: one WAVE each
+      hipLaunchKernelGGL(k3_dfs_kernel<true>, dim3(count), dim3(KD_T), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL(k3_dfs_kernel<false>, dim3((walkers + KD_T - 1) / KD_T), dim3(KD_T), 0, c->stream, a);
     BCE_HIP_TRY(c, hipMemcpyAsync(&h, a.dctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
     BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
     BCE_HIP_TRY(c, hipGetLastError());
