@@ -15,7 +15,7 @@ import oracle    # noqa: E402
 
 
 def gen(rs, n):
-    kind = rs.randint(0, 9)
+    kind = rs.randint(0, 10)
     if kind in (2, 3, 8) and n > 60000:      # long exact repeats: the CPU oracle walks them bit by bit (minutes at MBs)
         n = 20000 + n % 40000
     if kind == 0:
@@ -44,6 +44,14 @@ def gen(rs, n):
         return rs.randint(0, 256, n).astype(np.uint8)
     if kind == 7:
         return (rs.randint(0, 1 << rs.randint(1, 5), n).astype(np.uint8) << rs.randint(0, 5)).astype(np.uint8)
+    if kind == 9:          # long runs of one byte inside other data (executables): chains that cannot be skipped
+        base = rs.randint(0, 256, n).astype(np.uint8) if rs.randint(0, 2) else np.frombuffer(oracle.synth_text(int(rs.randint(1, 10 ** 6)), n), dtype=np.uint8).copy()
+        for _ in range(rs.randint(1, 6)):
+            if n > 10:
+                L = rs.randint(2, max(3, min(n // 2, 60000)))
+                at = rs.randint(0, n - L)
+                base[at:at + L] = rs.choice([0, 0, 255, 32, rs.randint(0, 256)])
+        return base
     blk = np.frombuffer(oracle.synth_text(int(rs.randint(1, 10 ** 6)), max(50, n // rs.randint(3, 200))), dtype=np.uint8)
     return np.tile(blk, n // len(blk) + 1)[:n].copy()
 
