@@ -12,6 +12,8 @@
 // bytes), and they end at row ISA[SA[s] - k], 8k rounds later, with (x0, x1) unchanged.  k is found by comparing
 // the text backwards from the x suffix-array positions (exact, no hashing).  SA / ISA are K1's arrays; the skip
 // is disabled when K1 did not end with all rotations distinct (periodic inputs) or the BWT was injected.
+// Chains that cannot be skipped but are regular (runs of one byte, periodic tables) are expanded in closed form:
+// see stair_run.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -29,6 +31,8 @@ constexpr uint32_t KD_QUEUE = 4u << 20;        // queued nodes between passes
 constexpr uint32_t KD_UNI_MAX = 4096;           // up to this many queued walkers a pass gives every walker a wave of its own
 constexpr uint32_t KD_SBLK = 8;                // tagged-symbol slots a walker reserves at a time (one atomic with return per 8 symbols)
 constexpr uint32_t KD_HOLE = 0x7FFu;           // (plane, round high) of an unused slot: sorts behind every real symbol
+constexpr uint32_t KD_STAIR_MIN = 32;            // rows from which a walker at plane 0 looks for a staircase (see stair_run)
+constexpr uint32_t KD_STAIR_RETRY = 256;         // nodes a walker waits after a failed look
 constexpr uint32_t K3_DFS_PASS = 4096;         // nodes one walker classifies per pass before it hands its work on
 
 struct DfsCtl {
@@ -40,9 +44,11 @@ struct DfsCtl {
   uint32_t queued;       // nodes handed to the next pass
   uint32_t pad;
   uint32_t dbg_hist[32]; uint32_t dbg_maxvis; uint32_t dbg_skips; uint64_t dbg_skipbytes;
+  uint32_t dbg_stairs, dbg_stairsyms; uint64_t dbg_stairnodes;
 };
 
 struct DNode { uint32_t s, x0, x1, plane; uint64_t round; };
+typedef __attribute__((address_space(4))) Granule ConstGranule;
 
 struct DfsArgs {
   K3Args k;
@@ -61,6 +67,13 @@ struct DfsArgs {
   uint32_t dbg;
 };
 
+// granule_rank1 with 64-bit masks (fewer scalar instructions)
+__device__ __forceinline__ uint32_t rank1_64(const Granule &g, uint32_t o) {
+  const uint64_t lo = (uint64_t)g.w0 | ((uint64_t)g.w1 << 32);
+  const uint64_t m = o >= 64u ? ~0ull : ((1ull << o) - 1ull);
+  const uint32_t m2 = o > 64u ? ((1u << (o - 64u)) - 1u) : 0u;
+  return g.cum + (uint32_t)__popcll(lo & m) + (uint32_t)__popc(g.w2 & m2);
+}
 __device__ __forceinline__ uint32_t ld32u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
@@ -166,6 +179,79 @@ __device__ __forceinline__ uint32_t chain_bytes(const DfsArgs &a, uint32_t s, ui
   return kk == n - 1 ? 0u : kk;                               // every row identical: cannot happen for a live node
 }
 
+// Staircase: the chain below a node whose x rows are the rotations at text positions a, a + p, ..., a + (x-1) p
+// inside a region of period p (a long run of one byte is p = 1; tables of equal records are p = record size).
+// Such a chain cannot be skipped -- every p bytes the row that reaches the start of the region meets a different
+// preceding byte and leaves, which codes one symbol -- and walking it is 8 nodes per byte of the region, one after
+// the other.  But it is entirely regular.  With a' = the start of the region (T[a'-1] = d differs from
+// c = T[a'-1+p], T[j] = T[j+p] from a' on), B = a - a', j* = the lowest bit in which c and d differ:
+//   * the first B bytes are pass-through for all rows;
+//   * event e = 0, 1, ... happens 8 (B + e p) rounds below the node, at plane j*: the rows are the positions
+//     a' + m p, m < x - e; all of them are preceded by c except a' (the first row if rows ascend with positions,
+//     else the last), so the node there has one row with the other bit: k = 2, the symbol says on which side of
+//     the x0 | x1 boundary that row is (always the same side), contexts (_0x, x1, x) = (x-e-1 or 1, x1, x-e);
+//     the row leaves without a child of its own, the other x-e-1 rows go on;
+//   * the side the leaving row is on shrinks by one per event; when it is empty the chain ends: xs = x0 or x1 events.
+// The plane-0 position of the node at event e is ISA[a'] or ISA[a' + (x-e-1) p]; its position in plane j* (the
+// symbol's sort key) follows through j* pass-through levels.  So the events are independent of each other: one
+// lane each.  Everything is checked exactly (suffix-array stride, periodicity by comparing the text), nothing is
+// assumed about why the rows are there.  Whole wave, uniform arguments; returns false if the node is no staircase.
+__device__ __forceinline__ uint32_t rank1_plane(const K3Args &k, uint32_t p, uint32_t pos) {
+  const uint32_t g = div96(pos);
+  return granule_rank1((k.gran + (size_t)p * k.ngran)[g], pos - g * 96u);
+}
+__device__ __forceinline__ bool stair_run(const DfsArgs &a, uint32_t s, uint32_t x0, uint32_t x1, uint64_t round, uint32_t lane,
+                                       uint64_t &nodes_out, uint64_t &maxround_out) {
+  const K3Args &k = a.k;
+  const uint32_t n = k.n, x = x0 + x1;
+  const uint32_t pa = a.sa[s], pb = a.sa[s + 1], pz = a.sa[s + x - 1];
+  const bool asc = pb > pa;
+  const uint32_t p = asc ? pb - pa : pa - pb;
+  const uint64_t span = (uint64_t)(x - 1) * p;
+  if (p == 0 || (asc ? (uint64_t)pa + span != pz : (uint64_t)pz + span != pa)) return false;
+  const uint32_t lo = asc ? pa : pz;                          // a
+  if ((uint64_t)lo + span + p > n) return false;              // the comparison below would wrap
+  bool bad = false;
+  for (uint32_t i = lane; i < x; i += 64) bad |= a.sa[s + i] != (asc ? pa + i * p : pa - i * p);
+  if (__any(bad)) return false;
+  // T[j] == T[j + p] on [a', a + (x-1) p) and the first byte before that where it fails
+  const uint32_t p1 = lo + (uint32_t)span, lim = p1 - 1u;
+  const uint32_t lce = lce_back_wave(a.text, n, p1, p1 + p, lim, lane);
+  if (lce >= lim || lce < span) return false;                 // reaches the start of the text / not periodic
+  const uint32_t B = lce - (uint32_t)span, as = lo - B;       // as >= 2
+  const uint32_t d = a.text[as - 1u], c = a.text[as - 1u + p];
+  const uint32_t js = (uint32_t)__ffs((int)(c ^ d)) - 1u, cb = (c >> js) & 1u;
+  const uint32_t L0 = asc ? 1u : 0u;                          // the leaving row is among the first x0 rows
+  const uint32_t xs = L0 ? x0 : x1;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(&a.dctl->nsym, xs);
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  if ((uint64_t)base + xs > a.symcap) { a.dctl->err = 2; nodes_out = 0; maxround_out = 0; return true; }
+  for (uint32_t e = lane; e < xs; e += 64) {
+    const uint32_t xe0 = x0 - (L0 ? e : 0u), xe1 = x1 - (L0 ? 0u : e), xe = xe0 + xe1;
+    uint32_t pos = a.isa[asc ? as : as + (xe - 1u) * p];
+    for (uint32_t q = 0; q < js; ++q) {
+      const uint32_t r = rank1_plane(k, q, pos);
+      pos = ((c >> q) & 1u) ? k.zeros[q] + r : pos - r;
+    }
+    uint32_t kw, ew;
+    pack_symbol(k.cfg[js], js, cb ? L0 : 1u - L0, 2u, cb ? 1u : xe - 1u, xe1, xe, kw, ew);
+    const uint64_t r = round + 8ull * ((uint64_t)B + (uint64_t)e * p) + js;
+    const uint32_t i = base + e;
+    a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = pos;
+    a.trlo[i] = (uint32_t)r;
+    a.trhi[i] = (uint32_t)(r >> 32) | (js << 8);
+  }
+  if (lane == 0) {
+    atomicAdd(&a.dctl->cntp[js], xs);
+    if (a.dbg) { atomicAdd(&a.dctl->dbg_stairs, 1u); atomicAdd(&a.dctl->dbg_stairsyms, xs); }
+  }
+  const uint64_t bytes = (uint64_t)B + (uint64_t)(xs - 1u) * p;
+  nodes_out = 8ull * bytes + js + 1u;
+  maxround_out = round + 8ull * bytes + js;
+  return true;
+}
+
 // One pass of the walkers.  Lane = walker (UNI = false), or WAVE = walker (UNI = true, few walkers left: every value
 // of the walk then depends on blockIdx only, so the compiler keeps it in scalar registers and runs the ~300
 // instructions of a node on the scalar unit instead of issuing them for 64 lanes of which one works; the lanes
@@ -184,7 +270,6 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   // A value a vector load returned is "divergent" to the compiler even when every lane loaded the same address:
   // readfirstlane moves it to a scalar register, and everything computed from it follows.
   auto uni = [&](uint32_t v) -> uint32_t { return UNI ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v) : v; };
-  auto uni_gran = [&](const Granule &g) -> Granule { return Granule{uni(g.cum), uni(g.w0), uni(g.w1), uni(g.w2)}; };
   auto uni_node = [&](const DNode &d) -> DNode {
     return DNode{uni(d.s), uni(d.x0), uni(d.x1), uni(d.plane), ((uint64_t)uni((uint32_t)(d.round >> 32)) << 32) | uni((uint32_t)d.round)};
   };
@@ -223,6 +308,12 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   uint32_t quiet = 8;                                         // pass-through nodes in a row (8 = one whole byte)
   uint32_t sbase = 0, sused = KD_SBLK;                        // my block of tagged-symbol slots (none yet)
   uint32_t seen_err = 0;
+  uint32_t stair_next = 0;                                    // visited count from which I look for a staircase again
+  auto pop = [&]() {                                          // this subtree is finished: the next pending one
+    if (sp) { cur = uni_node(stack[--sp]); quiet = 8; }
+    else if (next < a.in_count) { cur = fetch(next); next += W; quiet = 8; }
+    else alive = false;
+  };
   // All 64 lanes stay in the loop until every walker of the wave is finished: finished lanes help with the
   // cooperative text comparisons.
   while (__any(alive)) {
@@ -254,7 +345,37 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
       const uint32_t kk = uni(chain_bytes(a, sL, xL, lane));
       if (UNI || (int)lane == L) { mykk = kk; if (!kk) quiet = 0; }
     }
-    if (alive) {
+    // ---- staircase: a node of many rows at plane 0 whose rows are equally spaced text positions (stair_run) ----
+    bool consumed = false;
+    {
+      bool cand = alive && a.skip_ok && cur.plane == 0 && x >= KD_STAIR_MIN && visited >= stair_next;
+      if (cand) {                                              // cheap look by the walker itself: first, second and last row
+        const uint32_t pa = a.sa[cur.s], pb = a.sa[cur.s + 1], pz = a.sa[cur.s + x - 1];
+        const uint64_t span = (uint64_t)(x - 1) * (pb > pa ? pb - pa : pa - pb);
+        cand = pb > pa ? (uint64_t)pa + span == pz : (uint64_t)pz + span == pa;
+        if (!cand) stair_next = visited + KD_STAIR_RETRY;
+      }
+      uint64_t wants = __ballot(cand);
+      if (UNI) wants &= 1ull;
+      while (wants) {
+        const int L = __ffsll((long long)wants) - 1;
+        wants &= wants - 1;
+        const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)cur.s, L);
+        const uint32_t x0L = (uint32_t)__builtin_amdgcn_readlane((int)cur.x0, L), x1L = (uint32_t)__builtin_amdgcn_readlane((int)cur.x1, L);
+        const uint64_t rL = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur.round >> 32), L) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur.round, L);
+        uint64_t nn = 0, mr = 0;
+        const bool ok = stair_run(a, sL, x0L, x1L, rL, lane, nn, mr);
+        if (UNI || (int)lane == L) {
+          if (ok) { consumed = true; nodes += nn; maxround = mr > maxround ? mr : maxround; }
+          else stair_next = visited + KD_STAIR_RETRY;
+        }
+      }
+    }
+    if (alive && consumed) {
+      ++visited;
+      if (a.dctl->err) alive = false; else pop();
+    } else if (alive) {
       ++visited;
       if (mykk) {                                    // mykk whole bytes of pass-through: 8*mykk rounds, no symbols
         const uint32_t pa = uni(a.sa[cur.s]);
@@ -263,15 +384,45 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
         nodes += 8ull * mykk;
         if (a.dbg && writer) { atomicAdd(&a.dctl->dbg_skips, 1u); atomicAdd((unsigned long long *)&a.dctl->dbg_skipbytes, (unsigned long long)mykk); }
       }
+      if (UNI) {
+        // A wave-walker is on a long chain, and most of a chain is pass-through (all rows have the same bit): take those
+        // nodes in a loop that does nothing else -- two ranks, one comparison -- up to the next byte boundary, where
+        // the looks for a skip / a staircase above happen.
+        uint32_t s = cur.s, p = cur.plane, steps = 0;
+        const uint32_t xx = cur.x0 + cur.x1;
+        do {
+          // (the rank directory does not change during K3: constant address space + uniform index = scalar loads
+          //  through the scalar cache, which a chain that moves a row per byte keeps hitting)
+          const ConstGranule *G = (const ConstGranule *)(k.gran + (size_t)p * k.ngran);
+          const uint32_t ga = div96(s), gb = div96(s + xx);
+          const uint32_t zp = k.zeros[p];                    // all three loads in flight together
+          const Granule qa{G[ga].cum, G[ga].w0, G[ga].w1, G[ga].w2}, qb{G[gb].cum, G[gb].w0, G[gb].w1, G[gb].w2};
+          const uint32_t rs = rank1_64(qa, s - ga * 96u), n1x = rank1_64(qb, s + xx - gb * 96u) - rs;
+          if (n1x == 0) s -= rs;
+          else if (n1x == xx) s = zp + rs;
+          else break;
+          p = (p + 1u) & 7u;
+          ++steps;
+        } while (p != 0);
+        cur.s = s; cur.plane = p; cur.round += steps;
+        nodes += steps; quiet += steps;
+        if (steps && p == 0) { visited += steps - 1u; continue; }
+        visited += steps;
+      }
       const uint32_t p = cur.plane;
       const Granule *G = k.gran + (size_t)p * k.ngran;
+      auto ldg = [&](uint32_t g) -> Granule {                 // wave-walker: scalar load (see above)
+        if (!UNI) return G[g];
+        const ConstGranule *C = (const ConstGranule *)G;
+        return Granule{C[g].cum, C[g].w0, C[g].w1, C[g].w2};
+      };
       const Node nd{cur.s, cur.x0, cur.x1};
       const uint32_t ga = div96(nd.s), gb = div96(nd.s + nd.x0 + nd.x1), gm = div96(nd.s + nd.x0);
-      const Granule qa = uni_gran(G[ga]), qb = uni_gran(G[gb]);
+      const Granule qa = ldg(ga), qb = ldg(gb);
       NodeFlat nf;
       node_flat_pre(nd, granule_rank1(qa, nd.s - ga * 96u), granule_rank1(qb, nd.s + nd.x0 + nd.x1 - gb * 96u), nf);
       Granule qm = gm == ga ? qa : qb;
-      if (nf.need_mid && gm != ga && gm != gb) qm = uni_gran(G[gm]);
+      if (nf.need_mid && gm != ga && gm != gb) qm = ldg(gm);
       uint32_t has0, has1, sym, kq;
       Node c0, c1;
       node_flat_post(nd, k.zeros[p], nf, granule_rank1(qm, nd.s + nd.x0 - gm * 96u), has0, c0, has1, c1, sym, kq);
@@ -311,9 +462,7 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
       }
       if (has0) { cur = DNode{c0.s, c0.x0, c0.x1, pn, cur.round + 1}; }
       else if (has1) { cur = DNode{c1.s, c1.x0, c1.x1, pn, cur.round + 1}; }
-      else if (sp) { cur = uni_node(stack[--sp]); quiet = 8; }
-      else if (next < a.in_count) { cur = fetch(next); next += W; quiet = 8; }
-      else alive = false;
+      else pop();
     }
   }
   // the unused slots of my last block are holes: they sort behind every real symbol and are cut off by the host
@@ -409,9 +558,9 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) 
     BCE_HIP_TRY(c, hipMemsetAsync(&a.dctl->queued, 0, 4, c->stream));
   }
   if (a.dbg) {
-    fprintf(stderr, "dfs: live %u passes %u err %u nsym %u (cap %u) nodes %llu maxround %llu maxvisited %u skips %u skipbytes %llu\n", live,
+    fprintf(stderr, "dfs: live %u passes %u err %u nsym %u (cap %u) nodes %llu maxround %llu maxvisited %u skips %u skipbytes %llu stairs %u (%u symbols)\n", live,
             passes, h.err, h.nsym, cap, (unsigned long long)h.nodes, (unsigned long long)h.maxround, h.dbg_maxvis, h.dbg_skips,
-            (unsigned long long)h.dbg_skipbytes);
+            (unsigned long long)h.dbg_skipbytes, h.dbg_stairs, h.dbg_stairsyms);
     for (int i = 0; i < 32; ++i) if (h.dbg_hist[i]) fprintf(stderr, "  x in [2^%d, 2^%d): %u nodes\n", i, i + 1, h.dbg_hist[i]);
   }
   if (h.err) return BCE_HIP_OK;                     // fall back to the rounds; nothing was modified

@@ -126,3 +126,42 @@ def test_periodic_blocks_with_many_rows():
     for knobs in ({}, {3: 1}, {0: 5}):
         arch, _ = _encode_with_knobs(data, knobs)
         assert arch == want, "knobs %r" % (knobs,)
+
+
+def _region(unit, length):
+    return (unit * (length // len(unit) + 1))[:length]
+
+
+@pytest.mark.parametrize("case", ["zeros", "ff", "period2", "period3", "period7-in-random", "two-regions", "at-start", "at-end",
+                                  "record-table"])
+def test_staircase_chains_match_oracle(case):
+    """Long runs of one byte and periodic tables (executables): chains whose rows are equally spaced text positions.
+    The walkers expand them analytically (stair_run); every other path must give the same archive."""
+    import numpy as np
+    rs = np.random.RandomState(5)
+    text = oracle.synth_text(91, 60000)
+    rnd = rs.randint(0, 256, 60000).astype(np.uint8).tobytes()
+    if case == "zeros":
+        data = text[:30000] + bytes(9000) + text[30000:]
+    elif case == "ff":
+        data = text[:30000] + b"\xff" * 7000 + text[30000:] + b"\xff" * 100 + b"z"
+    elif case == "period2":
+        data = text[:20000] + _region(b"\x00\x02", 12001) + text[20000:]
+    elif case == "period3":
+        data = rnd[:20000] + _region(b"abc", 10000) + text[:20000] + _region(b"cab", 500) + rnd[20000:40000]
+    elif case == "period7-in-random":
+        data = rnd[:30000] + _region(b"\x01\x00\x00\x00\x00\x00\x80", 15000) + rnd[30000:]
+    elif case == "two-regions":     # the same pattern twice: the node is a staircase only below the shorter one
+        data = text[:20000] + bytes(6000) + text[20000:40000] + bytes(4000) + b"\x01" + bytes(300) + text[40000:]
+    elif case == "at-start":        # the region reaches position 0: the walkers must not take the shortcut blindly
+        data = bytes(5000) + text + _region(b"\x00\x07", 3000) + b"q"
+    elif case == "at-end":
+        data = text + _region(b"xy", 8000)
+    else:                           # 16-byte records that differ in one counter byte, then identical ones
+        data = text[:10000] + b"".join(b"REC" + bytes([i & 255]) + bytes(12) for i in range(300)) + (b"REC\x00" + bytes(12)) * 400 + text[10000:]
+    want = oracle.compress(data)
+    for knobs in ({}, {3: 1}, {0: 9}, {1: 1}):
+        arch, st = _encode_with_knobs(data, knobs)
+        assert arch == want, "knobs %r" % (knobs,)
+        assert st["nodes"] == 8 * len(data) - 8
+    assert bce_amd.decompress_device(want) == data

@@ -50,7 +50,11 @@ def gen(rs, n):
             if n > 10:
                 L = rs.randint(2, max(3, min(n // 2, 60000)))
                 at = rs.randint(0, n - L)
-                base[at:at + L] = rs.choice([0, 0, 255, 32, rs.randint(0, 256)])
+                if rs.randint(0, 2):
+                    base[at:at + L] = rs.choice([0, 0, 255, 32, rs.randint(0, 256)])
+                else:                                           # a table of equal records (period 2..24)
+                    unit = rs.randint(0, 4, rs.randint(2, 25)).astype(np.uint8) * rs.choice([1, 1, 85])
+                    base[at:at + L] = np.resize(unit, L)
         return base
     blk = np.frombuffer(oracle.synth_text(int(rs.randint(1, 10 ** 6)), max(50, n // rs.randint(3, 200))), dtype=np.uint8)
     return np.tile(blk, n // len(blk) + 1)[:n].copy()
