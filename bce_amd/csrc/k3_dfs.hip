@@ -45,6 +45,9 @@ struct DfsCtl {
   uint32_t pad;
   uint32_t dbg_hist[32]; uint32_t dbg_maxvis; uint32_t dbg_skips; uint64_t dbg_skipbytes;
   uint32_t dbg_stairs, dbg_stairsyms; uint64_t dbg_stairnodes;
+  unsigned long long dbg_slow;   // slowest chain-skip comparison: cycles >> 10 in the high half, x << 20 | min(kk, 2^20 - 1) below
+  unsigned long long dbg_maxwave;   // slowest wave: cycles >> 12 of (walk, chain-skip comparisons, staircases), 20 bits each
+  uint64_t dbg_cyc[4];   // wave cycles: whole walk, chain-skip comparisons, staircases; [3] = staircase looks
 };
 
 struct DNode { uint32_t s, x0, x1, plane; uint64_t round; };
@@ -94,8 +97,9 @@ __device__ __forceinline__ uint32_t lce_back_wave(const uint8_t *__restrict__ T,
     if (cq == 0) cq = n;
     uint32_t run = cp < cq ? cp : cq;                        // bytes before either side wraps
     if (run > lim - t) run = lim - t;
-    if (run >= 1024) {
-      // lane L owns the bytes at distances [16 L, 16 L + 16) from the current position
+    if (cp >= 1024u && cq >= 1024u) {
+      // lane L owns the bytes at distances [16 L, 16 L + 16) from the current position (a whole KB is read even when
+      // fewer bytes are wanted: a difference beyond the limit does not count)
       const uint8_t *a = T + (cp - 16u * lane - 16u), *b = T + (cq - 16u * lane - 16u);
       uint32_t match = 16;                                   // bytes matching from the NEAREST (highest address) end
 #pragma unroll
@@ -106,10 +110,12 @@ __device__ __forceinline__ uint32_t lce_back_wave(const uint8_t *__restrict__ T,
       const uint64_t mm = __ballot(match < 16);
       if (mm) {
         const uint32_t L = (uint32_t)__ffsll((long long)mm) - 1u;     // nearest lane with a mismatch
-        return t + 16u * L + (uint32_t)__builtin_amdgcn_readlane((int)match, (int)L);
+        const uint32_t at = 16u * L + (uint32_t)__builtin_amdgcn_readlane((int)match, (int)L);
+        return at < lim - t ? t + at : lim;
       }
+      if (lim - t <= 1024u) return lim;
       t += 1024; cp -= 1024; cq -= 1024;
-    } else {                                                 // uniform scalar stretch (< 1 KB, up to the next wrap)
+    } else {                                                 // within 1 KB of the start of the text: byte by byte up to the wrap
       uint32_t i = 0;
       while (i < run && T[cp - 1 - i] == T[cq - 1 - i]) ++i;
       t += i; cp -= i; cq -= i;
@@ -168,13 +174,20 @@ __device__ __forceinline__ uint32_t chain_bytes(const DfsArgs &a, uint32_t s, ui
       }
     }
   }
-  if (kk > KD_NEAR) {                                         // n - 1 > KD_NEAR here, so the offsets below are < n
-    const uint32_t pa2 = cyc_back(pa, KD_NEAR, n);
-    for (uint32_t i = 1; i < x && kk > KD_NEAR; ++i) {
+  // Every row agrees with the first on the nearest KD_NEAR bytes.  Deepen in stages (4 KB, 64 KB, 1 MB, ...): the
+  // answer is the MINIMUM over the rows, so no pair is compared further than the stage -- two rows that happen
+  // to share megabytes (copies of a file) cost nothing when a third row differs after a kilobyte.
+  uint32_t done = KD_NEAR;                                    // all rows agree with the first on [0, done)
+  for (uint32_t lim = 4096; kk > done; lim = lim < (1u << 28) ? lim * 16u : n) {      // n - 1 > KD_NEAR here, so offsets stay < n
+    uint32_t upto = kk < lim ? kk : lim;
+    const uint32_t pa2 = cyc_back(pa, done, n);
+    for (uint32_t i = 1; i < x && upto > done; ++i) {
       const uint32_t pb = a.sa[s + i];
       if (a.isa[pb] == ra) continue;
-      kk = KD_NEAR + lce_back_wave(a.text, n, pa2, cyc_back(pb, KD_NEAR, n), kk - KD_NEAR, lane);
+      const uint32_t l = done + lce_back_wave(a.text, n, pa2, cyc_back(pb, done, n), upto - done, lane);
+      if (l < upto) { upto = l; kk = l; }
     }
+    done = upto;
   }
   return kk == n - 1 ? 0u : kk;                               // every row identical: cannot happen for a live node
 }
@@ -252,6 +265,192 @@ __device__ __forceinline__ bool stair_run(const DfsArgs &a, uint32_t s, uint32_t
   return true;
 }
 
+// Several staircases in one node: the same periodic pattern occurs in R places (2 <= R <= KD_REGIONS), so the rows are R
+// progressions lo_r, lo_r + p, ..., hi_r.  Per row the depth (in bytes) at which it leaves is known in closed form --
+// row m of region r meets the byte before its region after B_r + m p bytes, B_r = lo_r - (start of the region) --
+// so the main chain at depth t is "the rows with leave depth >= t", in their old order, and every event (a depth at
+// which rows leave) can be worked out on its own from R-term sums: the counts, the node's row (the minimum of the
+// ISA of the regions' first and last surviving positions), and through the 8 planes the symbols of the node that
+// the leaving rows split off (rows leaving with different bytes leave at different planes; at most one symbol per
+// leaving row).  The stretch stops before any region is down to two rows, so that the leaving rows are never
+// end rows: all of them are then on the same side of the x0 | x1 boundary (only a region's LAST row can be on
+// the other side -- checked), rows that leave never form a node of their own, and the main chain cannot die
+// inside the stretch.  The walker continues normally from the node at the stop depth; when a region has died it looks
+// again.  Everything is verified exactly: decomposition (every row has its neighbour at -p / +p in the node or is a
+// start / an end; starts and ends pair up as disjoint position intervals), periodicity of every region and equality
+// of the pattern across regions by text comparison.  Whole wave, uniform arguments.  Returns 0 if not applicable.
+constexpr uint32_t KD_REGIONS = 8;
+constexpr uint32_t KD_STAIRS_MAXX = 1u << 18;
+struct StairRegs { uint32_t S[KD_REGIONS], E[KD_REGIONS], B[KD_REGIONS], X[KD_REGIONS], D[KD_REGIONS], PE[KD_REGIONS + 1], tS[KD_REGIONS], tE[KD_REGIONS]; };
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+  return v;
+}
+
+__device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, uint32_t s, uint32_t x0, uint32_t x1, uint64_t round,
+                                               uint32_t lane, DNode &next, uint64_t &nodes_out) {
+  const K3Args &k = a.k;
+  const uint32_t n = k.n, x = x0 + x1;
+  if (x > KD_STAIRS_MAXX) return 0;
+  // stride: the smallest distance between neighbouring rows among 64 samples (rows of one region are neighbours
+  // almost everywhere; a wrong guess fails the decomposition)
+  uint32_t p;
+  {
+    const uint32_t i = (uint32_t)(((uint64_t)(x - 2u) * lane) / 63u);
+    const uint32_t qa = a.sa[s + i], qb = a.sa[s + i + 1u];
+    p = wave_min_u32(qa > qb ? qa - qb : qb - qa);
+  }
+  if (p == 0 || p > 65536u) return 0;
+  // starts and ends of the progressions
+  uint32_t nS = 0, nE = 0;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint32_t nchunk = (x + 63u) / 64u;
+  for (uint32_t it = 0; it < nchunk; ++it) {                  // from both ends inwards: starts and ends of many regions
+    const uint32_t base = 64u * ((it & 1u) ? nchunk - 1u - (it >> 1) : (it >> 1));     // gather there, and too many = give up
+    const uint32_t i = base + lane;
+    const bool have = i < x;
+    bool st = have, en = have;
+    uint32_t q = 0;
+    if (have) {
+      q = a.sa[s + i];
+      if (q >= p) st = !(a.isa[q - p] - s < x);
+      if ((uint64_t)q + p < n) en = !(a.isa[q + p] - s < x);
+    }
+    const uint64_t bs = __ballot(st), be = __ballot(en);
+    const uint32_t cs = (uint32_t)__popcll(bs), ce = (uint32_t)__popcll(be);
+    if (nS + cs > KD_REGIONS || nE + ce > KD_REGIONS) return 0;
+    if (st) R->tS[nS + (uint32_t)__popcll(bs & lt)] = q;
+    if (en) R->tE[nE + (uint32_t)__popcll(be & lt)] = q;
+    nS += cs; nE += ce;
+  }
+  if (nS != nE || nS < 2) return 0;
+  const uint32_t nr = nS;
+  __syncthreads();
+  if (lane < nr) {                                            // sort both lists (distinct values): rank by counting
+    uint32_t rs = 0, re = 0;
+    const uint32_t vs = R->tS[lane], ve = R->tE[lane];
+    for (uint32_t j = 0; j < nr; ++j) { rs += R->tS[j] < vs ? 1u : 0u; re += R->tE[j] < ve ? 1u : 0u; }
+    R->S[rs] = vs; R->E[re] = ve;
+  }
+  __syncthreads();
+  {
+    bool bad = false;
+    uint32_t xr = 0;
+    if (lane < nr) {
+      const uint32_t lo = R->S[lane], hi = R->E[lane];
+      bad = hi < lo || (hi - lo) % p != 0 || (lane + 1u < nr && hi >= R->S[lane + 1u]) || (uint64_t)hi + p > n;
+      if (!bad) { xr = (hi - lo) / p + 1u; bad = xr < 3u; }
+      R->X[lane] = xr;
+    }
+    const uint32_t tot = wave_sum_u32(xr);
+    if (__any(bad) || tot != x) return 0;
+  }
+  __syncthreads();
+  // periodicity of every region, the bytes before its start, and the same pattern in all regions
+  const uint32_t hi0 = R->E[0];
+  for (uint32_t r = 0; r < nr; ++r) {
+    const uint32_t lo = R->S[r], hi = R->E[r], span = hi - lo, lim = hi - 1u;
+    const uint32_t lce = lce_back_wave(a.text, n, hi, hi + p, lim, lane);
+    if (lce >= lim || lce < span) return 0;
+    if (r && lce_back_wave(a.text, n, hi0, hi, p, lane) < p) return 0;
+    if (lane == 0) { R->B[r] = lce - span; R->D[r] = a.text[lo - (lce - span) - 1u]; }
+  }
+  __syncthreads();
+  // sides: every row is on the side of region 0's first row except, possibly, the regions' last rows
+  const uint32_t beta = (a.isa[R->S[0]] - s >= x0) ? 1u : 0u;
+  uint32_t nbar = 0;
+  for (uint32_t r = 0; r < nr; ++r) nbar += ((a.isa[R->E[r]] - s >= x0) ? 1u : 0u) != beta ? 1u : 0u;
+  if (nbar == 0 || nbar != (beta ? x0 : x1)) return 0;
+  // the stretch: events at depths below tstop
+  uint32_t tstop = 0xFFFFFFFFu;
+  for (uint32_t r = 0; r < nr; ++r) { const uint32_t t = R->B[r] + (R->X[r] - 2u) * p; tstop = t < tstop ? t : tstop; }
+  if (tstop == 0) return 0;
+  uint32_t etot = 0;
+  for (uint32_t r = 0; r < nr; ++r) {
+    uint32_t e = 0;
+    if (tstop > R->B[r]) { e = (tstop - R->B[r] + p - 1u) / p; const uint32_t cap = R->X[r] - 2u; e = e < cap ? e : cap; }
+    if (lane == 0) R->PE[r] = etot;
+    etot += e;
+  }
+  if (lane == 0) R->PE[nr] = etot;
+  __syncthreads();
+  uint32_t base = 0;
+  if (etot) {
+    if (lane == 0) base = atomicAdd(&a.dctl->nsym, etot);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if ((uint64_t)base + etot > a.symcap) { a.dctl->err = 2; return 2; }
+  }
+  // state of the chain at depth t: rows left, first row; the rows leaving exactly at t
+  auto state = [&](uint32_t t, uint32_t &xall, uint32_t &smin, uint32_t &nl, uint32_t *ld, uint32_t *le) {
+    xall = 0; smin = 0xFFFFFFFFu; nl = 0;
+    for (uint32_t r = 0; r < nr; ++r) {
+      const uint32_t B = R->B[r];
+      const uint32_t mm = t <= B ? 0u : (t - B + p - 1u) / p;          // first row of region r that is still there
+      xall += R->X[r] - mm;
+      const uint32_t r1 = a.isa[R->S[r] + mm * p - t], r2 = a.isa[R->E[r] - t];
+      smin = r1 < smin ? r1 : smin; smin = r2 < smin ? r2 : smin;
+      if (t >= B && (t - B) % p == 0) { ld[nl] = R->D[r]; le[nl] = R->PE[r] + mm; ++nl; }
+    }
+  };
+  for (uint32_t eb = 0; eb < etot; eb += 64) {
+    const uint32_t e = eb + lane;
+    if (e < etot) {
+      uint32_t r = 0;
+      while (e >= R->PE[r + 1u]) ++r;
+      const uint32_t t = R->B[r] + (e - R->PE[r]) * p;
+      uint32_t xall, pos, nl, ld[KD_REGIONS], le[KD_REGIONS];
+      state(t, xall, pos, nl, ld, le);
+      if (le[0] == e) {                                      // several regions may leave a row at this depth: the first one works
+        const uint32_t c = a.text[hi0 - t - 1u];
+        const uint32_t mainb = xall - nbar - nl;             // rows that stay, on the common side
+        uint32_t lm = (1u << nl) - 1u, nsy = 0;
+        for (uint32_t q = 0; q < 8u && lm; ++q) {
+          const uint32_t cq = (c >> q) & 1u;
+          uint32_t mino = 0, ones = 0, lq = 0;
+          for (uint32_t l = 0; l < nl; ++l) if ((lm >> l) & 1u) {
+            const uint32_t bit = (ld[l] >> q) & 1u;
+            ++lq; ones += bit;
+            if (bit != cq) mino |= 1u << l;
+          }
+          if (mino) {
+            const uint32_t xb = mainb + lq, x0n = beta ? nbar : xb, x1n = beta ? xb : nbar, xn = x0n + x1n;
+            const uint32_t n1x = (cq ? mainb + nbar : 0u) + ones, n0x = xn - n1x;
+            const int32_t u = (int32_t)(x0n - n1x), v = (int32_t)(n1x - x1n);
+            const uint32_t mn = u < 0 ? 0u : (uint32_t)u, mx = x0n - (v < 0 ? 0u : (uint32_t)v);
+            if (mx != mn) {
+              const uint32_t n0x0 = beta ? (cq ? 0u : nbar) : ((cq ? 0u : mainb) + (lq - ones));   // zeros among the first x0 rows
+              uint32_t kw, ew;
+              pack_symbol(k.cfg[q], q, n0x0 - mn, mx - mn + 1u, n0x, x1n, xn, kw, ew);
+              const uint64_t rr = round + 8ull * t + q;
+              const uint32_t i = base + le[nsy];
+              a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = pos;
+              a.trlo[i] = (uint32_t)rr;
+              a.trhi[i] = (uint32_t)(rr >> 32) | (q << 8);
+              atomicAdd(&a.dctl->cntp[q], 1u);
+              ++nsy;
+            }
+            lm &= ~mino;
+          }
+          const uint32_t r1 = rank1_plane(k, q, pos);
+          pos = cq ? k.zeros[q] + r1 : pos - r1;
+        }
+        for (uint32_t j = nsy; j < nl; ++j) { const uint32_t i = base + le[j]; a.ts[i] = 0; a.trlo[i] = 0; a.trhi[i] = KD_HOLE; }
+      }
+    }
+  }
+  {
+    uint32_t xall, smin, nl, ld[KD_REGIONS], le[KD_REGIONS];
+    state(tstop, xall, smin, nl, ld, le);
+    const uint32_t xb = xall - nbar;
+    next = DNode{smin, beta ? nbar : xb, beta ? xb : nbar, 0u, round + 8ull * tstop};
+  }
+  nodes_out = 8ull * tstop;
+  if (a.dbg && lane == 0) { atomicAdd(&a.dctl->dbg_stairs, 1u << 16); atomicAdd(&a.dctl->dbg_stairsyms, etot); }
+  return 1;
+}
+
 // One pass of the walkers.  Lane = walker (UNI = false), or WAVE = walker (UNI = true, few walkers left: every value
 // of the walk then depends on blockIdx only, so the compiler keeps it in scalar registers and runs the ~300
 // instructions of a node on the scalar unit instead of issuing them for 64 lanes of which one works; the lanes
@@ -261,6 +460,7 @@ __device__ __forceinline__ bool stair_run(const DfsArgs &a, uint32_t s, uint32_t
 template <bool UNI>
 __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   __shared__ DNode lstack[UNI ? KD_STACK : 1];
+  __shared__ StairRegs sregs;
   const K3Args &k = a.k;
   const EnumCtl *ctl = k.ctl;
   const uint32_t lane = threadIdx.x & 63u;
@@ -308,7 +508,8 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   uint32_t quiet = 8;                                         // pass-through nodes in a row (8 = one whole byte)
   uint32_t sbase = 0, sused = KD_SBLK;                        // my block of tagged-symbol slots (none yet)
   uint32_t seen_err = 0;
-  uint32_t stair_next = 0;                                    // visited count from which I look for a staircase again
+  uint32_t skip_next = 0, skip_wait = 64u;                    // chain skip: back-off while it does not pay
+  uint32_t stair_next = 0, stair_wait = KD_STAIR_RETRY;       // visited count from which I look for a staircase again; back-off
   auto pop = [&]() {                                          // this subtree is finished: the next pending one
     if (sp) { cur = uni_node(stack[--sp]); quiet = 8; }
     else if (next < a.in_count) { cur = fetch(next); next += W; quiet = 8; }
@@ -316,6 +517,8 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   };
   // All 64 lanes stay in the loop until every walker of the wave is finished: finished lanes help with the
   // cooperative text comparisons.
+  uint64_t cyc_skip = 0, cyc_stair = 0, n_look = 0;
+  const uint64_t cyc0 = a.dbg ? clock64() : 0;
   while (__any(alive)) {
     if ((visited & 31u) == 0) seen_err = uni(a.dctl->err);          // a long chain should not wait for this load on every node
     if (alive && (visited >= a.budget || seen_err)) {
@@ -334,29 +537,46 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
     }
     // ---- chain skip: lanes at plane 0 after a whole byte of pass-through, served one after the other by the wave ----
     const uint32_t x = cur.x0 + cur.x1;
-    uint64_t want = __ballot(alive && a.skip_ok && cur.plane == 0 && x <= KD_MAXX && quiet >= 8u);
+    uint64_t want = __ballot(alive && a.skip_ok && cur.plane == 0 && x <= KD_MAXX && quiet >= 8u && visited >= skip_next);
     if (UNI) want &= 1ull;                                     // one walker per wave: one request
     uint32_t mykk = 0;
+    const uint64_t c1 = (a.dbg && want) ? clock64() : 0;
     while (want) {
       const int L = __ffsll((long long)want) - 1;
       want &= want - 1;
       const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)cur.s, L);
       const uint32_t xL = (uint32_t)__builtin_amdgcn_readlane((int)x, L);
+      const uint64_t tq = UNI ? 0 : clock64();
       const uint32_t kk = uni(chain_bytes(a, sL, xL, lane));
-      if (UNI || (int)lane == L) { mykk = kk; if (!kk) quiet = 0; }
+      if (UNI || (int)lane == L) {
+        // lane-walkers: the whole wave worked for this one; long comparisons count against its budget, so that it
+        // moves on to a pass where it has a wave of its own (~2^12 cycles = one node of the walk)
+        if (!UNI) visited += (uint32_t)((clock64() - tq) >> 12);
+        if (a.dbg && !UNI) atomicMax(&a.dctl->dbg_slow, (((unsigned long long)(clock64() - tq) >> 10) << 32) | ((unsigned long long)xL << 20) | (kk < 0xFFFFFu ? kk : 0xFFFFFu));
+        mykk = kk;
+        if (!kk) quiet = 0;
+        // comparing the rows costs ~x/64 batches of dependent loads: a chain that keeps yielding a byte or two for
+        // that (rows of a periodic table: something leaves every period) is looked at less and less often
+        if (8u * kk < xL / 8u) { skip_next = visited + skip_wait; skip_wait = skip_wait < 2048u ? skip_wait * 2u : skip_wait; }
+        else skip_wait = 64u;
+      }
     }
+    if (c1) cyc_skip += clock64() - c1;
     // ---- staircase: a node of many rows at plane 0 whose rows are equally spaced text positions (stair_run) ----
     bool consumed = false;
     {
-      bool cand = alive && a.skip_ok && cur.plane == 0 && x >= KD_STAIR_MIN && visited >= stair_next;
+      const bool cand = alive && a.skip_ok && cur.plane == 0 && x >= KD_STAIR_MIN && visited >= stair_next && mykk == 0;
+      bool single = false;
       if (cand) {                                              // cheap look by the walker itself: first, second and last row
         const uint32_t pa = a.sa[cur.s], pb = a.sa[cur.s + 1], pz = a.sa[cur.s + x - 1];
         const uint64_t span = (uint64_t)(x - 1) * (pb > pa ? pb - pa : pa - pb);
-        cand = pb > pa ? (uint64_t)pa + span == pz : (uint64_t)pz + span == pa;
-        if (!cand) stair_next = visited + KD_STAIR_RETRY;
+        single = pb > pa ? (uint64_t)pa + span == pz : (uint64_t)pz + span == pa;
       }
       uint64_t wants = __ballot(cand);
+      const uint64_t singles = __ballot(single);
       if (UNI) wants &= 1ull;
+      const uint64_t c2 = (a.dbg && wants) ? clock64() : 0;
+      if (c2) n_look += (uint64_t)__popcll(wants);
       while (wants) {
         const int L = __ffsll((long long)wants) - 1;
         wants &= wants - 1;
@@ -365,12 +585,23 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
         const uint64_t rL = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur.round >> 32), L) << 32) |
                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cur.round, L);
         uint64_t nn = 0, mr = 0;
-        const bool ok = stair_run(a, sL, x0L, x1L, rL, lane, nn, mr);
+        bool ok = false;
+        uint32_t res = 0;
+        DNode nx{0u, 1u, 1u, 0u, 0ull};
+        const uint64_t tq = UNI ? 0 : clock64();
+        if ((singles >> L) & 1ull) ok = stair_run(a, sL, x0L, x1L, rL, lane, nn, mr);
+        if (!ok) res = stairs_run(a, &sregs, sL, x0L, x1L, rL, lane, nx, nn);
         if (UNI || (int)lane == L) {
+          if (!UNI) visited += (uint32_t)((clock64() - tq) >> 12);
           if (ok) { consumed = true; nodes += nn; maxround = mr > maxround ? mr : maxround; }
-          else stair_next = visited + KD_STAIR_RETRY;
+          else if (res == 1u) {                                // the chain continues at the end of the stretch
+            cur = uni_node(nx); nodes += nn; quiet = 0;
+            stair_wait = KD_STAIR_RETRY; stair_next = visited + 16u;
+          } else if (res == 2u) alive = false;                 // symbol buffer full: the tail is abandoned (err is set)
+          else { stair_next = visited + stair_wait; stair_wait = stair_wait < 2048u ? stair_wait * 2u : stair_wait; }
         }
       }
+      if (c2) cyc_stair += clock64() - c2;
     }
     if (alive && consumed) {
       ++visited;
@@ -469,6 +700,14 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   if (!writer) return;
   for (uint32_t j = sused; j < KD_SBLK; ++j) { a.ts[sbase + j] = 0; a.trlo[sbase + j] = 0; a.trhi[sbase + j] = KD_HOLE; }
   if (a.dbg) atomicMax(&a.dctl->dbg_maxvis, visited);
+  if (a.dbg && lane == 0) {
+    atomicAdd((unsigned long long *)&a.dctl->dbg_cyc[0], (unsigned long long)(clock64() - cyc0));
+    atomicAdd((unsigned long long *)&a.dctl->dbg_cyc[1], (unsigned long long)cyc_skip);
+    atomicAdd((unsigned long long *)&a.dctl->dbg_cyc[2], (unsigned long long)cyc_stair);
+    atomicAdd((unsigned long long *)&a.dctl->dbg_cyc[3], (unsigned long long)n_look);
+    const unsigned long long tw = (unsigned long long)(clock64() - cyc0) >> 12, ts = cyc_skip >> 12, tt = cyc_stair >> 12;
+    atomicMax(&a.dctl->dbg_maxwave, ((tw & 0xFFFFFull) << 40) | ((ts & 0xFFFFFull) << 20) | (tt & 0xFFFFFull));
+  }
   atomicAdd((unsigned long long *)&a.dctl->nodes, (unsigned long long)nodes);
   atomicMax((unsigned long long *)&a.dctl->maxround, (unsigned long long)maxround);
 }
@@ -539,6 +778,7 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) 
   BCE_HIP_TRY(c, hipMemsetAsync(a.dctl, 0, sizeof(DfsCtl), c->stream));
   DfsCtl h;
   uint32_t count = live, passes = 0;
+  double t_pass = a.dbg ? (hipStreamSynchronize(c->stream), now_s()) : 0.0;
   const DNode *in = nullptr;
   for (;;) {
     a.in = in; a.in_count = count; a.out = queue[passes & 1];
@@ -550,6 +790,18 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) 
     BCE_HIP_TRY(c, hipMemcpyAsync(&h, a.dctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
     BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
     BCE_HIP_TRY(c, hipGetLastError());
+    if (a.dbg) {
+      const double now = now_s();
+      fprintf(stderr, "dfs pass %u: %u walkers%s, %.3f ms, %u queued, %u symbols so far\n", passes, count,
+              (passes > 0 && count <= KD_UNI_MAX) ? " (waves)" : "", (now - t_pass) * 1e3, h.queued, h.nsym);
+      fprintf(stderr, "   slowest chain-skip comparison so far: %llu K cycles, x = %llu, kk = %llu\n", h.dbg_slow >> 32, (h.dbg_slow >> 20) & 0xFFF, h.dbg_slow & 0xFFFFF);
+      fprintf(stderr, "   slowest wave of this pass: %.2f M cycles, of which chain-skip comparisons %.2f M, staircases %.2f M\n",
+              (double)(h.dbg_maxwave >> 40) * 4096e-6, (double)((h.dbg_maxwave >> 20) & 0xFFFFF) * 4096e-6, (double)(h.dbg_maxwave & 0xFFFFF) * 4096e-6);
+      BCE_HIP_TRY(c, hipMemsetAsync(&a.dctl->dbg_maxwave, 0, 8, c->stream));
+      fprintf(stderr, "   wave cycles so far: walk %.0f M, chain-skip comparisons %.0f M, staircases %.0f M (%llu looks)\n", h.dbg_cyc[0] * 1e-6,
+              h.dbg_cyc[1] * 1e-6, h.dbg_cyc[2] * 1e-6, (unsigned long long)h.dbg_cyc[3]);
+      t_pass = now;
+    }
     c->stats.k3_launches += 1.0;
     ++passes;
     if (h.err || h.queued == 0) break;
@@ -558,9 +810,9 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) 
     BCE_HIP_TRY(c, hipMemsetAsync(&a.dctl->queued, 0, 4, c->stream));
   }
   if (a.dbg) {
-    fprintf(stderr, "dfs: live %u passes %u err %u nsym %u (cap %u) nodes %llu maxround %llu maxvisited %u skips %u skipbytes %llu stairs %u (%u symbols)\n", live,
+    fprintf(stderr, "dfs: live %u passes %u err %u nsym %u (cap %u) nodes %llu maxround %llu maxvisited %u skips %u skipbytes %llu stairs %u + %u of several regions (%u symbols)\n", live,
             passes, h.err, h.nsym, cap, (unsigned long long)h.nodes, (unsigned long long)h.maxround, h.dbg_maxvis, h.dbg_skips,
-            (unsigned long long)h.dbg_skipbytes, h.dbg_stairs, h.dbg_stairsyms);
+            (unsigned long long)h.dbg_skipbytes, h.dbg_stairs & 0xFFFFu, h.dbg_stairs >> 16, h.dbg_stairsyms);
     for (int i = 0; i < 32; ++i) if (h.dbg_hist[i]) fprintf(stderr, "  x in [2^%d, 2^%d): %u nodes\n", i, i + 1, h.dbg_hist[i]);
   }
   if (h.err) return BCE_HIP_OK;                     // fall back to the rounds; nothing was modified

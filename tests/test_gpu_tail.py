@@ -133,7 +133,7 @@ def _region(unit, length):
 
 
 @pytest.mark.parametrize("case", ["zeros", "ff", "period2", "period3", "period7-in-random", "two-regions", "at-start", "at-end",
-                                  "record-table"])
+                                  "record-table", "period2-twice", "three-regions-phases", "many-zero-runs", "same-length-twice"])
 def test_staircase_chains_match_oracle(case):
     """Long runs of one byte and periodic tables (executables): chains whose rows are equally spaced text positions.
     The walkers expand them analytically (stair_run); every other path must give the same archive."""
@@ -157,6 +157,15 @@ def test_staircase_chains_match_oracle(case):
         data = bytes(5000) + text + _region(b"\x00\x07", 3000) + b"q"
     elif case == "at-end":
         data = text + _region(b"xy", 8000)
+    elif case == "period2-twice":   # the same table in two places, same bytes before it: two rows leave together
+        data = text[:20000] + b"\x00\x00" + _region(b"\x00\x02", 9001) + b"\x01" + text[20000:40000] + b"\x00\x00" + _region(b"\x00\x02", 7000) + text[40000:]
+    elif case == "three-regions-phases":   # three places, different phases at the start and different bytes before
+        data = (rnd[:10000] + b"Q" + _region(b"abc", 6000) + rnd[10000:20000] + b"R" + _region(b"bca", 5000) + b"a" + text[:20000] +
+                b"Q" + _region(b"cab", 4001) + b"\xff" + rnd[20000:30000])
+    elif case == "many-zero-runs":  # more regions than the closed form takes at once: the walkers take over until few are left
+        data = b"".join(text[i * 3000:(i + 1) * 3000] + bytes(300 * (i + 1) + (i % 3)) for i in range(14)) + text[42000:]
+    elif case == "same-length-twice":
+        data = text[:20000] + b"A" + bytes(5000) + b"B" + text[20000:40000] + b"A" + bytes(5000) + b"C" + text[40000:]
     else:                           # 16-byte records that differ in one counter byte, then identical ones
         data = text[:10000] + b"".join(b"REC" + bytes([i & 255]) + bytes(12) for i in range(300)) + (b"REC\x00" + bytes(12)) * 400 + text[10000:]
     want = oracle.compress(data)

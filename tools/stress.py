@@ -46,11 +46,14 @@ def gen(rs, n):
         return (rs.randint(0, 1 << rs.randint(1, 5), n).astype(np.uint8) << rs.randint(0, 5)).astype(np.uint8)
     if kind == 9:          # long runs of one byte inside other data (executables): chains that cannot be skipped
         base = rs.randint(0, 256, n).astype(np.uint8) if rs.randint(0, 2) else np.frombuffer(oracle.synth_text(int(rs.randint(1, 10 ** 6)), n), dtype=np.uint8).copy()
-        for _ in range(rs.randint(1, 6)):
+        unit0 = rs.randint(0, 4, rs.randint(1, 9)).astype(np.uint8) * rs.choice([1, 1, 85])    # the same pattern in several places
+        for _ in range(rs.randint(1, 12)):
             if n > 10:
                 L = rs.randint(2, max(3, min(n // 2, 60000)))
                 at = rs.randint(0, n - L)
-                if rs.randint(0, 2):
+                if rs.randint(0, 3) == 0:
+                    base[at:at + L] = np.resize(np.roll(unit0, rs.randint(0, len(unit0))), L)
+                elif rs.randint(0, 2):
                     base[at:at + L] = rs.choice([0, 0, 255, 32, rs.randint(0, 256)])
                 else:                                           # a table of equal records (period 2..24)
                     unit = rs.randint(0, 4, rs.randint(2, 25)).astype(np.uint8) * rs.choice([1, 1, 85])
