@@ -174,3 +174,19 @@ def test_staircase_chains_match_oracle(case):
         assert arch == want, "knobs %r" % (knobs,)
         assert st["nodes"] == 8 * len(data) - 8
     assert bce_amd.decompress_device(want) == data
+
+
+def test_staircases_are_expanded_not_walked(capfd, monkeypatch):
+    """The closed forms must actually run (the walkers alone would give the same archive, only slowly): the walker
+    statistics (BCE_HIP_DFS_DEBUG) count single staircases and those of several regions."""
+    import re
+    text = oracle.synth_text(92, 60000)
+    data = (text[:20000] + b"\x00\x00" + _region(b"\x00\x02", 9001) + b"\x01" + text[20000:40000] + b"\x00\x00" +
+            _region(b"\x00\x02", 7000) + text[40000:50000] + bytes(5000) + text[50000:])
+    monkeypatch.setenv("BCE_HIP_DFS_DEBUG", "1")
+    arch, st = _encode_with_knobs(data, {})
+    err = capfd.readouterr().err
+    assert arch == oracle.compress(data)
+    m = re.search(r"stairs (\d+) \+ (\d+) of several regions \((\d+) symbols\)", err)
+    assert m, err[-2000:]
+    assert int(m.group(1)) >= 1 and int(m.group(2)) >= 1 and int(m.group(3)) >= 5000
