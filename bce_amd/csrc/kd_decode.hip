@@ -68,6 +68,12 @@ struct DecArgs {
   const uint32_t *res;       // answers, same indexing
   uint32_t capP, n, par;
   uint32_t zeros[8];         // zeros of plane p = C[(p+1)&7]: the child1 lists of plane p start there
+  // Mailbox of the wave tail kernel (pinned, host-coherent; nullptr = leave at every query round):
+  //   [0] device -> host: number of the query round whose queries are in Q / E / info
+  //   [1] host -> device: number of the query round whose answers are in res
+  //   [2] device -> host: set to 1 when the kernel has left
+  uint32_t *mbox;
+  uint32_t seq_base;         // number of the first query round of this launch (numbers never repeat within a decode)
 };
 
 __device__ __forceinline__ Node *dec_nodes(const DecArgs &a, uint32_t par, uint32_t p) {
@@ -341,10 +347,10 @@ __global__ __launch_bounds__(1024) void dec_scan_kernel(DecArgs a) {
 // runs those rounds on the device (classify from R, children, the new ranks), and stops IN FRONT of the first
 // round that holds a query, does not fit, or is empty; the host then runs that round the normal way.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int DT_T = 256;
+constexpr int DT_T = 1024;
 constexpr int DT_NPT = 4;
 constexpr uint32_t DT_CAP = DT_T * DT_NPT;      // nodes of all planes together
-constexpr uint32_t DT_ENTER = 512;              // the host tries the tail kernel at or below this many nodes
+constexpr uint32_t DT_ENTER = 2048;             // the host tries the tail kernel at or below this many nodes
 
 // `resume` != 0: the first round is the one a previous launch stopped at; its queries were answered by the host
 // (a.res, in the order they were emitted).  When the kernel stops at a round with queries it EMITS them (a.Q / a.E /
@@ -368,7 +374,14 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
   }
   __syncthreads();
   uint32_t total = off[8];
-  if (total > DT_CAP || total == 0 || ctl->err) { if (tid == 0) { rounds_done[0] = 0; rounds_done[1] = total > DT_CAP ? 2u : 0u; } return; }
+  if (total > DT_CAP || total == 0 || ctl->err) {
+    if (tid == 0) {
+      rounds_done[0] = 0; rounds_done[1] = total > DT_CAP ? 2u : 0u; rounds_done[2] = 0; rounds_done[3] = a.seq_base; rounds_done[4] = resume & 1u;
+      __threadfence_system();
+      if (a.mbox) __hip_atomic_store(&a.mbox[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
   for (uint32_t q = tid; q < total; q += DT_T) {
     uint32_t p = 0;
 #pragma unroll
@@ -378,6 +391,9 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
   }
   uint64_t nodes_total = ctl->nodes_total;
   uint32_t why = 0;
+  uint32_t seq = a.seq_base, pending = 0;                     // query rounds are numbered (see DecArgs::mbox)
+  bool have_ans = (resume & 1u) != 0;                         // the answers of the round about to run are in res
+  __shared__ uint32_t got_flag;
   __syncthreads();
   for (;;) {
     if (total == 0 || executed >= max_rounds) break;
@@ -405,7 +421,7 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
       }
     }
     if (__syncthreads_or(badn)) { why = 3; break; }
-    const bool answered = (resume & 1u) && executed == 0;    // this round's queries came back from the host
+    const bool answered = have_ans;                          // this round's queries came back from the host
     uint32_t qx = 0;                                         // exclusive query rank of my first node (list order = stream order)
     if (__syncthreads_or(stop)) {
       // exclusive scan of (queries | escapes << 32) in list order, and the per-plane starts
@@ -455,8 +471,28 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
           a.info->cur_nodes = total;
           a.info->err = 0;
         }
-        why = 1;
-        break;
+        pending = seq;
+        bool got = false;
+        if (a.mbox) {                                          // stay resident: see dec_tail64_kernel
+          __threadfence_system();
+          __syncthreads();
+          if (tid == 0) {
+            __hip_atomic_store(&a.mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint64_t t0 = wall_clock64();
+            uint32_t g = 0;
+            for (;;) {
+              if (__hip_atomic_load(&a.mbox[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == seq) { g = 1; break; }
+              if (wall_clock64() - t0 > 200000ull) break;
+              __builtin_amdgcn_s_sleep(4);
+            }
+            got_flag = g;
+          }
+          __syncthreads();
+          got = got_flag != 0;
+          __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        if (!got) { why = 1; break; }
+        ++seq; pending = 0; have_ans = true;
       }
     }
     uint32_t has0[DT_NPT], has1[DT_NPT], rval[DT_NPT];
@@ -466,7 +502,7 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
 #pragma unroll
     for (int it = 0; it < DT_NPT; ++it) {
       uint32_t v = cl[it].mn;
-      if (valid[it] && cl[it].kind == 3u) { v += a.res[qx]; ++qx; if (v > cl[it].mx) { over = 1; v = cl[it].mn; } }
+      if (valid[it] && cl[it].kind == 3u) { v += __hip_atomic_load(const_cast<uint32_t *>(&a.res[qx]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); ++qx; if (v > cl[it].mx) { over = 1; v = cl[it].mn; } }
       rval[it] = dec_children(nd[it], cl[it], v, a.zeros[pl[it]], has0[it], c0[it], has1[it], c1[it]);
       if (!valid[it]) has0[it] = has1[it] = 0;
       mine += (uint64_t)has0[it] | ((uint64_t)has1[it] << 32);
@@ -526,7 +562,7 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
     if (tid < 9) off[tid] = noff[tid];
     __syncthreads();
     total = off[8];
-    par ^= 1u; cur ^= 1u; ++executed;
+    par ^= 1u; cur ^= 1u; ++executed; have_ans = false;
   }
   __syncthreads();
   for (uint32_t q = tid; q < total; q += DT_T) {
@@ -542,7 +578,11 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
     ctl->next_nodes = total;
     rounds_done[0] = executed;
     rounds_done[1] = why;
+    rounds_done[2] = pending;
+    rounds_done[3] = seq;
+    rounds_done[4] = have_ans ? 1u : 0u;
     __threadfence_system();
+    if (a.mbox) __hip_atomic_store(&a.mbox[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -560,7 +600,14 @@ __global__ __launch_bounds__(64) void dec_tail64_kernel(DecArgs a, uint32_t max_
   uint32_t cnt[8][2], total = 0;
 #pragma unroll
   for (int p = 0; p < 8; ++p) { cnt[p][0] = ctl->cnt[par][p][0]; cnt[p][1] = ctl->cnt[par][p][1]; total += cnt[p][0] + cnt[p][1]; }
-  if (total > 64 || total == 0 || ctl->err) { if (lane == 0) { rounds_done[0] = 0; rounds_done[1] = total > 64 ? 2u : 0u; } return; }
+  if (total > 64 || total == 0 || ctl->err) {
+    if (lane == 0) {
+      rounds_done[0] = 0; rounds_done[1] = total > 64 ? 2u : 0u; rounds_done[2] = 0; rounds_done[3] = a.seq_base; rounds_done[4] = resume & 1u;
+      __threadfence_system();
+      if (a.mbox) __hip_atomic_store(&a.mbox[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
   Node nd{0u, 1u, 1u};
   uint32_t pl = 0;
   {
@@ -577,6 +624,8 @@ __global__ __launch_bounds__(64) void dec_tail64_kernel(DecArgs a, uint32_t max_
     }
   }
   uint64_t nodes_total = ctl->nodes_total;
+  uint32_t seq = a.seq_base, pending = 0;                     // query rounds are numbered; `pending` = the one I left at
+  bool have_ans = (resume & 1u) != 0;                         // the answers of the round about to run are in res
   for (;;) {
     if (total == 0 || executed >= max_rounds) break;
     const bool valid = lane < total;
@@ -587,7 +636,7 @@ __global__ __launch_bounds__(64) void dec_tail64_kernel(DecArgs a, uint32_t max_
     const bool ise = isq && kq > (uint32_t)kMaxK;
     const uint64_t mq = __ballot(isq), me = __ballot(ise);
     const uint32_t qidx = (uint32_t)__popcll(mq & below), eidx = (uint32_t)__popcll(me & below);   // lane order = stream order
-    const bool answered = resume && executed == 0;             // this round's queries came back from the host
+    const bool answered = have_ans;                            // this round's queries came back from the host
     if (mq && !answered) {
       // emit the round's queries (host-visible buffers) and leave; the lists stay as they are
       if (isq) {
@@ -612,13 +661,31 @@ __global__ __launch_bounds__(64) void dec_tail64_kernel(DecArgs a, uint32_t max_
         }
       }
       if (lane == 0) { a.info->cur_nodes = total; a.info->err = 0; }
-      why = 1;
-      break;
+      pending = seq;
+      bool got = false;
+      if (a.mbox) {
+        // Stay resident: publish the round's number, wait for the host to post the same number back (it polls the
+        // mailbox while the kernel runs), at most ~2 ms -- then leave as without a mailbox; the host answers and relaunches.
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(&a.mbox[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint64_t t0 = wall_clock64();                    // 100 MHz
+        for (;;) {
+          uint32_t v = 0;
+          if (lane == 0) v = __hip_atomic_load(&a.mbox[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+          v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+          if (v == seq) { got = true; break; }
+          if (wall_clock64() - t0 > 200000ull) break;
+          __builtin_amdgcn_s_sleep(4);
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      }
+      if (!got) { why = 1; break; }
+      ++seq; pending = 0; have_ans = true;
     }
     uint32_t has0, has1;
     Node c0, c1;
     uint32_t v = cl.mn;
-    if (isq) v += a.res[qidx];
+    if (isq) v += __hip_atomic_load(const_cast<uint32_t *>(&a.res[qidx]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host memory, possibly written while we run
     if (__ballot(isq && v > cl.mx)) { why = 3; break; }        // an answer outside [mn, mx]: inconsistent archive
     const uint32_t rval = dec_children(nd, cl, v, a.zeros[pl], has0, c0, has1, c1);
     if (!valid) has0 = has1 = 0;
@@ -649,7 +716,7 @@ __global__ __launch_bounds__(64) void dec_tail64_kernel(DecArgs a, uint32_t max_
 #pragma unroll
     for (int p = 0; p < 8; ++p) { cnt[p][0] = ncnt[p][0]; cnt[p][1] = ncnt[p][1]; }
     __syncthreads();
-    par ^= 1u; ++executed;
+    par ^= 1u; ++executed; have_ans = false;
   }
   // hand the state back
   {
@@ -670,7 +737,11 @@ __global__ __launch_bounds__(64) void dec_tail64_kernel(DecArgs a, uint32_t max_
     ctl->next_nodes = total;
     rounds_done[0] = executed;
     rounds_done[1] = why;
+    rounds_done[2] = pending;                                  // the query round whose queries are out (why == 1)
+    rounds_done[3] = seq;                                      // the next number
+    rounds_done[4] = have_ans ? 1u : 0u;                       // the round I stopped at has been answered (the decoders moved on)
     __threadfence_system();
+    if (a.mbox) __hip_atomic_store(&a.mbox[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -934,11 +1005,22 @@ struct Pinned {
     p = nullptr; cap = 0;
     size_t want = 2 * cap > bytes ? 2 * cap : bytes;          // pinning is slow: grow geometrically
     if (want < ((size_t)16 << 20)) want = (size_t)16 << 20;
-    BCE_HIP_TRY(c, hipHostMalloc(&p, want, hipHostMallocDefault));
+    BCE_HIP_TRY(c, hipHostMalloc(&p, want, hipHostMallocCoherent | hipHostMallocMapped));   // the wave tail kernel reads answers written while it runs
     cap = want;
     return BCE_HIP_OK;
   }
   ~Pinned() { if (p) (void)hipHostFree(p); }
+};
+
+struct Mailbox {               // a few host-coherent words the wave tail kernel and the host exchange while the kernel runs
+  uint32_t *host = nullptr, *dev = nullptr;
+  int open(bce_hip_ctx *c) {
+    BCE_HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&host), 64, hipHostMallocCoherent | hipHostMallocMapped));
+    for (int i = 0; i < 16; ++i) host[i] = 0;
+    BCE_HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), host, 0));
+    return BCE_HIP_OK;
+  }
+  ~Mailbox() { if (host) (void)hipHostFree(host); }
 };
 
 uint32_t dec_capP(uint32_t n) {
@@ -1033,6 +1115,11 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
   double t_q = 0, t_copy = 0, t_host = 0, t_c = 0;
   uint64_t tail_rounds = 0;
   bool answered_pending = false;                              // pin_res holds the answers of the round about to run
+  Mailbox mbox;                                               // of the wave tail kernel (see DecArgs::mbox)
+  if (!getenv("BCE_DEC_NO_MAILBOX")) BCE_TRY(mbox.open(c));
+  uint32_t next_seq = 1, last_answered = 0;
+  uint64_t mbox_rounds = 0, launches_wave = 0, launches_wg = 0, rounds_wg = 0;
+  double t_wave = 0, t_wg = 0;
   BCE_TRY(ensure(c, c->runs, 64));
   uint32_t *d_rounds = c->runs.as<uint32_t>();
   while (cur_nodes) {
@@ -1051,33 +1138,62 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
       at.res = static_cast<const uint32_t *>(pin_res.p);
       bool resume = false, force_wg = false;
       answered_pending = false;
+      auto answer_round = [&]() -> uint64_t {                   // the queries in pin_q / pin_e -> answers in pin_res
+        const DecInfo in = *info;
+        uint64_t qt = 0;
+        for (int p = 0; p < 8; ++p) {
+          QueryPool::answer(hd.dec[p], at.Q + in.qbase[p], at.E + in.ebase[p], static_cast<uint32_t *>(pin_res.p) + in.qbase[p], in.qtot[p]);
+          qt += in.qtot[p];
+        }
+        return qt;
+      };
       for (;;) {
-        uint32_t done[2] = {0, 0};
+        uint32_t done[5] = {0, 0, 0, 0, 0};
         const bool wave = !force_wg && cur_nodes <= 64;
         at.par = round & 1u;
+        const double t_launch = now_s();
+        at.mbox = mbox.dev;
+        at.seq_base = next_seq;
+        if (at.mbox) __atomic_store_n(&mbox.host[2], 0u, __ATOMIC_RELEASE);
         if (wave) hipLaunchKernelGGL(dec_tail64_kernel, dim3(1), dim3(64), 0, c->stream, at, 1u << 30, d_rounds, resume ? 1u : 0u);
         else hipLaunchKernelGGL(dec_tail_kernel, dim3(1), dim3(DT_T), 0, c->stream, at, 1u << 30, d_rounds, (resume ? 1u : 0u) | 2u);
-        BCE_HIP_TRY(c, hipMemcpyAsync(done, d_rounds, 8, hipMemcpyDeviceToHost, c->stream));
+        if (at.mbox) {
+          // (before the copies below are queued: a device-to-host copy into pageable memory blocks the host until the kernel is done)
+          // the tail kernel stays resident over query rounds: serve its mailbox until it says it has left
+          const double t_poll = now_s();
+          for (uint32_t spins = 0;; ++spins) {
+            if (__atomic_load_n(&mbox.host[0], __ATOMIC_ACQUIRE) == next_seq) {
+              queries_total += answer_round();
+              __atomic_store_n(&mbox.host[1], next_seq, __ATOMIC_RELEASE);
+              last_answered = next_seq++;
+              ++mbox_rounds;
+              continue;
+            }
+            if (__atomic_load_n(&mbox.host[2], __ATOMIC_ACQUIRE)) break;
+            if ((spins & 1023u) == 1023u && (hipStreamQuery(c->stream) != hipErrorNotReady || now_s() - t_poll > 30.0)) break;   // a failed launch never raises the flag
+            __builtin_ia32_pause();
+          }
+        }
+        BCE_HIP_TRY(c, hipMemcpyAsync(done, d_rounds, 20, hipMemcpyDeviceToHost, c->stream));
         BCE_HIP_TRY(c, hipMemcpyAsync(&ctl, c->ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
         BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
         BCE_HIP_TRY(c, hipGetLastError());
         if (getenv("BCE_DEC_TRACE")) fprintf(stderr, "tail: round %u wave %d resume %d -> done %u why %u next %u\n", round, (int)wave, (int)resume, done[0], done[1], ctl.next_nodes);
         round += done[0]; tail_rounds += done[0];
+        if (wave) { ++launches_wave; t_wave += now_s() - t_launch; } else { ++launches_wg; rounds_wg += done[0]; t_wg += now_s() - t_launch; }
         cur_nodes = ctl.next_nodes;
         nodes_total = ctl.nodes_total;
         // a resumed launch that could not even start its round (children outgrow the kernel, or an inconsistency):
         // the decoders have ALREADY answered this round's queries -- whoever runs the round must reuse the answers
-        const bool stuck = resume && done[0] == 0 && done[1] >= 2;
+        const bool stuck = done[4] != 0 && done[1] >= 2;          // the round the kernel stopped at has been answered already
         resume = false;
         force_wg = false;
         if (done[1] == 1) {                                      // queries of round `round` are in pin_q / pin_e
-          const DecInfo in = *info;
-          uint64_t qt = 0;
-          for (int p = 0; p < 8; ++p) {
-            QueryPool::answer(hd.dec[p], at.Q + in.qbase[p], at.E + in.ebase[p], static_cast<uint32_t *>(pin_res.p) + in.qbase[p], in.qtot[p]);
-            qt += in.qtot[p];
+          // (a wave kernel that gave up waiting may have been answered through the mailbox at the same moment)
+          if (!(at.mbox && done[2] != 0 && done[2] == last_answered)) {
+            queries_total += answer_round();
+            if (at.mbox) { last_answered = done[2]; next_seq = done[2] + 1u; }
           }
-          queries_total += qt;
           resume = true;
           continue;
         }
@@ -1152,9 +1268,11 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
     queries_total += qtotal;
     ++round;
   }
-  if (timing) { fprintf(stderr, "gpu decode: %u rounds (%llu of them in the tail kernel), %llu nodes, %llu queries: %.3f s (query pass %.3f, copy out %.3f, host decoders %.3f, children pass %.3f)\n",
-                        round, (unsigned long long)tail_rounds, (unsigned long long)nodes_total, (unsigned long long)queries_total, now_s() - tp0, t_q, t_copy, t_host, t_c); tp0 = now_s(); }
+  if (timing) { fprintf(stderr, "gpu decode: %u rounds (%llu of them in the tail kernels, %llu query rounds answered through the mailbox), %llu nodes, %llu queries: %.3f s (query pass %.3f, copy out %.3f, host decoders %.3f, children pass %.3f)\n",
+                        round, (unsigned long long)tail_rounds, (unsigned long long)mbox_rounds, (unsigned long long)nodes_total, (unsigned long long)queries_total, now_s() - tp0, t_q, t_copy, t_host, t_c); tp0 = now_s(); }
 
+  if (timing) fprintf(stderr, "gpu decode: tail kernels: wave %llu launches %.3f s, workgroup %llu launches (%llu rounds) %.3f s\n",
+                      (unsigned long long)launches_wave, t_wave, (unsigned long long)launches_wg, (unsigned long long)rounds_wg, t_wg);
   // ---- R -> planes -> granules -> BWT bytes ----
   FillArgs f;
   f.R = R; f.n = n;
