@@ -57,6 +57,18 @@ def test_tail_kernels_and_plain_rounds_agree(monkeypatch):
     assert bce_amd.decompress_device(arch) == data
 
 
+def test_tail_query_rounds_with_and_without_the_mailbox(monkeypatch):
+    """Tails in which many rounds ask something (a row leaves a run or a table every few rounds): the resident kernels
+    answered through the mailbox, and the leave / answer / relaunch protocol they fall back to."""
+    text = oracle.synth_text(23, 80000)
+    data = (text[:30000] + bytes(6000) + text[30000:50000] + (b"\x00\x02" * 2500) + b"\x07" + text[50000:] +
+            bytes(3000) + b"\x01" + (b"\x00\x02" * 1800))
+    arch = oracle.compress(data)
+    assert bce_amd.decompress_device(arch) == data
+    monkeypatch.setenv("BCE_DEC_NO_MAILBOX", "1")
+    assert bce_amd.decompress_device(arch) == data
+
+
 def test_custom_config_archives_decode():
     data = oracle.synth_text(12, 200000)
     cfg, _ = oracle.scan(data)
