@@ -342,7 +342,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
       // few live nodes and almost everything visited: finish depth-first (k3_dfs.hip).  The walkers' symbols
       // come after everything emitted so far, so flush that first.
       const uint64_t all = 8ull * (n - 1);
-      if (dfs_try < 2 && ctl.next_nodes && ctl.next_nodes <= kDfsEnter[dfs_try] && ctl.nodes_total >= all / 8) {
+      if (dfs_try < 2 && ctl.next_nodes && ctl.next_nodes <= kDfsEnter[dfs_try] && (ctl.nodes_total >= all / 8 || c->round >= 1024u)) {
         BCE_TRY(flush_symbols(c, ctl.sym_total));
         ctl.sym_total = 0;
         bool dfs_done = false;

@@ -225,14 +225,21 @@ __device__ __forceinline__ bool stair_run(const DfsArgs &a, uint32_t s, uint32_t
   const uint32_t lo = asc ? pa : pz;                          // a
   if ((uint64_t)lo + span + p > n) return false;              // the comparison below would wrap
   bool bad = false;
-  for (uint32_t i = lane; i < x; i += 64) bad |= a.sa[s + i] != (asc ? pa + i * p : pa - i * p);
+  for (uint32_t i0 = 0; i0 < x && !__any(bad); i0 += 256) {
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+      const uint32_t i = i0 + 64u * j + lane;
+      if (i < x) bad |= a.sa[s + i] != (asc ? pa + i * p : pa - i * p);
+    }
+  }
   if (__any(bad)) return false;
   // T[j] == T[j + p] on [a', a + (x-1) p) and the first byte before that where it fails
-  const uint32_t p1 = lo + (uint32_t)span, lim = p1 - 1u;
-  const uint32_t lce = lce_back_wave(a.text, n, p1, p1 + p, lim, lane);
-  if (lce >= lim || lce < span) return false;                 // reaches the start of the text / not periodic
-  const uint32_t B = lce - (uint32_t)span, as = lo - B;       // as >= 2
-  const uint32_t d = a.text[as - 1u], c = a.text[as - 1u + p];
+  const uint32_t p1 = lo + (uint32_t)span;
+  const uint32_t lce = lce_back_wave(a.text, n, p1, p1 + p, p1, lane);      // down to position 0, no wrap
+  if (lce < span) return false;                               // not periodic
+  const uint32_t B = lce - (uint32_t)span, as = lo - B;
+  const uint32_t d = as ? a.text[as - 1u] : a.text[n - 1u], c = a.text[as + p - 1u];     // rotations: position 0 follows n - 1
+  if (d == c) return false;                                   // (only when as == 0: the period goes on around the end)
   const uint32_t js = (uint32_t)__ffs((int)(c ^ d)) - 1u, cb = (c >> js) & 1u;
   const uint32_t L0 = asc ? 1u : 0u;                          // the leaving row is among the first x0 rows
   const uint32_t xs = L0 ? x0 : x1;
@@ -280,7 +287,7 @@ __device__ __forceinline__ bool stair_run(const DfsArgs &a, uint32_t s, uint32_t
 // start / an end; starts and ends pair up as disjoint position intervals), periodicity of every region and equality
 // of the pattern across regions by text comparison.  Whole wave, uniform arguments.  Returns 0 if not applicable.
 constexpr uint32_t KD_REGIONS = 8;
-constexpr uint32_t KD_STAIRS_MAXX = 1u << 18;
+constexpr uint32_t KD_STAIRS_MAXX = 1u << 24;
 struct StairRegs { uint32_t S[KD_REGIONS], E[KD_REGIONS], B[KD_REGIONS], X[KD_REGIONS], D[KD_REGIONS], PE[KD_REGIONS + 1], tS[KD_REGIONS], tE[KD_REGIONS]; };
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
@@ -306,24 +313,32 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
   // starts and ends of the progressions
   uint32_t nS = 0, nE = 0;
   const uint64_t lt = (1ull << lane) - 1ull;
-  const uint32_t nchunk = (x + 63u) / 64u;
-  for (uint32_t it = 0; it < nchunk; ++it) {                  // from both ends inwards: starts and ends of many regions
-    const uint32_t base = 64u * ((it & 1u) ? nchunk - 1u - (it >> 1) : (it >> 1));     // gather there, and too many = give up
-    const uint32_t i = base + lane;
-    const bool have = i < x;
-    bool st = have, en = have;
-    uint32_t q = 0;
-    if (have) {
-      q = a.sa[s + i];
-      if (q >= p) st = !(a.isa[q - p] - s < x);
-      if ((uint64_t)q + p < n) en = !(a.isa[q + p] - s < x);
+  // (chunks of 256 rows, 4 per lane so that the dependent loads of 4 rows overlap; from both ends inwards: starts
+  //  and ends of many regions gather there, and too many = give up early)
+  const uint32_t nchunk = (x + 255u) / 256u;
+  for (uint32_t it = 0; it < nchunk; ++it) {
+    const uint32_t base = 256u * ((it & 1u) ? nchunk - 1u - (it >> 1) : (it >> 1));
+    uint32_t q[4];
+    bool have[4], st[4], en[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint32_t i = base + 64u * j + lane; have[j] = i < x; q[j] = have[j] ? a.sa[s + i] : 0u; }
+    uint32_t rp[4], rn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rp[j] = (have[j] && q[j] >= p) ? a.isa[q[j] - p] : 0xFFFFFFFFu;
+      rn[j] = (have[j] && (uint64_t)q[j] + p < n) ? a.isa[q[j] + p] : 0xFFFFFFFFu;
     }
-    const uint64_t bs = __ballot(st), be = __ballot(en);
-    const uint32_t cs = (uint32_t)__popcll(bs), ce = (uint32_t)__popcll(be);
-    if (nS + cs > KD_REGIONS || nE + ce > KD_REGIONS) return 0;
-    if (st) R->tS[nS + (uint32_t)__popcll(bs & lt)] = q;
-    if (en) R->tE[nE + (uint32_t)__popcll(be & lt)] = q;
-    nS += cs; nE += ce;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      st[j] = have[j] && !(rp[j] != 0xFFFFFFFFu && rp[j] - s < x);
+      en[j] = have[j] && !(rn[j] != 0xFFFFFFFFu && rn[j] - s < x);
+      const uint64_t bs = __ballot(st[j]), be = __ballot(en[j]);
+      const uint32_t cs = (uint32_t)__popcll(bs), ce = (uint32_t)__popcll(be);
+      if (nS + cs > KD_REGIONS || nE + ce > KD_REGIONS) return 0;
+      if (st[j]) R->tS[nS + (uint32_t)__popcll(bs & lt)] = q[j];
+      if (en[j]) R->tE[nE + (uint32_t)__popcll(be & lt)] = q[j];
+      nS += cs; nE += ce;
+    }
   }
   if (nS != nE || nS < 2) return 0;
   const uint32_t nr = nS;
@@ -351,11 +366,14 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
   // periodicity of every region, the bytes before its start, and the same pattern in all regions
   const uint32_t hi0 = R->E[0];
   for (uint32_t r = 0; r < nr; ++r) {
-    const uint32_t lo = R->S[r], hi = R->E[r], span = hi - lo, lim = hi - 1u;
-    const uint32_t lce = lce_back_wave(a.text, n, hi, hi + p, lim, lane);
-    if (lce >= lim || lce < span) return 0;
+    const uint32_t lo = R->S[r], hi = R->E[r], span = hi - lo;
+    const uint32_t lce = lce_back_wave(a.text, n, hi, hi + p, hi, lane);    // down to position 0, no wrap
+    if (lce < span) return 0;
     if (r && lce_back_wave(a.text, n, hi0, hi, p, lane) < p) return 0;
-    if (lane == 0) { R->B[r] = lce - span; R->D[r] = a.text[lo - (lce - span) - 1u]; }
+    const uint32_t as = lo - (lce - span);
+    const uint32_t d = as ? a.text[as - 1u] : a.text[n - 1u];
+    if (d == a.text[as + p - 1u]) return 0;                   // (only when as == 0: the period goes on around the end)
+    if (lane == 0) { R->B[r] = lce - span; R->D[r] = d; }
   }
   __syncthreads();
   // sides: every row is on the side of region 0's first row except, possibly, the regions' last rows
@@ -742,12 +760,17 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) 
   const uint32_t n = c->n;
   const uint32_t live = ctl.next_nodes;
   const uint64_t all = 8ull * (n - 1);
-  if (live == 0 || live > enter || ctl.nodes_total < all / 8) return BCE_HIP_OK;
-  // tagged symbols: the tail is mostly pass-through, a fraction of the nodes that are left is plenty
+  // (not in the ramp-up: an eighth of all nodes visited -- or a thousand rounds gone by with this few nodes alive,
+  //  which is what an input that is one long run or one table looks like from the start)
+  if (live == 0 || live > enter || (ctl.nodes_total < all / 8 && c->round < 1024u)) return BCE_HIP_OK;
+  // tagged symbols: the tail is mostly pass-through, a fraction of the nodes that are left is plenty; if it is
+  // not (chains in which every byte codes a symbol or two), the walk is repeated with four times the room
   const uint64_t left = all > ctl.nodes_total ? all - ctl.nodes_total : 0;
-  uint64_t cap64 = left / 8 + (1u << 20);
+  uint64_t cap_scale = 1;
+retry:
+  uint64_t cap64 = (left / 8 + (1u << 20)) * cap_scale;
   if (cap64 < (4u << 20)) cap64 = 4u << 20;
-  if (cap64 > (32u << 20)) cap64 = 32u << 20;
+  if (cap64 > (512u << 20)) cap64 = 512u << 20;
   if (cap64 > left + 64) cap64 = left + 64;                  // a node codes at most one symbol
   const uint32_t cap = ((uint32_t)cap64 + 63u) & ~63u;       // keeps the carved arrays 8-byte aligned
   const uint32_t qcap = (uint32_t)(left + 64 < KD_QUEUE ? left + 64 : KD_QUEUE);      // queued nodes are distinct unvisited nodes
@@ -778,7 +801,8 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) 
   BCE_HIP_TRY(c, hipMemsetAsync(a.dctl, 0, sizeof(DfsCtl), c->stream));
   DfsCtl h;
   uint32_t count = live, passes = 0;
-  double t_pass = a.dbg ? (hipStreamSynchronize(c->stream), now_s()) : 0.0;
+  double t_pass = 0.0;
+  if (a.dbg) { BCE_HIP_TRY(c, hipStreamSynchronize(c->stream)); t_pass = now_s(); }
   const DNode *in = nullptr;
   for (;;) {
     a.in = in; a.in_count = count; a.out = queue[passes & 1];
@@ -815,6 +839,7 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) 
             (unsigned long long)h.dbg_skipbytes, h.dbg_stairs & 0xFFFFu, h.dbg_stairs >> 16, h.dbg_stairsyms);
     for (int i = 0; i < 32; ++i) if (h.dbg_hist[i]) fprintf(stderr, "  x in [2^%d, 2^%d): %u nodes\n", i, i + 1, h.dbg_hist[i]);
   }
+  if (h.err == 2 && cap64 < left + 64 && cap64 < (512u << 20)) { cap_scale *= 4; goto retry; }   // nothing was modified: once more with more room
   if (h.err) return BCE_HIP_OK;                     // fall back to the rounds; nothing was modified
   const uint32_t m = h.nsym;                         // reserved slots (real symbols + holes)
   uint32_t mv = 0;                                   // real symbols

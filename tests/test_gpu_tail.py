@@ -133,7 +133,8 @@ def _region(unit, length):
 
 
 @pytest.mark.parametrize("case", ["zeros", "ff", "period2", "period3", "period7-in-random", "two-regions", "at-start", "at-end",
-                                  "record-table", "period2-twice", "three-regions-phases", "many-zero-runs", "same-length-twice"])
+                                  "record-table", "period2-twice", "three-regions-phases", "many-zero-runs", "same-length-twice",
+                                  "whole-text-periodic", "two-tables-first-at-start"])
 def test_staircase_chains_match_oracle(case):
     """Long runs of one byte and periodic tables (executables): chains whose rows are equally spaced text positions.
     The walkers expand them analytically (stair_run); every other path must give the same archive."""
@@ -164,6 +165,10 @@ def test_staircase_chains_match_oracle(case):
                 b"Q" + _region(b"cab", 4001) + b"\xff" + rnd[20000:30000])
     elif case == "many-zero-runs":  # more regions than the closed form takes at once: the walkers take over until few are left
         data = b"".join(text[i * 3000:(i + 1) * 3000] + bytes(300 * (i + 1) + (i % 3)) for i in range(14)) + text[42000:]
+    elif case == "whole-text-periodic":   # the region IS the text up to its last byte: it starts at position 0, where the
+        data = b"ab" * 30000 + b"c"          # byte "before" is the last one (rotations)
+    elif case == "two-tables-first-at-start":
+        data = _region(b"\x00\x00\x01", 20000) + text[:30000] + b"\x07" + _region(b"\x00\x01\x00", 14000) + text[30000:]
     elif case == "same-length-twice":
         data = text[:20000] + b"A" + bytes(5000) + b"B" + text[20000:40000] + b"A" + bytes(5000) + b"C" + text[40000:]
     else:                           # 16-byte records that differ in one counter byte, then identical ones
