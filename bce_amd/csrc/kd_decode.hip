@@ -1023,6 +1023,80 @@ struct Mailbox {               // a few host-coherent words the wave tail kernel
   ~Mailbox() { if (host) (void)hipHostFree(host); }
 };
 
+// The very deep tail on the host.  A chain of a few nodes that goes on for millions of rounds (a megabyte run, a
+// whole-file duplicate) costs the wave kernel ~2 us per round -- the latency of one dependent load after the other
+// -- while a CPU core does the same round out of its caches in ~0.1 us.  So once the wave kernel has spent
+// max(kHostTailMin, n / 400) rounds on <= 64 nodes, the boundary ranks (8 x 4(n+1) B) and the node lists come to the host, the rounds
+// are finished here exactly as `bce -ds` runs them (decoder.cpp, BCE::code mode 0, bce.cpp:1246-1371, same decoders),
+// and the ranks go back for the plane fill.  The copies are ~2 x 60 ms per 10^8 bytes.
+constexpr uint32_t kHostTailMin = 50000;                    // ... rounds, or n / 400 if that is more (the copies cost ~n)
+
+int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vector<Decoder> &dec, uint32_t n, uint32_t *round,
+                  uint64_t *nodes_total, uint64_t *queries_total, bool *bad_out) {
+  const uint32_t par = *round & 1u;
+  std::vector<Node> cur[8][2], nxt[8][2];
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (uint32_t p = 0; p < 8; ++p) {
+    const uint32_t c0 = ctl.cnt[par][p][0], c1 = ctl.cnt[par][p][1];
+    const Node *base = a.nodes + ((size_t)(par * 8u + p)) * a.capP;
+    cur[p][0].resize(c0);
+    if (c0) BCE_HIP_TRY(c, hipMemcpy(cur[p][0].data(), base, (size_t)c0 * sizeof(Node), hipMemcpyDeviceToHost));
+    cur[p][1].resize(c1);
+    if (c1) {
+      BCE_HIP_TRY(c, hipMemcpy(cur[p][1].data(), base + (a.capP - c1), (size_t)c1 * sizeof(Node), hipMemcpyDeviceToHost));
+      for (uint32_t i = 0; i < c1 / 2; ++i) std::swap(cur[p][1][i], cur[p][1][c1 - 1u - i]);     // child1 lists grow downwards
+    }
+  }
+  const size_t stride = (size_t)n + 1;
+  std::vector<uint32_t> Rh(8 * stride);
+  BCE_HIP_TRY(c, hipMemcpy(Rh.data(), a.R, Rh.size() * 4, hipMemcpyDeviceToHost));
+  bool bad = false;
+  uint64_t nodes = 0, queries = 0;
+  uint32_t rounds = 0;
+  for (bool again = true; again && !bad;) {
+    for (uint32_t i = 0; i < 8 && !bad; ++i) {
+      uint32_t *R = Rh.data() + (size_t)i * stride;
+      const uint32_t zi = a.zeros[i];
+      for (int j = 0; j < 2 && !bad; ++j)
+        for (const Node &nd : cur[i][j]) {
+          const uint32_t s = nd.s, x0 = nd.x0, x1 = nd.x1, x = x0 + x1;
+          if ((uint64_t)s + x > n || R[s] == kUnknown || R[s + x] == kUnknown) { bad = true; break; }
+          const uint32_t s1 = R[s], n1x = R[s + x] - s1, s0 = s - s1;
+          if (n1x > x) { bad = true; break; }
+          uint32_t n1x0;
+          if (!n1x) { nxt[(i + 1) & 7][0].push_back(Node{s0, x0, x1}); n1x0 = 0; }
+          else if (n1x == x) { nxt[(i + 1) & 7][1].push_back(Node{zi + s1, x0, x1}); n1x0 = x0; }
+          else {
+            const uint32_t n0x = x - n1x;
+            uint32_t mn = x0 - n1x, mx = n1x - x1;
+            mn = ((int32_t)mn < 0) ? 0u : mn;
+            mx = ((int32_t)mx < 0) ? 0u : mx;
+            mx = x0 - mx;
+            uint32_t n0x0 = mn;
+            if (mx != mn) { n0x0 = mn + dec[i].get_adaptive(mx - mn + 1, n0x, x1, x); ++queries; }
+            if (n0x0 > mx) { bad = true; break; }
+            const uint32_t n0x1 = n0x - n0x0;
+            if (n0x0 && n0x1) nxt[(i + 1) & 7][0].push_back(Node{s0, n0x0, n0x1});
+            const uint32_t n1x1 = x1 - n0x1;
+            n1x0 = n1x - n1x1;
+            if (n1x0 && n1x1) nxt[(i + 1) & 7][1].push_back(Node{zi + s1, n1x0, n1x1});
+          }
+          R[s + x0] = s1 + n1x0;
+          ++nodes;
+        }
+    }
+    ++rounds;
+    again = false;
+    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 2; ++j) { cur[i][j].swap(nxt[i][j]); nxt[i][j].clear(); if (!cur[i][j].empty()) again = true; }
+  }
+  *bad_out = bad;
+  if (bad) return BCE_HIP_OK;
+  BCE_HIP_TRY(c, hipMemcpy(a.R, Rh.data(), Rh.size() * 4, hipMemcpyHostToDevice));
+  *round += rounds; *nodes_total += nodes; *queries_total += queries;
+  return BCE_HIP_OK;
+}
+
 uint32_t dec_capP(uint32_t n) {
   const uint64_t worst = (uint64_t)n / 2 + 2, soft = (uint64_t)192 << 20;
   return (uint32_t)(worst < soft ? worst : soft);
@@ -1118,6 +1192,8 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
   Mailbox mbox;                                               // of the wave tail kernel (see DecArgs::mbox)
   if (!getenv("BCE_DEC_NO_MAILBOX")) BCE_TRY(mbox.open(c));
   uint32_t next_seq = 1, last_answered = 0;
+  const bool host_tail_ok = !getenv("BCE_DEC_NO_HOST_TAIL");
+  const uint32_t kHostTailAfter = n / 400u > kHostTailMin ? n / 400u : kHostTailMin;
   uint64_t mbox_rounds = 0, launches_wave = 0, launches_wg = 0, rounds_wg = 0;
   double t_wave = 0, t_wg = 0;
   BCE_TRY(ensure(c, c->runs, 64));
@@ -1155,7 +1231,7 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
         at.mbox = mbox.dev;
         at.seq_base = next_seq;
         if (at.mbox) __atomic_store_n(&mbox.host[2], 0u, __ATOMIC_RELEASE);
-        if (wave) hipLaunchKernelGGL(dec_tail64_kernel, dim3(1), dim3(64), 0, c->stream, at, 1u << 30, d_rounds, resume ? 1u : 0u);
+        if (wave) hipLaunchKernelGGL(dec_tail64_kernel, dim3(1), dim3(64), 0, c->stream, at, host_tail_ok ? kHostTailAfter : (1u << 30), d_rounds, resume ? 1u : 0u);
         else hipLaunchKernelGGL(dec_tail_kernel, dim3(1), dim3(DT_T), 0, c->stream, at, 1u << 30, d_rounds, (resume ? 1u : 0u) | 2u);
         if (at.mbox) {
           // (before the copies below are queued: a device-to-host copy into pageable memory blocks the host until the kernel is done)
@@ -1203,6 +1279,17 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
           continue;
         }
         answered_pending = stuck;
+        if (wave && host_tail_ok && done[1] == 0 && done[0] >= kHostTailAfter && cur_nodes && cur_nodes <= 64) {
+          // a long chain of a few nodes: the rest of the rounds on the host (dec_host_tail)
+          bool bad = false;
+          const double th = now_s();
+          const uint32_t r0 = round;
+          BCE_TRY(dec_host_tail(c, a, ctl, hd.dec, n, &round, &nodes_total, &queries_total, &bad));
+          if (bad) { snprintf(c->err, sizeof c->err, "decode: inconsistent archive (round %u)", round); return BCE_HIP_E_INTERNAL; }
+          if (timing) fprintf(stderr, "gpu decode: %u rounds of the deep tail on the host, %.3f s with the copies\n", round - r0, now_s() - th);
+          cur_nodes = 0;
+          break;
+        }
         if (done[1] == 0 && done[0] && cur_nodes && cur_nodes <= DT_ENTER) continue;   // handed back (few nodes again) or out of max_rounds
         break;                                                   // nothing left, too many nodes (2) or an inconsistent node (3)
       }

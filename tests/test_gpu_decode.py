@@ -3,6 +3,8 @@
 Archives come from the oracle (the reference's `-c`), so this is parity with the reference's `-d` on the reference's
 own output; the host decoder (decoder.cpp, CPU-tested against the same archives) must agree byte for byte."""
 import numpy as np
+import time
+
 import pytest
 
 import bce_amd
@@ -96,3 +98,18 @@ def test_corrupt_archive_is_rejected_or_differs():
     except bce_amd.BceError:
         return
     assert out != data
+
+
+def test_deep_tail_finishes_on_the_host(monkeypatch):
+    """A run long enough that the wave tail kernel hands the rest of the rounds to the host (dec_host_tail), and the
+    same archive with that switched off."""
+    text = oracle.synth_text(29, 40000)
+    data = text[:20000] + bytes(150000) + text[20000:] + bytes(90000) + b"\x01"
+    arch = oracle.compress(data)
+    t0 = time.time()
+    assert bce_amd.decompress_device(arch) == data
+    dt = time.time() - t0
+    monkeypatch.setenv("BCE_DEC_NO_HOST_TAIL", "1")
+    t0 = time.time()
+    assert bce_amd.decompress_device(arch) == data
+    print("deep tail: %.2f s with the host tail, %.2f s without" % (dt, time.time() - t0))
