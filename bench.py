@@ -151,7 +151,7 @@ def main():
         alg_bytes = 384.0 * n + 16.0 * st["symbols"]     # 48 B/node x 8n nodes + 16 B/symbol
         traffic = None    # HBM bytes from PMC counters: measured offline (rocprofv3 --pmc passes), see profiles/
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_e_k3_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_f_k3_traffic.json")))
             if tj["bytes_per_gpu"] == n and not args.file and args.workload == "synth-text":
                 traffic = tj["traffic_bytes_corrected"]
         except Exception:
