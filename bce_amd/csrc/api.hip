@@ -362,7 +362,7 @@ int bce_hip_encode(bce_hip_ctx *c) {
     const uint32_t first = c->round;
     uint32_t executed = 0;
     BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    if (!c->dbg_no_tail && cur_nodes <= K3_TAIL_ENTER) {
+    if ((!c->dbg_no_tail || cur_nodes == 0) && cur_nodes <= K3_TAIL_ENTER) {       // (no node at all, e.g. one byte repeated: only this kernel says "done" then)
       // narrow phase: the persistent single-workgroup kernel loops over rounds on the device
       BCE_TRY(k3_tail(c));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));

@@ -195,3 +195,12 @@ def test_staircases_are_expanded_not_walked(capfd, monkeypatch):
     m = re.search(r"stairs (\d+) \+ (\d+) of several regions \((\d+) symbols\)", err)
     assert m, err[-2000:]
     assert int(m.group(1)) >= 1 and int(m.group(2)) >= 1 and int(m.group(3)) >= 5000
+
+
+@pytest.mark.parametrize("data", [b"\xd2" * 14, b"a", b"\x00" * 1000, b"ab" * 7])
+def test_inputs_without_nodes_on_every_path(data):
+    """One byte repeated has no node at all (every plane is constant): every knob combination must still finish."""
+    want = oracle.compress(data)
+    for knobs in ({}, {1: 1, 2: 1, 4: 1}, {2: 1}, {2: 1, 4: 1, 6: 1}, {1: 1}):
+        arch, _ = _encode_with_knobs(data, knobs)
+        assert arch == want, "knobs %r" % (knobs,)
