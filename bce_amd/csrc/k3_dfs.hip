@@ -43,6 +43,7 @@ struct DfsCtl {
   uint32_t cntp[8];      // symbols per plane
   uint32_t queued;       // nodes handed to the next pass
   uint32_t pad;
+  uint32_t njobs, pad2;  // staircase jobs queued so far
   uint32_t dbg_hist[32]; uint32_t dbg_maxvis; uint32_t dbg_skips; uint64_t dbg_skipbytes;
   uint32_t dbg_stairs, dbg_stairsyms; uint64_t dbg_stairnodes;
   unsigned long long dbg_slow;   // slowest chain-skip comparison: cycles >> 10 in the high half, x << 20 | min(kk, 2^20 - 1) below
@@ -51,6 +52,22 @@ struct DfsCtl {
 };
 
 struct DNode { uint32_t s, x0, x1, plane; uint64_t round; };
+
+// A staircase stretch (see stair_run / stairs_run) whose events are independent of each other.  Short ones are written
+// by the walker's own wave; long ones (10^4..10^6 events) are put on a job list and written by a grid-wide kernel
+// after the pass (kd_jobs_kernel), so that no single wave sits on them.
+constexpr uint32_t KD_REGIONS = 8;
+constexpr uint32_t KD_JOBS = 4096;               // jobs per depth-first tail (when the list is full the walker writes the events itself)
+constexpr uint32_t KD_JOB_MIN = 2048;            // events from which a stretch becomes a job
+struct StairJob {
+  uint32_t kind;                                  // 1 one region, 2 several
+  uint32_t p, x0, x1, base, events;
+  uint64_t round;
+  uint32_t as, asc, B, c, js;                     // one region
+  uint32_t nr, beta, nbar, hi0;                   // several regions
+  uint32_t S[KD_REGIONS], E[KD_REGIONS], Bv[KD_REGIONS], X[KD_REGIONS], D[KD_REGIONS], PE[KD_REGIONS + 1];
+  uint32_t tS[KD_REGIONS], tE[KD_REGIONS];        // scratch of the decomposition
+};
 typedef __attribute__((address_space(4))) Granule ConstGranule;
 
 struct DfsArgs {
@@ -61,6 +78,7 @@ struct DfsArgs {
   DfsCtl *dctl;
   uint32_t *tkey, *tesc, *ts, *trlo, *trhi;
   DNode *stacks;
+  StairJob *jobs;        // [KD_JOBS]
   const DNode *in;       // queued nodes of this pass; nullptr = the planes' node lists (first pass)
   DNode *out;            // nodes handed to the next pass
   uint32_t in_count, out_cap;
@@ -213,6 +231,39 @@ __device__ __forceinline__ uint32_t rank1_plane(const K3Args &k, uint32_t p, uin
   const uint32_t g = div96(pos);
   return granule_rank1((k.gran + (size_t)p * k.ngran)[g], pos - g * 96u);
 }
+// Event e of a one-region staircase (see stair_run).
+__device__ __forceinline__ void stair_event(const DfsArgs &a, const StairJob &J, uint32_t e) {
+  const K3Args &k = a.k;
+  const uint32_t L0 = J.asc, p = J.p, c = J.c, js = J.js, cb = (c >> js) & 1u;
+  const uint32_t xe0 = J.x0 - (L0 ? e : 0u), xe1 = J.x1 - (L0 ? 0u : e), xe = xe0 + xe1;
+  uint32_t pos = a.isa[L0 ? J.as : J.as + (xe - 1u) * p];
+  for (uint32_t q = 0; q < js; ++q) {
+    const uint32_t r = rank1_plane(k, q, pos);
+    pos = ((c >> q) & 1u) ? k.zeros[q] + r : pos - r;
+  }
+  uint32_t kw, ew;
+  pack_symbol(k.cfg[js], js, cb ? L0 : 1u - L0, 2u, cb ? 1u : xe - 1u, xe1, xe, kw, ew);
+  const uint64_t r = J.round + 8ull * ((uint64_t)J.B + (uint64_t)e * p) + js;
+  const uint32_t i = J.base + e;
+  a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = pos;
+  a.trlo[i] = (uint32_t)r;
+  a.trhi[i] = (uint32_t)(r >> 32) | (js << 8);
+}
+
+// Put a long stretch on the job list (whole wave; `J` uniform, or in LDS when `lds`).  False: write the events yourself.
+__device__ __forceinline__ bool stair_defer(const DfsArgs &a, const StairJob &J, uint32_t lane, bool lds) {
+  if (J.events < KD_JOB_MIN) return false;
+  uint32_t idx = 0;
+  if (lane == 0) idx = atomicAdd(&a.dctl->njobs, 1u);
+  idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+  if (idx >= KD_JOBS) return false;                           // (the counter stays above KD_JOBS: the host clamps it)
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(&J);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(a.jobs + idx);
+  if (lds) { for (uint32_t w = lane; w < sizeof(StairJob) / 4; w += 64) dst[w] = src[w]; }
+  else if (lane == 0) a.jobs[idx] = J;
+  return true;
+}
+
 __device__ __forceinline__ bool stair_run(const DfsArgs &a, uint32_t s, uint32_t x0, uint32_t x1, uint64_t round, uint32_t lane,
                                        uint64_t &nodes_out, uint64_t &maxround_out) {
   const K3Args &k = a.k;
@@ -240,28 +291,18 @@ __device__ __forceinline__ bool stair_run(const DfsArgs &a, uint32_t s, uint32_t
   const uint32_t B = lce - (uint32_t)span, as = lo - B;
   const uint32_t d = as ? a.text[as - 1u] : a.text[n - 1u], c = a.text[as + p - 1u];     // rotations: position 0 follows n - 1
   if (d == c) return false;                                   // (only when as == 0: the period goes on around the end)
-  const uint32_t js = (uint32_t)__ffs((int)(c ^ d)) - 1u, cb = (c >> js) & 1u;
+  const uint32_t js = (uint32_t)__ffs((int)(c ^ d)) - 1u;
   const uint32_t L0 = asc ? 1u : 0u;                          // the leaving row is among the first x0 rows
   const uint32_t xs = L0 ? x0 : x1;
   uint32_t base = 0;
   if (lane == 0) base = atomicAdd(&a.dctl->nsym, xs);
   base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
   if ((uint64_t)base + xs > a.symcap) { a.dctl->err = 2; nodes_out = 0; maxround_out = 0; return true; }
-  for (uint32_t e = lane; e < xs; e += 64) {
-    const uint32_t xe0 = x0 - (L0 ? e : 0u), xe1 = x1 - (L0 ? 0u : e), xe = xe0 + xe1;
-    uint32_t pos = a.isa[asc ? as : as + (xe - 1u) * p];
-    for (uint32_t q = 0; q < js; ++q) {
-      const uint32_t r = rank1_plane(k, q, pos);
-      pos = ((c >> q) & 1u) ? k.zeros[q] + r : pos - r;
-    }
-    uint32_t kw, ew;
-    pack_symbol(k.cfg[js], js, cb ? L0 : 1u - L0, 2u, cb ? 1u : xe - 1u, xe1, xe, kw, ew);
-    const uint64_t r = round + 8ull * ((uint64_t)B + (uint64_t)e * p) + js;
-    const uint32_t i = base + e;
-    a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = pos;
-    a.trlo[i] = (uint32_t)r;
-    a.trhi[i] = (uint32_t)(r >> 32) | (js << 8);
-  }
+  StairJob J;
+  J.kind = 1; J.p = p; J.x0 = x0; J.x1 = x1; J.base = base; J.events = xs; J.round = round;
+  J.as = as; J.asc = asc ? 1u : 0u; J.B = B; J.c = c; J.js = js;
+  if (!stair_defer(a, J, lane, false))
+    for (uint32_t e = lane; e < xs; e += 64) stair_event(a, J, e);
   if (lane == 0) {
     atomicAdd(&a.dctl->cntp[js], xs);
     if (a.dbg) { atomicAdd(&a.dctl->dbg_stairs, 1u); atomicAdd(&a.dctl->dbg_stairsyms, xs); }
@@ -286,14 +327,88 @@ __device__ __forceinline__ bool stair_run(const DfsArgs &a, uint32_t s, uint32_t
 // again.  Everything is verified exactly: decomposition (every row has its neighbour at -p / +p in the node or is a
 // start / an end; starts and ends pair up as disjoint position intervals), periodicity of every region and equality
 // of the pattern across regions by text comparison.  Whole wave, uniform arguments.  Returns 0 if not applicable.
-constexpr uint32_t KD_REGIONS = 8;
 constexpr uint32_t KD_STAIRS_MAXX = 1u << 24;
-struct StairRegs { uint32_t S[KD_REGIONS], E[KD_REGIONS], B[KD_REGIONS], X[KD_REGIONS], D[KD_REGIONS], PE[KD_REGIONS + 1], tS[KD_REGIONS], tE[KD_REGIONS]; };
+typedef StairJob StairRegs;                      // the walker's copy lives in LDS
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
   for (int o = 32; o; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
   return v;
+}
+
+// State of a chain of several staircases at depth t (bytes below the node): rows left, the first row, and the rows
+// that leave exactly at t (their bytes and their event numbers).
+__device__ __forceinline__ void stairs_state(const DfsArgs &a, const StairJob &J, uint32_t t, uint32_t &xall, uint32_t &smin,
+                                             uint32_t &nl, uint32_t *ld, uint32_t *le) {
+  const uint32_t p = J.p;
+  xall = 0; smin = 0xFFFFFFFFu; nl = 0;
+  for (uint32_t r = 0; r < J.nr; ++r) {
+    const uint32_t B = J.Bv[r];
+    const uint32_t mm = t <= B ? 0u : (t - B + p - 1u) / p;            // first row of region r that is still there
+    xall += J.X[r] - mm;
+    const uint32_t r1 = a.isa[J.S[r] + mm * p - t], r2 = a.isa[J.E[r] - t];
+    smin = r1 < smin ? r1 : smin; smin = r2 < smin ? r2 : smin;
+    if (t >= B && (t - B) % p == 0) { ld[nl] = J.D[r]; le[nl] = J.PE[r] + mm; ++nl; }
+  }
+}
+
+// Event e (numbered region by region) of a chain of several staircases (see stairs_run).
+__device__ __forceinline__ void stairs_event(const DfsArgs &a, const StairJob &J, uint32_t e) {
+  const K3Args &k = a.k;
+  const uint32_t p = J.p, beta = J.beta, nbar = J.nbar;
+  uint32_t r = 0;
+  while (e >= J.PE[r + 1u]) ++r;
+  const uint32_t t = J.Bv[r] + (e - J.PE[r]) * p;
+  uint32_t xall, pos, nl, ld[KD_REGIONS], le[KD_REGIONS];
+  stairs_state(a, J, t, xall, pos, nl, ld, le);
+  if (le[0] != e) return;                                    // several regions may leave a row at this depth: the first one works
+  const uint32_t c = a.text[J.hi0 - t - 1u];
+  const uint32_t mainb = xall - nbar - nl;                   // rows that stay, on the common side
+  uint32_t lm = (1u << nl) - 1u, nsy = 0;
+  for (uint32_t q = 0; q < 8u && lm; ++q) {
+    const uint32_t cq = (c >> q) & 1u;
+    uint32_t mino = 0, ones = 0, lq = 0;
+    for (uint32_t l = 0; l < nl; ++l) if ((lm >> l) & 1u) {
+      const uint32_t bit = (ld[l] >> q) & 1u;
+      ++lq; ones += bit;
+      if (bit != cq) mino |= 1u << l;
+    }
+    if (mino) {
+      const uint32_t xb = mainb + lq, x0n = beta ? nbar : xb, x1n = beta ? xb : nbar, xn = x0n + x1n;
+      const uint32_t n1x = (cq ? mainb + nbar : 0u) + ones, n0x = xn - n1x;
+      const int32_t u = (int32_t)(x0n - n1x), v = (int32_t)(n1x - x1n);
+      const uint32_t mn = u < 0 ? 0u : (uint32_t)u, mx = x0n - (v < 0 ? 0u : (uint32_t)v);
+      if (mx != mn) {
+        const uint32_t n0x0 = beta ? (cq ? 0u : nbar) : ((cq ? 0u : mainb) + (lq - ones));   // zeros among the first x0 rows
+        uint32_t kw, ew;
+        pack_symbol(k.cfg[q], q, n0x0 - mn, mx - mn + 1u, n0x, x1n, xn, kw, ew);
+        const uint64_t rr = J.round + 8ull * t + q;
+        const uint32_t i = J.base + le[nsy];
+        a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = pos;
+        a.trlo[i] = (uint32_t)rr;
+        a.trhi[i] = (uint32_t)(rr >> 32) | (q << 8);
+        atomicAdd(&a.dctl->cntp[q], 1u);
+        ++nsy;
+      }
+      lm &= ~mino;
+    }
+    const uint32_t r1 = rank1_plane(k, q, pos);
+    pos = cq ? k.zeros[q] + r1 : pos - r1;
+  }
+  for (uint32_t j = nsy; j < nl; ++j) { const uint32_t i = J.base + le[j]; a.ts[i] = 0; a.trlo[i] = 0; a.trhi[i] = KD_HOLE; }
+}
+
+// The events of the stretches queued during a pass, spread over the whole grid.
+__global__ __launch_bounds__(256) void kd_jobs_kernel(DfsArgs a, uint32_t first) {
+  uint32_t nj = a.dctl->njobs;
+  nj = nj < KD_JOBS ? nj : KD_JOBS;
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  for (uint32_t j = first; j < nj; ++j) {
+    const StairJob &J = a.jobs[j];
+    const uint32_t ne = J.events;
+    if (J.kind == 1u) { for (uint32_t e = tid; e < ne; e += nt) stair_event(a, J, e); }
+    else { for (uint32_t e = tid; e < ne; e += nt) stairs_event(a, J, e); }
+  }
 }
 
 __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, uint32_t s, uint32_t x0, uint32_t x1, uint64_t round,
@@ -373,7 +488,7 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
     const uint32_t as = lo - (lce - span);
     const uint32_t d = as ? a.text[as - 1u] : a.text[n - 1u];
     if (d == a.text[as + p - 1u]) return 0;                   // (only when as == 0: the period goes on around the end)
-    if (lane == 0) { R->B[r] = lce - span; R->D[r] = d; }
+    if (lane == 0) { R->Bv[r] = lce - span; R->D[r] = d; }
   }
   __syncthreads();
   // sides: every row is on the side of region 0's first row except, possibly, the regions' last rows
@@ -383,12 +498,12 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
   if (nbar == 0 || nbar != (beta ? x0 : x1)) return 0;
   // the stretch: events at depths below tstop
   uint32_t tstop = 0xFFFFFFFFu;
-  for (uint32_t r = 0; r < nr; ++r) { const uint32_t t = R->B[r] + (R->X[r] - 2u) * p; tstop = t < tstop ? t : tstop; }
+  for (uint32_t r = 0; r < nr; ++r) { const uint32_t t = R->Bv[r] + (R->X[r] - 2u) * p; tstop = t < tstop ? t : tstop; }
   if (tstop == 0) return 0;
   uint32_t etot = 0;
   for (uint32_t r = 0; r < nr; ++r) {
     uint32_t e = 0;
-    if (tstop > R->B[r]) { e = (tstop - R->B[r] + p - 1u) / p; const uint32_t cap = R->X[r] - 2u; e = e < cap ? e : cap; }
+    if (tstop > R->Bv[r]) { e = (tstop - R->Bv[r] + p - 1u) / p; const uint32_t cap = R->X[r] - 2u; e = e < cap ? e : cap; }
     if (lane == 0) R->PE[r] = etot;
     etot += e;
   }
@@ -400,67 +515,16 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     if ((uint64_t)base + etot > a.symcap) { a.dctl->err = 2; return 2; }
   }
-  // state of the chain at depth t: rows left, first row; the rows leaving exactly at t
-  auto state = [&](uint32_t t, uint32_t &xall, uint32_t &smin, uint32_t &nl, uint32_t *ld, uint32_t *le) {
-    xall = 0; smin = 0xFFFFFFFFu; nl = 0;
-    for (uint32_t r = 0; r < nr; ++r) {
-      const uint32_t B = R->B[r];
-      const uint32_t mm = t <= B ? 0u : (t - B + p - 1u) / p;          // first row of region r that is still there
-      xall += R->X[r] - mm;
-      const uint32_t r1 = a.isa[R->S[r] + mm * p - t], r2 = a.isa[R->E[r] - t];
-      smin = r1 < smin ? r1 : smin; smin = r2 < smin ? r2 : smin;
-      if (t >= B && (t - B) % p == 0) { ld[nl] = R->D[r]; le[nl] = R->PE[r] + mm; ++nl; }
-    }
-  };
-  for (uint32_t eb = 0; eb < etot; eb += 64) {
-    const uint32_t e = eb + lane;
-    if (e < etot) {
-      uint32_t r = 0;
-      while (e >= R->PE[r + 1u]) ++r;
-      const uint32_t t = R->B[r] + (e - R->PE[r]) * p;
-      uint32_t xall, pos, nl, ld[KD_REGIONS], le[KD_REGIONS];
-      state(t, xall, pos, nl, ld, le);
-      if (le[0] == e) {                                      // several regions may leave a row at this depth: the first one works
-        const uint32_t c = a.text[hi0 - t - 1u];
-        const uint32_t mainb = xall - nbar - nl;             // rows that stay, on the common side
-        uint32_t lm = (1u << nl) - 1u, nsy = 0;
-        for (uint32_t q = 0; q < 8u && lm; ++q) {
-          const uint32_t cq = (c >> q) & 1u;
-          uint32_t mino = 0, ones = 0, lq = 0;
-          for (uint32_t l = 0; l < nl; ++l) if ((lm >> l) & 1u) {
-            const uint32_t bit = (ld[l] >> q) & 1u;
-            ++lq; ones += bit;
-            if (bit != cq) mino |= 1u << l;
-          }
-          if (mino) {
-            const uint32_t xb = mainb + lq, x0n = beta ? nbar : xb, x1n = beta ? xb : nbar, xn = x0n + x1n;
-            const uint32_t n1x = (cq ? mainb + nbar : 0u) + ones, n0x = xn - n1x;
-            const int32_t u = (int32_t)(x0n - n1x), v = (int32_t)(n1x - x1n);
-            const uint32_t mn = u < 0 ? 0u : (uint32_t)u, mx = x0n - (v < 0 ? 0u : (uint32_t)v);
-            if (mx != mn) {
-              const uint32_t n0x0 = beta ? (cq ? 0u : nbar) : ((cq ? 0u : mainb) + (lq - ones));   // zeros among the first x0 rows
-              uint32_t kw, ew;
-              pack_symbol(k.cfg[q], q, n0x0 - mn, mx - mn + 1u, n0x, x1n, xn, kw, ew);
-              const uint64_t rr = round + 8ull * t + q;
-              const uint32_t i = base + le[nsy];
-              a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = pos;
-              a.trlo[i] = (uint32_t)rr;
-              a.trhi[i] = (uint32_t)(rr >> 32) | (q << 8);
-              atomicAdd(&a.dctl->cntp[q], 1u);
-              ++nsy;
-            }
-            lm &= ~mino;
-          }
-          const uint32_t r1 = rank1_plane(k, q, pos);
-          pos = cq ? k.zeros[q] + r1 : pos - r1;
-        }
-        for (uint32_t j = nsy; j < nl; ++j) { const uint32_t i = base + le[j]; a.ts[i] = 0; a.trlo[i] = 0; a.trhi[i] = KD_HOLE; }
-      }
-    }
+  if (lane == 0) {
+    R->kind = 2; R->p = p; R->x0 = x0; R->x1 = x1; R->base = base; R->events = etot; R->round = round;
+    R->nr = nr; R->beta = beta; R->nbar = nbar; R->hi0 = hi0;
   }
+  __syncthreads();
+  if (!stair_defer(a, *R, lane, true))
+    for (uint32_t e = lane; e < etot; e += 64) stairs_event(a, *R, e);
   {
     uint32_t xall, smin, nl, ld[KD_REGIONS], le[KD_REGIONS];
-    state(tstop, xall, smin, nl, ld, le);
+    stairs_state(a, *R, tstop, xall, smin, nl, ld, le);
     const uint32_t xb = xall - nbar;
     next = DNode{smin, beta ? nbar : xb, beta ? xb : nbar, 0u, round + 8ull * tstop};
   }
@@ -777,8 +841,8 @@ retry:
   const uint32_t wmax = qcap < KD_WALKERS ? qcap : KD_WALKERS;
   // carve: tkey tesc ts trlo trhi | sort keys x2 vals x2 | DfsCtl | queue x2 | stacks
   const size_t o_sort = (size_t)cap * 4 * 5, o_ctl = o_sort + (size_t)cap * 4 * 4, o_q = o_ctl + 512,
-               o_stack = o_q + 2 * (size_t)qcap * sizeof(DNode);
-  BCE_TRY(ensure(c, c->dfs, o_stack + (size_t)wmax * KD_STACK * sizeof(DNode)));
+               o_stack = o_q + 2 * (size_t)qcap * sizeof(DNode), o_jobs = o_stack + (size_t)wmax * KD_STACK * sizeof(DNode);
+  BCE_TRY(ensure(c, c->dfs, o_jobs + (size_t)KD_JOBS * sizeof(StairJob)));
   uint8_t *base = c->dfs.as<uint8_t>();
   DfsArgs a;
   a.k = k3_make_args(c, c->round, 0);
@@ -793,6 +857,7 @@ retry:
   a.dctl = reinterpret_cast<DfsCtl *>(base + o_ctl);
   DNode *queue[2] = {reinterpret_cast<DNode *>(base + o_q), reinterpret_cast<DNode *>(base + o_q) + qcap};
   a.stacks = reinterpret_cast<DNode *>(base + o_stack);
+  a.jobs = reinterpret_cast<StairJob *>(base + o_jobs);
   a.round0 = c->round;
   a.symcap = cap;
   a.out_cap = qcap;
@@ -800,7 +865,7 @@ retry:
   a.dbg = getenv("BCE_HIP_DFS_DEBUG") ? 1u : 0u;
   BCE_HIP_TRY(c, hipMemsetAsync(a.dctl, 0, sizeof(DfsCtl), c->stream));
   DfsCtl h;
-  uint32_t count = live, passes = 0;
+  uint32_t count = live, passes = 0, jobs_done = 0;
   double t_pass = 0.0;
   if (a.dbg) { BCE_HIP_TRY(c, hipStreamSynchronize(c->stream)); t_pass = now_s(); }
   const DNode *in = nullptr;
@@ -811,13 +876,17 @@ retry:
       hipLaunchKernelGGL(k3_dfs_kernel<true>, dim3(count), dim3(KD_T), 0, c->stream, a);
     else
       hipLaunchKernelGGL(k3_dfs_kernel<false>, dim3((walkers + KD_T - 1) / KD_T), dim3(KD_T), 0, c->stream, a);
+    // the long staircase stretches the walkers queued in this pass: their events, over the whole grid
+    hipLaunchKernelGGL(kd_jobs_kernel, dim3(1024), dim3(256), 0, c->stream, a, jobs_done);
     BCE_HIP_TRY(c, hipMemcpyAsync(&h, a.dctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
     BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
     BCE_HIP_TRY(c, hipGetLastError());
+    jobs_done = h.njobs < KD_JOBS ? h.njobs : KD_JOBS;
     if (a.dbg) {
       const double now = now_s();
       fprintf(stderr, "dfs pass %u: %u walkers%s, %.3f ms, %u queued, %u symbols so far\n", passes, count,
               (passes > 0 && count <= KD_UNI_MAX) ? " (waves)" : "", (now - t_pass) * 1e3, h.queued, h.nsym);
+      fprintf(stderr, "   staircase jobs so far: %u\n", jobs_done);
       fprintf(stderr, "   slowest chain-skip comparison so far: %llu K cycles, x = %llu, kk = %llu\n", h.dbg_slow >> 32, (h.dbg_slow >> 20) & 0xFFF, h.dbg_slow & 0xFFFFF);
       fprintf(stderr, "   slowest wave of this pass: %.2f M cycles, of which chain-skip comparisons %.2f M, staircases %.2f M\n",
               (double)(h.dbg_maxwave >> 40) * 4096e-6, (double)((h.dbg_maxwave >> 20) & 0xFFFFF) * 4096e-6, (double)(h.dbg_maxwave & 0xFFFFF) * 4096e-6);
