@@ -364,7 +364,9 @@ int bce_hip_encode(bce_hip_ctx *c) {
     BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     if ((!c->dbg_no_tail || cur_nodes == 0) && cur_nodes <= K3_TAIL_ENTER) {       // (no node at all, e.g. one byte repeated: only this kernel says "done" then)
       // narrow phase: the persistent single-workgroup kernel loops over rounds on the device
-      BCE_TRY(k3_tail(c));
+      // (while the depth-first tail may still take over, come back after 1024 rounds: an input that is one long run
+      //  or one table has this few nodes from the first round on, and its millions of rounds belong to the walkers)
+      BCE_TRY(k3_tail(c, (dfs_try < 2 && !c->dbg_no_dfs) ? 1024u : K3_TAIL_MAXROUNDS));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
       BCE_TRY(k3_sync_ctl(c, &ctl));
       executed = ctl.tail_rounds;

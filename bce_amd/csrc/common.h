@@ -176,7 +176,7 @@ int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint);
 int k3_rounds_small(bce_hip_ctx *c, uint32_t count, uint64_t cur_nodes, bool growing);   // one launch per round, narrow rounds
 int k3_clear_small_bail(bce_hip_ctx *c);   // queue `count` rounds from c->round (no sync)
 int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done);   // k3_dfs.hip: finish the enumeration depth-first
-int k3_tail(bce_hip_ctx *c);                        // queue the persistent narrow-round kernel from c->round (no sync)
+int k3_tail(bce_hip_ctx *c, uint32_t max_rounds = K3_TAIL_MAXROUNDS);   // queue the persistent narrow-round kernel from c->round (no sync)
 int k3_fetch_tail_runs(bce_hip_ctx *c, uint32_t rounds);
 int k3_sync_ctl(bce_hip_ctx *c, EnumCtl *out);      // copy the control block back (syncs the stream)
 int k3_fetch_runs(bce_hip_ctx *c, uint32_t first_round, uint32_t count);  // append run-table rows to run_log

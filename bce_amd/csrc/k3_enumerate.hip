@@ -915,12 +915,13 @@ int k3_clear_small_bail(bce_hip_ctx *c) {
   return BCE_HIP_OK;
 }
 
-int k3_tail(bce_hip_ctx *c) {
+int k3_tail(bce_hip_ctx *c, uint32_t max_rounds) {
+  if (max_rounds == 0 || max_rounds > K3_TAIL_MAXROUNDS) max_rounds = K3_TAIL_MAXROUNDS;
   BCE_TRY(ensure(c, c->truns, (size_t)K3_TAIL_MAXROUNDS * 8 * sizeof(RunEntry)));
   if (!c->h_truns) BCE_HIP_TRY(c, hipHostMalloc(&c->h_truns, (size_t)K3_TAIL_MAXROUNDS * 8 * sizeof(RunEntry), hipHostMallocDefault));
   const K3Args a = k3_make_args(c, c->round, 0);
-  if (c->scan_mode) hipLaunchKernelGGL(k3_tail_kernel<true>, dim3(1), dim3(KT_T), 0, c->stream, a, c->truns.as<RunEntry>(), K3_TAIL_MAXROUNDS);
-  else hipLaunchKernelGGL(k3_tail_kernel<false>, dim3(1), dim3(KT_T), 0, c->stream, a, c->truns.as<RunEntry>(), K3_TAIL_MAXROUNDS);
+  if (c->scan_mode) hipLaunchKernelGGL(k3_tail_kernel<true>, dim3(1), dim3(KT_T), 0, c->stream, a, c->truns.as<RunEntry>(), max_rounds);
+  else hipLaunchKernelGGL(k3_tail_kernel<false>, dim3(1), dim3(KT_T), 0, c->stream, a, c->truns.as<RunEntry>(), max_rounds);
   BCE_HIP_TRY(c, hipGetLastError());
   c->stats.k3_launches += 1.0;
   return BCE_HIP_OK;
