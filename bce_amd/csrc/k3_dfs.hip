@@ -12,8 +12,14 @@
 // bytes), and they end at row ISA[SA[s] - k], 8k rounds later, with (x0, x1) unchanged.  k is found by comparing
 // the text backwards from the x suffix-array positions (exact, no hashing).  SA / ISA are K1's arrays; the skip
 // is disabled when K1 did not end with all rotations distinct (periodic inputs) or the BWT was injected.
-// Chains that cannot be skipped but are regular (runs of one byte, periodic tables) are expanded in closed form:
-// see stair_run.
+//
+// Chains that cannot be skipped but are regular -- the rows are equally spaced text positions inside a run of one
+// byte or a periodic table, and one row leaves every period -- are expanded in closed form: stair_run (one region),
+// stairs_run (the same pattern in up to 8 places).  Their events are independent of each other; long stretches go on
+// a job list that a grid-wide kernel works off after the pass (kd_jobs_kernel).
+//
+// Passes: lane = walker while many nodes are queued; wave = walker (scalar registers, scalar loads, a tight loop
+// over pass-through nodes) once <= KD_UNI_MAX are left.  A walker hands its work on after a.budget nodes.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -45,7 +51,7 @@ struct DfsCtl {
   uint32_t pad;
   uint32_t njobs, pad2;  // staircase jobs queued so far
   uint32_t dbg_hist[32]; uint32_t dbg_maxvis; uint32_t dbg_skips; uint64_t dbg_skipbytes;
-  uint32_t dbg_stairs, dbg_stairsyms; uint64_t dbg_stairnodes;
+  uint32_t dbg_stairs, dbg_stairsyms;
   unsigned long long dbg_slow;   // slowest chain-skip comparison: cycles >> 10 in the high half, x << 20 | min(kk, 2^20 - 1) below
   unsigned long long dbg_maxwave;   // slowest wave: cycles >> 12 of (walk, chain-skip comparisons, staircases), 20 bits each
   uint64_t dbg_cyc[4];   // wave cycles: whole walk, chain-skip comparisons, staircases; [3] = staircase looks

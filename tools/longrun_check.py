@@ -1,5 +1,8 @@
-import sys, time, hashlib
-sys.path.insert(0, '/root/repo')
+"""Megabyte runs and tables through the encoder (vs the oracle) and the GPU-assisted decoder, with times: the inputs the
+staircase closed forms (k3_dfs.hip) and the decoder's host tail (kd_decode.hip) exist for.
+    python tools/longrun_check.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bce_amd, oracle
 text = oracle.synth_text(5, 3000000)
 cases = {
