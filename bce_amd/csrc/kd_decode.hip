@@ -24,6 +24,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -1029,6 +1030,10 @@ struct Mailbox {               // a few host-coherent words the wave tail kernel
 // max(kHostTailMin, n / 400) rounds on <= 64 nodes, the boundary ranks (8 x 4(n+1) B) and the node lists come to the host, the rounds
 // are finished here exactly as `bce -ds` runs them (decoder.cpp, BCE::code mode 0, bce.cpp:1246-1371, same decoders),
 // and the ranks go back for the plane fill.  The copies are ~2 x 60 ms per 10^8 bytes.
+__global__ void dec_scatter_kernel(uint32_t *__restrict__ R, const uint64_t *__restrict__ idx, const uint32_t *__restrict__ val, uint64_t m) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) R[idx[i]] = val[i];
+}
+
 constexpr uint32_t kHostTailMin = 50000;                    // ... rounds, or n / 400 if that is more (the copies cost ~n)
 
 int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vector<Decoder> &dec, uint32_t n, uint32_t *round,
@@ -1048,14 +1053,17 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
     }
   }
   const size_t stride = (size_t)n + 1;
-  std::vector<uint32_t> Rh(8 * stride);
-  BCE_HIP_TRY(c, hipMemcpy(Rh.data(), a.R, Rh.size() * 4, hipMemcpyDeviceToHost));
+  std::unique_ptr<uint32_t[]> Rbuf(new uint32_t[8 * stride]);             // (not value-initialised: 3.2 GB at 10^8 bytes)
+  uint32_t *Rh = Rbuf.get();
+  BCE_HIP_TRY(c, hipMemcpy(Rh, a.R, 8 * stride * 4, hipMemcpyDeviceToHost));
+  std::vector<uint64_t> widx;                                              // what the host learns goes back as (index, value) pairs
+  std::vector<uint32_t> wval;
   bool bad = false;
   uint64_t nodes = 0, queries = 0;
   uint32_t rounds = 0;
   for (bool again = true; again && !bad;) {
     for (uint32_t i = 0; i < 8 && !bad; ++i) {
-      uint32_t *R = Rh.data() + (size_t)i * stride;
+      uint32_t *R = Rh + (size_t)i * stride;
       const uint32_t zi = a.zeros[i];
       for (int j = 0; j < 2 && !bad; ++j)
         for (const Node &nd : cur[i][j]) {
@@ -1082,6 +1090,7 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
             if (n1x0 && n1x1) nxt[(i + 1) & 7][1].push_back(Node{zi + s1, n1x0, n1x1});
           }
           R[s + x0] = s1 + n1x0;
+          if (widx.size() <= stride) { widx.push_back((uint64_t)i * stride + s + x0); wval.push_back(s1 + n1x0); }   // beyond that the whole array goes back
           ++nodes;
         }
     }
@@ -1092,7 +1101,19 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
   }
   *bad_out = bad;
   if (bad) return BCE_HIP_OK;
-  BCE_HIP_TRY(c, hipMemcpy(a.R, Rh.data(), Rh.size() * 4, hipMemcpyHostToDevice));
+  if (widx.size() > stride) {                                            // (more than an eighth of everything: the whole array)
+    BCE_HIP_TRY(c, hipMemcpy(a.R, Rh, 8 * stride * 4, hipMemcpyHostToDevice));
+  } else if (!widx.empty()) {
+    const size_t m = widx.size();
+    BCE_TRY(ensure(c, c->skey[0], m * 8));
+    BCE_TRY(ensure(c, c->skey[1], m * 4));
+    BCE_HIP_TRY(c, hipMemcpy(c->skey[0].p, widx.data(), m * 8, hipMemcpyHostToDevice));
+    BCE_HIP_TRY(c, hipMemcpy(c->skey[1].p, wval.data(), m * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(dec_scatter_kernel, dim3((unsigned)((m + 255) / 256 < 4096 ? (m + 255) / 256 : 4096)), dim3(256), 0, c->stream,
+                       a.R, c->skey[0].as<uint64_t>(), c->skey[1].as<uint32_t>(), (uint64_t)m);
+    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    BCE_HIP_TRY(c, hipGetLastError());
+  }
   *round += rounds; *nodes_total += nodes; *queries_total += queries;
   return BCE_HIP_OK;
 }
