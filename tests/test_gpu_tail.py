@@ -204,3 +204,24 @@ def test_inputs_without_nodes_on_every_path(data):
     for knobs in ({}, {1: 1, 2: 1, 4: 1}, {2: 1}, {2: 1, 4: 1, 6: 1}, {1: 1}):
         arch, _ = _encode_with_knobs(data, knobs)
         assert arch == want, "knobs %r" % (knobs,)
+
+
+def test_megabyte_runs_do_not_crawl():
+    """Two zero runs of 1.2 MB and 0.8 MB (19 M rounds): the closed forms keep the encoder at a fraction of a second
+    (the walkers alone took a minute), the decoder's host tail keeps it at a few seconds; both exact."""
+    text = oracle.synth_text(6, 600000)
+    data = text[:200000] + bytes(1200000) + text[200000:400000] + bytes(800000) + b"\x01" + text[400000:]
+    want = oracle.compress(data)
+    rf = bce_amd.RankFile(data)
+    try:
+        t0 = time.time()
+        arch = bce_amd.BCE().encode(rf)
+        t_enc = time.time() - t0
+    finally:
+        rf.close()
+    assert arch == want
+    t0 = time.time()
+    assert bce_amd.decompress_device(arch) == data
+    t_dec = time.time() - t0
+    print("megabyte runs: encode %.2f s, decode %.2f s" % (t_enc, t_dec))
+    assert t_enc < 5.0 and t_dec < 20.0
