@@ -316,7 +316,9 @@ int bce_hip_enum_model(bce_hip_ctx *c, uint32_t *out, uint64_t cap_records, uint
 }
 
 // ---- BCE::encode ------------------------------------------------------------------------------------
-int bce_hip_encode(bce_hip_ctx *c) {
+static int encode_body(bce_hip_ctx *c);
+int bce_hip_encode(bce_hip_ctx *c) { return bce_guarded(c, [&] { return encode_body(c); }); }
+static int encode_body(bce_hip_ctx *c) {
   BCE_TRY(check_stage(c, 3));
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t n = c->n;
@@ -461,7 +463,11 @@ int bce_hip_encode(bce_hip_ctx *c) {
 // `bce -s`: BCE<ScanCoder<31>, unbwt::noop>::encode + save_config (bce.cpp:1384-1402, 726-834).  The enumeration
 // runs on the GPU in scan mode (raw symbol tuples instead of model records); the eight ScanCoders consume them on
 // the host in stream order, then pick the context bits.
+static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes);
 int bce_hip_scan(bce_hip_ctx *c, uint8_t config288[BCE_HIP_CONFIG_BYTES], double result_bytes[9]) {
+  return bce_guarded(c, [&] { return scan_body(c, config288, result_bytes); });
+}
+static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes) {
   BCE_TRY(check_stage(c, 3));
   if (!config288) return BCE_HIP_E_ARG;
   BCE_HIP_TRY(c, hipSetDevice(c->device));

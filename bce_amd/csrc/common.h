@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <chrono>
+#include <exception>
+#include <new>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -152,6 +154,16 @@ inline int ensure(bce_hip_ctx *c, DevBuf &b, size_t bytes) {
 inline void release(DevBuf &b) {
   if (b.p) (void)hipFree(b.p);
   b.p = nullptr; b.cap = 0;
+}
+
+// C ABI boundary: no C++ exception may leave an entry point (a host allocation that fails in a std::vector, a thread that
+// cannot be started): the heavy entry points run their body through this.
+template <class F>
+inline int bce_guarded(bce_hip_ctx *c, F &&body) {
+  try { return body(); }
+  catch (const std::bad_alloc &) { if (c) snprintf(c->err, sizeof c->err, "host allocation failed"); return BCE_HIP_E_NOMEM; }
+  catch (const std::exception &e) { if (c) snprintf(c->err, sizeof c->err, "%s", e.what()); return BCE_HIP_E_INTERNAL; }
+  catch (...) { if (c) snprintf(c->err, sizeof c->err, "unknown exception"); return BCE_HIP_E_INTERNAL; }
 }
 
 inline double now_s() {

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <new>
 #include <stdio.h>
 #include <vector>
 
@@ -35,7 +36,13 @@ struct Triple { uint32_t s, x0, x1; };
 }  // namespace
 
 // Decode an archive produced by `bce -c`.  out == NULL: only report the decoded size in *out_len.
+static int decompress_body(const uint8_t *archive, size_t len, uint8_t *out, size_t cap, size_t *out_len);
 extern "C" int bce_hip_decompress(const uint8_t *archive, size_t len, uint8_t *out, size_t cap, size_t *out_len) {
+  try { return decompress_body(archive, len, out, cap, out_len); }          // no C++ exception may cross the C ABI
+  catch (const std::bad_alloc &) { return BCE_HIP_E_NOMEM; }
+  catch (...) { return BCE_HIP_E_INTERNAL; }
+}
+static int decompress_body(const uint8_t *archive, size_t len, uint8_t *out, size_t cap, size_t *out_len) {
   if (!archive || !out_len) return BCE_HIP_E_ARG;
   bce::ArchiveHead hd;
   if (bce::parse_archive(archive, len, hd, /*header_only=*/true) != 0) return BCE_HIP_E_ARG;

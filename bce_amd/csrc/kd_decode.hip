@@ -1131,8 +1131,12 @@ using namespace bce;
 
 // `bce -d` on the GPU: archive -> original bytes (see the header of this file).  The context is only used for its
 // device, stream and scratch buffers; any compression state in it is dropped.
+static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t len, uint8_t *out, size_t cap, size_t *out_len);
 extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive, size_t len, uint8_t *out, size_t cap,
                                          size_t *out_len) {
+  return bce_guarded(c, [&] { return decompress_device_body(c, archive, len, out, cap, out_len); });
+}
+static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t len, uint8_t *out, size_t cap, size_t *out_len) {
   if (!c || !archive || !out_len) return BCE_HIP_E_ARG;
   ArchiveHead hd;
   if (parse_archive(archive, len, hd, /*header_only=*/true) != 0) return BCE_HIP_E_ARG;
