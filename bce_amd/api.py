@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libbcehip.so")
+_LIB_PATH = os.environ.get("BCE_HIP_LIB") or os.path.join(_HERE, "lib", "libbcehip.so")   # (BCE_HIP_LIB: kernel-variant experiments)
 _lib = None
 
 CONFIG_BYTES = 288
@@ -271,13 +271,14 @@ def stats(rf: RankFile) -> dict:
     return st.as_dict()
 
 
-def compress(data, config=None, device=0) -> bytes:
+def compress(data, config=None, device=0, ctx=None) -> bytes:
     """`bce -c` on an in-memory buffer (bce.cpp:1403-1427 minus file I/O) -> archive bytes."""
-    rf = RankFile(data, device=device)
+    rf = RankFile(data, device=device, ctx=ctx)
     try:
         return BCE(config).encode(rf)
     finally:
-        rf.close()
+        if ctx is None:
+            rf.close()
 
 
 def compress_device(device_ptr, n, config=None, device=0, ctx=None):

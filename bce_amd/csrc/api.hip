@@ -78,9 +78,14 @@ int flush_symbols(bce_hip_ctx *c, uint64_t nsym) {
 
 extern "C" {
 
+static int create_body(bce_hip_ctx **out, int device);
 int bce_hip_create(bce_hip_ctx **out, int device) {
   if (!out) return BCE_HIP_E_ARG;
   *out = nullptr;
+  // (HostCoder starts 8 threads: std::system_error must not cross the C ABI)
+  return bce_guarded(nullptr, [&] { return create_body(out, device); });
+}
+static int create_body(bce_hip_ctx **out, int device) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return BCE_HIP_E_DEVICE;
   bce_hip_ctx *c = new (std::nothrow) bce_hip_ctx();
@@ -95,7 +100,8 @@ int bce_hip_create(bce_hip_ctx **out, int device) {
     return BCE_HIP_E_DEVICE;
   }
   c->sync_flush = getenv("BCE_HIP_SYNC_FLUSH") != nullptr;
-  c->coder = new (std::nothrow) HostCoder();
+  try { c->coder = new HostCoder(); }
+  catch (...) { c->coder = nullptr; }
   if (!c->coder) { bce_hip_destroy(c); return BCE_HIP_E_NOMEM; }
   *out = c;
   return BCE_HIP_OK;
@@ -168,6 +174,10 @@ int bce_hip_debug_set(bce_hip_ctx *c, int knob, uint32_t value) {
     case 4: c->dbg_no_small = value; break;
     case 5: c->dbg_step_small = value; break;
     case 6: c->dbg_no_fused = value; break;
+    case 7: c->dbg_no_local = value; break;
+    case 8: c->dbg_local_from = value; break;
+    case 9: c->dbg_local_budget = value; break;
+    case 10: c->dbg_tail_round = value; break;
     case 2: c->dbg_no_tail = value; break;
     case 3: c->dbg_no_skip = value; break;
     default: return BCE_HIP_E_ARG;
@@ -336,7 +346,9 @@ static int encode_body(bce_hip_ctx *c) {
   bool have_ctl = false, wide_once = false;
   const uint32_t early_max = 4;                   // early small flushes: 1M, 2M, 4M, 8M records (0..5 measured: +3 % on text, neutral on random data)
   // depth-first tail: first attempt when the live set is small, a second one (if the first ran out of room) when tiny
-  uint32_t kDfsEnter[2] = {65536u, 2048u};
+  // (first attempt: from 2 M live nodes down the tail starts with workgroup-local rounds, k3_local_kernel; without them
+  //  the walkers alone take over at 65 536)
+  uint32_t kDfsEnter[2] = {c->dbg_no_local ? 65536u : (2u << 20), 2048u};
   if (const char *e = getenv("BCE_HIP_DFS_ENTER")) kDfsEnter[0] = (uint32_t)strtoul(e, nullptr, 10);
   int dfs_try = 0;
   for (;;) {
@@ -344,7 +356,7 @@ static int encode_body(bce_hip_ctx *c) {
       // few live nodes and almost everything visited: finish depth-first (k3_dfs.hip).  The walkers' symbols
       // come after everything emitted so far, so flush that first.
       const uint64_t all = 8ull * (n - 1);
-      if (dfs_try < 2 && ctl.next_nodes && ctl.next_nodes <= kDfsEnter[dfs_try] && (ctl.nodes_total >= all / 8 || c->round >= 1024u)) {
+      if (dfs_try < 2 && ctl.next_nodes && ctl.next_nodes <= kDfsEnter[dfs_try] && (ctl.nodes_total >= all / 8 || c->round >= 1024u || c->dbg_tail_round)) {
         BCE_TRY(flush_symbols(c, ctl.sym_total));
         ctl.sym_total = 0;
         bool dfs_done = false;
@@ -418,6 +430,7 @@ static int encode_body(bce_hip_ctx *c) {
     c->round = first + executed;
     if (c->progress) c->progress(ctl.nodes_total, 8ull * n, c->progress_user);
     decaying = ctl.next_nodes <= cur_nodes && c->round > 16;   // past the ramp-up: the node count no longer doubles
+    if (c->dbg_tail_round && c->round >= c->dbg_tail_round) decaying = true;   // test knob 10: the tail starts while the count still grows
     have_ctl = true;
     cur_nodes = ctl.next_nodes;
     const bool done = ctl.done_round != 0xFFFFFFFFu;
@@ -450,6 +463,7 @@ static int encode_body(bce_hip_ctx *c) {
     c->stats.t_coder += now_s() - tw;
     for (FlushSlot &sl : c->slot) account_slot(c, sl);
   }
+  if (c->coder->failed()) { snprintf(c->err, sizeof c->err, "host allocation failed in a range-coder thread"); return BCE_HIP_E_NOMEM; }
   c->stats.t_coder_busy = c->coder->busy_seconds();
   c->stats.rounds = ctl.done_round;
   c->stats.nodes = ctl.nodes_total;
@@ -552,8 +566,7 @@ int bce_hip_archive_copy(bce_hip_ctx *c, uint8_t *out, size_t cap) {
   BCE_TRY(check_stage(c, 4));
   if (!out) return BCE_HIP_E_ARG;
   if (cap < c->coder->archive_words() * 2) return BCE_HIP_E_OVERFLOW;
-  c->coder->assemble(reinterpret_cast<uint16_t *>(out));
-  return BCE_HIP_OK;
+  return bce_guarded(c, [&] { c->coder->assemble(reinterpret_cast<uint16_t *>(out)); return (int)BCE_HIP_OK; });
 }
 
 static int compress_loaded(bce_hip_ctx *c, uint8_t *out, size_t cap, size_t *out_len) {

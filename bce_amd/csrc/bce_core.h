@@ -34,13 +34,24 @@ BCE_HD uint32_t popc32(uint32_t x) {
 }
 
 // floor(s / 96) for any 32-bit s: s/3 = (s * 0xAAAAAAAB) >> 33, then / 32.
-BCE_HD uint32_t div96(uint32_t s) { return (uint32_t)(((uint64_t)s * 0xAAAAAAABull) >> 38); }
+BCE_HD uint32_t div96(uint32_t s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umulhi(s, 0xAAAAAAABu) >> 6;          // one v_mul_hi_u32 (the 64-bit product form compiles to v_mad_u64_u32)
+#else
+  return (uint32_t)(((uint64_t)s * 0xAAAAAAABull) >> 38);
+#endif
+}
 
-// rank1 inside one granule for offset o in [0, 96)
+// rank1 inside one granule for offset o in [0, 96): b = the bits below o & 31; the word o falls in is masked with b, the
+// words before it count whole, the words after it not at all.  ~13 VALU instructions on the device (two compares, one
+// v_bfm, four selects, three ands, three popcounts with accumulate) -- the rank is the inner loop of every K3 kernel.
+// (Selecting the WORD by o instead of the masks makes the compiler index the granule through scratch memory.)
 BCE_HD uint32_t granule_rank1(const Granule &g, uint32_t o) {
-  uint32_t m0 = o >= 32 ? 0xFFFFFFFFu : ((1u << o) - 1u);
-  uint32_t m1 = o >= 64 ? 0xFFFFFFFFu : (o > 32 ? ((1u << (o - 32)) - 1u) : 0u);
-  uint32_t m2 = o > 64 ? ((1u << (o - 64)) - 1u) : 0u;
+  const bool lt32 = o < 32u, lt64 = o < 64u;
+  const uint32_t b = (1u << (o & 31u)) - 1u;
+  const uint32_t m0 = lt32 ? b : 0xFFFFFFFFu;
+  const uint32_t m1 = lt32 ? 0u : (lt64 ? b : 0xFFFFFFFFu);
+  const uint32_t m2 = lt64 ? 0u : b;
   return g.cum + popc32(g.w0 & m0) + popc32(g.w1 & m1) + popc32(g.w2 & m2);
 }
 
@@ -162,17 +173,27 @@ BCE_HD void node_step(const Node &nd, uint32_t zeros_p, Rank1 rank1, StepOut &o)
 
 // floor(a / b) for quotients known to be < 2^24 (here < 32): one float reciprocal and an exact integer
 // correction instead of the generic ~30-instruction u32 division.  Exact: the float estimate is within +-1.
+// Host and device run the SAME arithmetic (rn conversions, a correctly rounded reciprocal, one rn multiply),
+// so tests/test_core_cpu.py checks on the CPU exactly what the kernels compute.
 BCE_HD uint32_t small_quotient(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  uint32_t q = (uint32_t)((float)a * __frcp_rn((float)b));
+  const float r = __frcp_rn((float)b);
+#else
+  const float r = 1.0f / (float)b;
+#endif
+  uint32_t q = (uint32_t)((float)a * r);
   // q may be off by one either way (and a*rcp can round up to 2^k): fix with exact arithmetic
   uint64_t prod = (uint64_t)q * b;
   if (prod > a) { --q; prod -= b; }
   if ((uint64_t)a - prod >= b) ++q;
   return q;
-#else
-  return a / b;
-#endif
+}
+
+// AdaptiveCoder::get_context's slot number (bce.cpp:671-677): ctx = (((c1 << bits) / cs) << bits) | ((c2 << bits) / cs)
+// in uint32 arithmetic, i.e. c1 << bits WRAPS for c1 >= 2^(32-bits) (inputs of 2^27 bytes and more).
+// Both quotients stay < 2^bits <= 32 (c1, c2 < cs; after a wrap cs > c1 >= 2^(32-bits) bounds it too).
+BCE_HD uint32_t context_index(uint32_t bits, uint32_t c1, uint32_t c2, uint32_t cs) {
+  return (small_quotient((uint32_t)(c1 << bits), cs) << bits) | small_quotient((uint32_t)(c2 << bits), cs);
 }
 
 // Symbol record = two u32 words kept in two arrays (SoA):
@@ -194,8 +215,7 @@ BCE_HD void pack_symbol(const PlaneCfg &cfg, uint32_t plane, uint32_t sym, uint3
     sym >>= 1;
   }
   const uint32_t bits = cfg.bits[k];
-  // both quotients are < 2^bits <= 32 (c1, c2 < cs; also after the uint32 wrap of c1 << bits)
-  const uint32_t ctx = (small_quotient((uint32_t)(c1 << bits), cs) << bits) | small_quotient((uint32_t)(c2 << bits), cs);
+  const uint32_t ctx = context_index(bits, c1, c2, cs);
   const uint32_t slot = cfg.ctxoff[k] + ctx;
   key_word = sym | (k << 5) | (slot << 10) | (plane << 26);
   esc_word = esc | (nesc << 27);

@@ -81,7 +81,7 @@ struct bce_hip_ctx {
   bool k1_valid = false;                         // sa[sa_res] / rank hold this input's suffix order (K1 ran; no injected BWT)
   int sa_res = 0;
   // debug knobs (bce_hip_debug_set): 0 = default
-  uint32_t dbg_dfs_budget = 0, dbg_no_dfs = 0, dbg_no_tail = 0, dbg_no_skip = 0, dbg_no_small = 0, dbg_step_small = 0, dbg_no_fused = 0;
+  uint32_t dbg_dfs_budget = 0, dbg_no_dfs = 0, dbg_no_tail = 0, dbg_no_skip = 0, dbg_no_small = 0, dbg_step_small = 0, dbg_no_fused = 0, dbg_no_local = 0, dbg_local_from = 0, dbg_local_budget = 0, dbg_tail_round = 0;
   uint64_t sym_cap_user = 0;
   bool sync_flush = false;                       // BCE_HIP_SYNC_FLUSH: flushes wait for their copy (profiling)
   bce_hip_progress_fn progress = nullptr;        // bce_hip_set_progress

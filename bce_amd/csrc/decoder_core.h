@@ -49,6 +49,7 @@ struct alignas(128) Decoder {
     }
   }
   uint32_t get(uint32_t k) {                                     // :592-608
+    if (k == 0) return 0;                                        // (only a crafted header asks this: no division by zero)
     if (R - 1 < k) reset();                                      // h - l < k (never with the full range: R - 1 wraps to 2^64 - 1)
     const uint64_t step = (R - 1) / k;
     const uint32_t s = (uint32_t)(D / step);
@@ -279,7 +280,9 @@ inline int parse_archive(const uint8_t *archive, size_t len, ArchiveHead &hd, bo
   mainc.open(w + 1, header_size);
   mainc.init();
   hd.n = mainc.getv();                                            // :1181-1183
-  if (hd.n == 0) return -1;
+  // n < 2^31 is what the encoder accepts (saidx_t) and what every size computed from n assumes; a crafted header can
+  // decode to more (getv reads up to 31 bits and a slack symbol), and n + 1 would wrap to 0 in the next get()
+  if (hd.n == 0 || hd.n >= 0x80000000u) return -1;
   hd.offset = mainc.get(hd.n + 1);
   uint32_t size = mainc.getv();
   if (header_only) return 0;

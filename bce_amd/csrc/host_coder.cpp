@@ -52,6 +52,7 @@ void RangeCoder::flush() {
 
 void HostCoder::begin(const uint8_t config[9][32], const uint32_t C[8], uint32_t n) {
   drain();
+  failed_.store(false);
   for (int i = 0; i < 8; ++i) {
     w_[i].busy = 0; w_[i].nsym = 0;
     plane[i] = RangeCoder();
@@ -142,16 +143,25 @@ void HostCoder::consume(int p, const SymRun *runs, size_t nruns, const uint64_t 
 }
 
 HostCoder::HostCoder() {
-  for (int p = 0; p < 8; ++p) w_[p].th = std::thread([this, p]() { run(p); });
+  // (std::thread may throw std::system_error: the threads started so far are stopped and joined before it goes on to
+  //  the caller, bce_hip_create, which turns it into a status)
+  try {
+    for (int p = 0; p < 8; ++p) w_[p].th = std::thread([this, p]() { run(p); });
+  } catch (...) {
+    stop_threads();
+    throw;
+  }
 }
 
-HostCoder::~HostCoder() {
+void HostCoder::stop_threads() {
   for (int p = 0; p < 8; ++p) {
     { std::lock_guard<std::mutex> g(w_[p].mu); w_[p].stop = true; }
     w_[p].cv.notify_all();
   }
   for (int p = 0; p < 8; ++p) if (w_[p].th.joinable()) w_[p].th.join();
 }
+
+HostCoder::~HostCoder() { stop_threads(); }
 
 void HostCoder::run(int p) {
   Worker &w = w_[p];
@@ -164,10 +174,19 @@ void HostCoder::run(int p) {
       b = w.q.front();
       w.q.pop_front();
     }
-    if (b->wait_ready) b->wait_ready();
     const auto t0 = std::chrono::steady_clock::now();
-    consume(p, b->runs[p].data(), b->runs[p].size(), b->out);
-    for (const SymRun &r : b->runs[p]) w.nsym += r.count;
+    // No exception leaves this thread (it would end in std::terminate, across the C ABI): a failed allocation of the
+    // output vector marks the coder as failed; the batch still counts as done so that wait / drain never hang, and
+    // the encode entry point reports BCE_HIP_E_NOMEM (failed()).
+    try {
+      if (b->wait_ready) b->wait_ready();
+      if (!failed_.load(std::memory_order_relaxed)) {
+        consume(p, b->runs[p].data(), b->runs[p].size(), b->out);
+        for (const SymRun &r : b->runs[p]) w.nsym += r.count;
+      }
+    } catch (...) {
+      failed_.store(true);
+    }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     {
       std::lock_guard<std::mutex> g(done_mu_);
@@ -246,9 +265,19 @@ void HostCoder::assemble(uint16_t *dst) const {          // :1152-1157
     for (int i = 0; i < 8; ++i) memcpy(at[i], plane[i].data().data(), plane[i].data().size() * 2);
     return;
   }
+  // (a thread that cannot be started: the threads running are joined and this one copies the rest -- never a
+  //  joinable std::thread destroyed, never an exception out of here)
   std::thread th[8];
-  for (int i = 0; i < 8; ++i) th[i] = std::thread([this, i, &at] { memcpy(at[i], plane[i].data().data(), plane[i].data().size() * 2); });
-  for (int i = 0; i < 8; ++i) th[i].join();
+  int started = 0;
+  try {
+    for (; started < 8; ++started) {
+      const int i = started;
+      th[i] = std::thread([this, i, &at] { memcpy(at[i], plane[i].data().data(), plane[i].data().size() * 2); });
+    }
+  } catch (...) {
+  }
+  for (int i = started; i < 8; ++i) memcpy(at[i], plane[i].data().data(), plane[i].data().size() * 2);
+  for (int i = 0; i < started; ++i) th[i].join();
 }
 
 void HostCoder::finish(const uint8_t config[9][32], uint32_t n, uint32_t offset, std::vector<uint16_t> &archive) {

@@ -83,6 +83,7 @@ struct HostCoder {
   void assemble(uint16_t *dst) const;
   void finish(const uint8_t config[9][32], uint32_t n, uint32_t offset, std::vector<uint16_t> &archive);   // all in one (tests)
   double busy_seconds();             // max over planes of the time spent coding since begin()
+  bool failed() const { return failed_.load(); }   // a coder thread ran out of memory since begin()
 
  private:
   struct Worker {
@@ -99,7 +100,9 @@ struct HostCoder {
   std::condition_variable done_cv_;
   std::vector<uint16_t> header_;             // the coded header of the last finish()
   uint64_t submitted_ = 0, completed_ = 0;   // in units of (batch, plane); guarded by done_mu_
+  std::atomic<bool> failed_{false};
   void run(int p);
+  void stop_threads();
 };
 
 // Exact floor(x / d) for d < kRecipMax by one multiplication (host_coder.cpp explains the two magic variants).

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "scan_util.h"
 #include "k3_args.h"
 
 namespace bce {
@@ -39,7 +40,8 @@ constexpr uint32_t KD_SBLK = 8;                // tagged-symbol slots a walker r
 constexpr uint32_t KD_HOLE = 0x7FFu;           // (plane, round high) of an unused slot: sorts behind every real symbol
 constexpr uint32_t KD_STAIR_MIN = 32;            // rows from which a walker at plane 0 looks for a staircase (see stair_run)
 constexpr uint32_t KD_STAIR_RETRY = 256;         // nodes a walker waits after a failed look
-constexpr uint32_t K3_DFS_PASS = 4096;         // nodes one walker classifies per pass before it hands its work on
+constexpr uint32_t K3_DFS_PASS = 4096;         // nodes one WAVE-walker classifies per pass before it hands its work on
+constexpr uint32_t K3_DFS_LANE_PASS = 256;     // ... and one lane-walker (64 of them advance in lockstep: a pass lasts as long as its longest walk)
 
 struct DfsCtl {
   uint32_t nsym;         // tagged symbols emitted
@@ -48,7 +50,7 @@ struct DfsCtl {
   uint64_t maxround;
   uint32_t cntp[8];      // symbols per plane
   uint32_t queued;       // nodes handed to the next pass
-  uint32_t pad;
+  uint32_t spilled;      // k3_local_kernel: children that did not fit a workgroup's LDS list (worked off by another local pass)
   uint32_t njobs, pad2;  // staircase jobs queued so far
   uint32_t dbg_hist[32]; uint32_t dbg_maxvis; uint32_t dbg_skips; uint64_t dbg_skipbytes;
   uint32_t dbg_stairs, dbg_stairsyms;
@@ -92,6 +94,12 @@ struct DfsArgs {
   uint32_t symcap;
   uint32_t budget;
   uint32_t dbg;
+  DNode *spill;          // k3_local_kernel: overflow of a workgroup's LDS list
+  uint32_t spill_cap;
+  uint32_t lb_budget;    // rounds a workgroup runs in one pass
+  uint32_t lane_budget;  // nodes a LANE-walker classifies per pass (the wave runs as long as its longest walker: keep it short)
+  uint32_t lpw;          // lane-walkers per wave (the other lanes only help with the cooperative comparisons)
+  uint32_t lb_quiet;     // pass-through levels after which a child arriving at plane 0 is a chain for the walkers
 };
 
 // granule_rank1 with 64-bit masks (fewer scalar instructions)
@@ -552,8 +560,10 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   const K3Args &k = a.k;
   const EnumCtl *ctl = k.ctl;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t gid = UNI ? blockIdx.x : blockIdx.x * KD_T + threadIdx.x;
-  const uint32_t W = UNI ? gridDim.x : gridDim.x * KD_T;
+  // (lane-walkers: only the first a.lpw lanes of a wave walk -- a wave serves its walkers' chain comparisons one after
+  //  the other, so when there are fewer walkers than lanes on the chip they are spread over more waves)
+  const uint32_t gid = UNI ? blockIdx.x : blockIdx.x * a.lpw + threadIdx.x;
+  const uint32_t W = UNI ? gridDim.x : gridDim.x * a.lpw;
   const bool writer = !UNI || lane == 0;                     // side effects of a wave-walker: one lane
   // A value a vector load returned is "divergent" to the compiler even when every lane loaded the same address:
   // readfirstlane moves it to a scalar register, and everything computed from it follows.
@@ -586,7 +596,7 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
     return uni_node(DNode{nd.s, nd.x0, nd.x1, p, a.round0});
   };
   uint32_t next = gid;                                        // my next queued node
-  bool alive = next < a.in_count;
+  bool alive = next < a.in_count && (UNI || lane < a.lpw);
   DNode cur{0u, 1u, 1u, 1u, 0ull};
   if (alive) { cur = fetch(next); next += W; }
   DNode *stack = UNI ? lstack : a.stacks + (size_t)gid * KD_STACK;     // a wave-walker's stack: LDS, every lane writes the same
@@ -609,7 +619,7 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   const uint64_t cyc0 = a.dbg ? clock64() : 0;
   while (__any(alive)) {
     if ((visited & 31u) == 0) seen_err = uni(a.dctl->err);          // a long chain should not wait for this load on every node
-    if (alive && (visited >= a.budget || seen_err)) {
+    if (alive && (visited >= (UNI ? a.budget : a.lane_budget) || seen_err)) {
       // hand on: current node, stack, queued nodes not started
       uint32_t rest = 0;
       if (next < a.in_count) rest = (a.in_count - next + W - 1u) / W;
@@ -800,6 +810,267 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   atomicMax((unsigned long long *)&a.dctl->maxround, (unsigned long long)maxround);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Workgroup-local rounds.  Between the wide rounds (millions of nodes, two launches each) and the walkers (<= 65 536
+// nodes, one lane each) lie hundreds of rounds of 10^5..10^6 nodes: too few to hide a launch (a round costs 16-50 us
+// whatever it holds) and too bushy for one lane per subtree.  Subtrees are independent and the round structure only
+// orders the symbols, so here every workgroup takes LB_IN consecutive live nodes and runs THEIR rounds on its own:
+// both list buffers in LDS, one classification per node (no count pass: the compaction is a block scan), no launch
+// and no grid-wide step between rounds.  Symbols are tagged (plane, round, s) like the walkers' and sorted into stream
+// order with theirs.  A workgroup stops after lb_budget rounds or when fewer than LB_MIN nodes are left and hands those
+// to the walkers' queue; a child that arrives at plane 0 after a whole byte of pass-through levels (the start of a
+// chain the walkers can skip) goes there at once.  Children that do not fit the LDS list are spilled to a global
+// queue that another launch of this kernel works off.
+// ------------------------------------------------------------------------------------------------------
+#ifndef LB_T_VALUE
+#define LB_T_VALUE 256
+#endif
+constexpr int LB_T = LB_T_VALUE;               // (one wave per workgroup -- LB_T_VALUE 64 -- was measured: 11.4 instead of 4.4 ms for the
+                                               //  first pass over the natural corpus)
+constexpr int LB_NPT = LB_T == 64 ? 2 : 3;
+constexpr uint32_t LB_CAP = LB_T == 64 ? 128 : 736;   // nodes per LDS list (<= LB_T * LB_NPT)
+constexpr uint32_t LB_IN = LB_CAP / 2;         // nodes a workgroup starts with
+constexpr uint32_t LB_MIN = LB_T == 64 ? 8 : 48;      // fewer nodes than this: handed back (re-chunked with others, or the walkers)
+constexpr uint32_t LB_SBLK = LB_T == 64 ? 256 : 1024; // tagged-symbol slots a workgroup reserves at a time
+constexpr uint32_t LB_XCAP = LB_T == 64 ? 32 : 96;    // nodes on their way to the walkers, buffered in LDS
+
+struct LNode { uint32_t s, x0, x1, meta; };    // meta: [2:0] plane, [8:3] pass-through levels in a row (saturating), [31:9] round - round0
+constexpr uint32_t LB_RSH = 9;
+
+__device__ __forceinline__ DNode lnode_out(const DfsArgs &a, const LNode &l) {
+  return DNode{l.s, l.x0, l.x1, l.meta & 7u, a.round0 + (uint64_t)(l.meta >> LB_RSH)};
+}
+
+__global__ __launch_bounds__(LB_T) void k3_local_kernel(DfsArgs a) {
+  __shared__ LNode buf[2][LB_CAP];
+  __shared__ LNode xbuf[LB_XCAP];
+  __shared__ uint64_t ws[LB_T / 64];
+  __shared__ uint32_t s_bc[4];                 // results of thread 0's atomics: symbol block, queue slot, spill slot, stop
+  __shared__ uint32_t s_cntp[8], s_maxrel;
+  const K3Args &k = a.k;
+  const EnumCtl *ctl = k.ctl;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t first = blockIdx.x * LB_IN;
+  uint32_t total = a.in_count - first < LB_IN ? a.in_count - first : LB_IN;
+  if (tid < 8) s_cntp[tid] = 0;
+  if (tid == 8) s_maxrel = 0;
+  if (a.in) {
+    for (uint32_t q = tid; q < total; q += LB_T) {
+      const DNode d = a.in[first + q];
+      buf[0][q] = LNode{d.s, d.x0, d.x1, d.plane | ((uint32_t)(d.round - a.round0) << LB_RSH)};
+    }
+  } else {                                     // first pass: the planes' node lists, all at round0
+    uint32_t pbase[9];
+    uint32_t acc = 0;
+#pragma unroll
+    for (uint32_t p = 0; p < 8; ++p) { pbase[p] = acc; acc += ctl->cnt[k.par][p][0] + ctl->cnt[k.par][p][1]; }
+    pbase[8] = acc;
+    for (uint32_t q = tid; q < total; q += LB_T) {
+      const uint32_t g = first + q;
+      uint32_t p = 0;
+#pragma unroll
+      for (uint32_t j = 1; j < 8; ++j) p += g >= pbase[j] ? 1u : 0u;
+      const uint32_t idx = g - pbase[p], c0 = ctl->cnt[k.par][p][0];
+      const Node nd = plane_nodes(k, k.par, p)[idx < c0 ? idx : (k.capP - 1u - (idx - c0))];
+      buf[0][q] = LNode{nd.s, nd.x0, nd.x1, p};
+    }
+  }
+  // replicated in every thread (all update them identically): my symbol block, nodes waiting in xbuf
+  uint32_t sbase = 0, ssize = 0, sused = 0, xn = 0;
+  uint32_t cur = 0, rounds = 0, maxrel = 0;
+  uint64_t nodes = 0;
+  bool abort = false;
+  __syncthreads();
+  for (;;) {
+    if (total < LB_MIN || rounds >= a.lb_budget) break;
+    if ((rounds & 15u) == 15u) {               // somebody ran out of room: the whole tail is abandoned
+      if (tid == 0) s_bc[3] = a.dctl->err;
+      __syncthreads();
+      if (s_bc[3]) { abort = true; break; }
+    }
+    // ---- classify my nodes: all loads of a phase in flight together (as k3_classify) ----
+    // (items beyond the list are skipped as a whole: a workgroup spends most of its rounds on a fraction of its capacity)
+    const uint32_t nit = (total + LB_T - 1u) / LB_T;
+    LNode nd[LB_NPT];
+    bool valid[LB_NPT];
+    uint32_t ga[LB_NPT], gb[LB_NPT], gm[LB_NPT];
+    Granule qa[LB_NPT], qb[LB_NPT], qm[LB_NPT];
+#pragma unroll
+    for (int it = 0; it < LB_NPT; ++it) {
+      const uint32_t q = (uint32_t)it * LB_T + tid;
+      valid[it] = q < total;
+      if ((uint32_t)it >= nit) continue;
+      nd[it] = buf[cur][valid[it] ? q : 0u];
+      const Granule *G = k.gran + (size_t)(nd[it].meta & 7u) * k.ngran;
+      ga[it] = div96(nd[it].s);
+      gb[it] = div96(nd[it].s + nd[it].x0 + nd[it].x1);
+      gm[it] = div96(nd[it].s + nd[it].x0);
+      qa[it] = G[ga[it]];
+      qb[it] = G[gb[it]];
+#ifdef LB_MID_ALWAYS
+      qm[it] = G[gm[it]];
+#endif
+    }
+    NodeFlat nf[LB_NPT];
+#pragma unroll
+    for (int it = 0; it < LB_NPT; ++it) {
+      if ((uint32_t)it >= nit) continue;
+      const Node n3{nd[it].s, nd[it].x0, nd[it].x1};
+      node_flat_pre(n3, granule_rank1(qa[it], nd[it].s - ga[it] * 96u),
+                    granule_rank1(qb[it], nd[it].s + nd[it].x0 + nd[it].x1 - gb[it] * 96u), nf[it]);
+#ifndef LB_MID_ALWAYS
+      qm[it] = gm[it] == ga[it] ? qa[it] : qb[it];
+      if (valid[it] && nf[it].need_mid && gm[it] != ga[it] && gm[it] != gb[it])
+        qm[it] = (k.gran + (size_t)(nd[it].meta & 7u) * k.ngran)[gm[it]];
+#endif
+    }
+    uint32_t has0[LB_NPT], has1[LB_NPT], ex0[LB_NPT], ex1[LB_NPT], sym[LB_NPT], kq[LB_NPT], cmeta[LB_NPT];
+    Node c0[LB_NPT], c1[LB_NPT];
+    uint64_t mine = 0;                         // [15:0] children that stay, [31:16] symbols, [47:32] children for the walkers
+#pragma unroll
+    for (int it = 0; it < LB_NPT; ++it) {
+      if ((uint32_t)it >= nit) { has0[it] = has1[it] = ex0[it] = ex1[it] = 0u; nf[it].need_mid = 0u; continue; }
+      const Node n3{nd[it].s, nd[it].x0, nd[it].x1};
+      const uint32_t p = nd[it].meta & 7u, pn = (p + 1u) & 7u, quiet = (nd[it].meta >> 3) & 63u, rel = nd[it].meta >> LB_RSH;
+      node_flat_post(n3, k.zeros[p], nf[it], granule_rank1(qm[it], nd[it].s + nd[it].x0 - gm[it] * 96u), has0[it], c0[it],
+                     has1[it], c1[it], sym[it], kq[it]);
+      has0[it] = valid[it] ? has0[it] : 0u;
+      has1[it] = valid[it] ? has1[it] : 0u;
+      nf[it].need_mid = valid[it] ? nf[it].need_mid : 0u;
+      const uint32_t cq = (nf[it].need_mid || (has0[it] && has1[it])) ? 0u : (quiet < 63u ? quiet + 1u : 63u);
+      cmeta[it] = pn | (cq << 3) | ((rel + 1u) << LB_RSH);
+      // a chain worth a walker's skip: at plane 0 after lb_quiet levels (whole bytes) without a symbol or a split
+      const bool chain = a.skip_ok && pn == 0u && cq >= a.lb_quiet;
+      ex0[it] = (has0[it] && chain && c0[it].x0 + c0[it].x1 <= KD_MAXX) ? 1u : 0u;
+      ex1[it] = (has1[it] && chain && c1[it].x0 + c1[it].x1 <= KD_MAXX) ? 1u : 0u;
+      if (valid[it]) maxrel = rel > maxrel ? rel : maxrel;
+      mine += (uint64_t)(has0[it] - ex0[it] + has1[it] - ex1[it]) | ((uint64_t)nf[it].need_mid << 16) |
+              ((uint64_t)(ex0[it] + ex1[it]) << 32);
+    }
+    // ---- one packed block scan ----
+    uint64_t tot;
+    uint64_t ex;
+    {
+      const uint32_t lane = tid & 63u, wid = tid >> 6;
+      const uint64_t inc = wave_incl_sum64(mine);
+      if (lane == 63) ws[wid] = inc;
+      __syncthreads();
+      uint64_t wbase = 0;
+      tot = 0;
+#pragma unroll
+      for (int i = 0; i < LB_T / 64; ++i) { const uint64_t t = ws[i]; if ((uint32_t)i < wid) wbase += t; tot += t; }
+      ex = wbase + inc - mine;
+    }
+    const uint32_t tch = (uint32_t)(tot & 0xFFFFu), tsy = (uint32_t)((tot >> 16) & 0xFFFFu), tex = (uint32_t)(tot >> 32);
+    // ---- room: a new symbol block, the walkers' queue when xbuf is full, the spill queue when the list overflows ----
+    const bool need_s = sused + tsy > ssize, need_x = xn + tex > LB_XCAP, need_p = tch > LB_CAP;
+    uint32_t xdirect = 0;                      // this round's exits go straight to the queue, behind xbuf's content
+    if (need_s || need_x || need_p) {
+      if (need_s)                              // what is left of the old block becomes holes (sorted behind everything, cut off)
+        for (uint32_t j = sbase + sused + tid; j < sbase + ssize; j += LB_T) { a.ts[j] = 0; a.trlo[j] = 0; a.trhi[j] = KD_HOLE; }
+      if (tid == 0) {
+        uint32_t stop = 0;
+        if (need_s) {
+          const uint32_t sz = tsy > LB_SBLK ? tsy : LB_SBLK;
+          const uint32_t b = atomicAdd(&a.dctl->nsym, sz);
+          if ((uint64_t)b + sz > a.symcap) { a.dctl->err = 2; stop = 1; }
+          s_bc[0] = b;
+        }
+        if (need_x) {
+          const uint32_t o = atomicAdd(&a.dctl->queued, xn + tex);
+          if ((uint64_t)o + xn + tex > a.out_cap) { a.dctl->err = 4; stop = 1; }
+          s_bc[1] = o;
+        }
+        if (need_p) {
+          const uint32_t o = atomicAdd(&a.dctl->spilled, tch - LB_CAP);
+          if ((uint64_t)o + (tch - LB_CAP) > a.spill_cap) { a.dctl->err = 4; stop = 1; }
+          s_bc[2] = o;
+        }
+        s_bc[3] = stop;
+      }
+      __syncthreads();
+      if (s_bc[3]) { abort = true; break; }
+      if (need_s) { sbase = s_bc[0]; ssize = tsy > LB_SBLK ? tsy : LB_SBLK; sused = 0; }
+      if (need_x) {
+        for (uint32_t j = tid; j < xn; j += LB_T) a.out[s_bc[1] + j] = lnode_out(a, xbuf[j]);
+        xdirect = s_bc[1] + xn + 1u;           // (+1: 0 means "into xbuf")
+      }
+    }
+    const uint32_t spill0 = need_p ? s_bc[2] : 0u;
+    // ---- place: children into the other list (any order), symbols into my block, exits ----
+    {
+      uint32_t rc = (uint32_t)(ex & 0xFFFFu), rs = (uint32_t)((ex >> 16) & 0xFFFFu), rx = (uint32_t)(ex >> 32);
+#pragma unroll
+      for (int it = 0; it < LB_NPT; ++it) {
+        if ((uint32_t)it >= nit) continue;
+        const uint32_t p = nd[it].meta & 7u;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          const uint32_t has = side ? has1[it] : has0[it], exq = side ? ex1[it] : ex0[it];
+          if (!has) continue;
+          const Node &c = side ? c1[it] : c0[it];
+          const LNode l{c.s, c.x0, c.x1, cmeta[it]};
+          if (exq) {
+            if (xdirect) a.out[xdirect - 1u + rx] = lnode_out(a, l); else xbuf[xn + rx] = l;
+            ++rx;
+          } else {
+            if (rc < LB_CAP) buf[cur ^ 1u][rc] = l; else a.spill[spill0 + rc - LB_CAP] = lnode_out(a, l);
+            ++rc;
+          }
+        }
+        if (nf[it].need_mid) {
+          const uint32_t i = sbase + sused + rs;
+          ++rs;
+          uint32_t kw, ew;
+          pack_symbol(k.cfg[p], p, sym[it], kq[it], nf[it].n0x, nd[it].x1, nd[it].x0 + nd[it].x1, kw, ew);
+          const uint64_t r = a.round0 + (uint64_t)(nd[it].meta >> LB_RSH);
+#ifndef LB_NO_SYMSTORE
+          a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = nd[it].s;
+          a.trlo[i] = (uint32_t)r;
+          a.trhi[i] = (uint32_t)(r >> 32) | (p << 8);
+#else
+          if (kw == 0xFFFFFFFFu && ew == 0xFFFFFFFFu && r == 12345) a.tkey[i] = kw;
+#endif
+          atomicAdd(&s_cntp[p], 1u);
+        }
+      }
+    }
+    sused += tsy;
+    xn = xdirect ? 0u : xn + tex;
+    nodes += total;
+    total = tch < LB_CAP ? tch : LB_CAP;
+    cur ^= 1u;
+    ++rounds;
+    __syncthreads();
+  }
+  if (abort) return;
+  // ---- the chains in xbuf go to the walkers, the nodes that are left to the queue of the next local pass (the host
+  //      decides whether there is one); the rest of my symbol block becomes holes ----
+  __syncthreads();
+  if (total + xn) {
+    if (tid == 0) {
+      uint32_t stop = 0, o = 0, o2 = 0;
+      if (xn) { o = atomicAdd(&a.dctl->queued, xn); if ((uint64_t)o + xn > a.out_cap) stop = 1; }
+      if (total) { o2 = atomicAdd(&a.dctl->spilled, total); if ((uint64_t)o2 + total > a.spill_cap) stop = 1; }
+      if (stop) a.dctl->err = 4;
+      s_bc[1] = o; s_bc[2] = o2; s_bc[3] = stop;
+    }
+    __syncthreads();
+    if (!s_bc[3]) {
+      for (uint32_t j = tid; j < xn; j += LB_T) a.out[s_bc[1] + j] = lnode_out(a, xbuf[j]);
+      for (uint32_t j = tid; j < total; j += LB_T) a.spill[s_bc[2] + j] = lnode_out(a, buf[cur][j]);
+    }
+  }
+  for (uint32_t j = sbase + sused + tid; j < sbase + ssize; j += LB_T) { a.ts[j] = 0; a.trlo[j] = 0; a.trhi[j] = KD_HOLE; }
+  atomicMax(&s_maxrel, maxrel);
+  __syncthreads();
+  if (tid < 8 && s_cntp[tid]) atomicAdd(&a.dctl->cntp[tid], s_cntp[tid]);
+  if (tid == 0 && nodes) {
+    atomicAdd((unsigned long long *)&a.dctl->nodes, (unsigned long long)nodes);
+    atomicMax((unsigned long long *)&a.dctl->maxround, (unsigned long long)(a.round0 + s_maxrel));
+  }
+}
+
 // keys[i] = src[perm[i]]
 __global__ void kd_gather_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ perm, uint32_t m,
                                  uint32_t *__restrict__ keys) {
@@ -818,12 +1089,17 @@ __global__ void kd_place_kernel(const uint32_t *__restrict__ tkey, const uint32_
   }
 }
 
-// Host side.  The walkers start when the node count has stopped growing, at most `enter` nodes are alive and an
-// eighth of all nodes has been visited (i.e. not in the ramp-up).  Passes follow each other until no node is
-// queued.  Preconditions (checked by the caller): the symbol buffer is empty (everything emitted so far has been
-// flushed), `ctl` is current.  On success the symbol buffer holds the tail's symbols in stream order, run_log
-// holds one run per plane, and *done = true.  On an error (more symbols than the tagged buffer holds, queue full)
-// nothing has been changed and the caller continues with the round-based kernels.
+// Host side.  The tail starts when the node count has stopped growing, at most `enter` nodes are alive and an
+// eighth of all nodes has been visited (i.e. not in the ramp-up).  With more than KD_LOCAL_FROM nodes alive the
+// workgroup-local rounds come first (k3_local_kernel: one launch over the planes' lists, further ones while it
+// spills); what they hand on, or the planes' lists themselves, goes to the walkers, whose passes follow each other
+// until no node is queued.  Preconditions (checked by the caller): the symbol buffer is empty (everything emitted so
+// far has been flushed), `ctl` is current.  On success the symbol buffer holds the tail's symbols in stream order,
+// run_log holds one run per plane, and *done = true.  On an error (more symbols than the tagged buffer holds, queue
+// full) nothing has been changed and the caller continues with the round-based kernels.
+constexpr uint32_t KD_LOCAL_FROM = 65536;       // live nodes above which the tail starts with workgroup-local rounds
+constexpr uint32_t KD_LOCAL_QUEUE = 16u << 20;  // walker queue / spill queue capacity in that case
+constexpr uint32_t KD_LOCAL_BUDGET = 256;       // rounds per workgroup and pass (BCE_HIP_LOCAL_BUDGET overrides; 1024 measured: 45 instead of 34 ms on the natural corpus)
 int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) {
   *done = false;
   if (c->scan_mode || c->dbg_no_dfs) return BCE_HIP_OK;
@@ -832,23 +1108,30 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) 
   const uint64_t all = 8ull * (n - 1);
   // (not in the ramp-up: an eighth of all nodes visited -- or a thousand rounds gone by with this few nodes alive,
   //  which is what an input that is one long run or one table looks like from the start)
-  if (live == 0 || live > enter || (ctl.nodes_total < all / 8 && c->round < 1024u)) return BCE_HIP_OK;
+  if (live == 0 || live > enter || (ctl.nodes_total < all / 8 && c->round < 1024u && !c->dbg_tail_round)) return BCE_HIP_OK;
   // tagged symbols: the tail is mostly pass-through, a fraction of the nodes that are left is plenty; if it is
   // not (chains in which every byte codes a symbol or two), the walk is repeated with four times the room
   const uint64_t left = all > ctl.nodes_total ? all - ctl.nodes_total : 0;
+  const uint32_t local_from = c->dbg_local_from ? c->dbg_local_from : KD_LOCAL_FROM;
+  const bool local = live > local_from && !c->dbg_no_local;
   uint64_t cap_scale = 1;
 retry:
-  uint64_t cap64 = (left / 8 + (1u << 20)) * cap_scale;
+  // (the bushy part the local rounds take codes more symbols per node than the chains of the deep tail)
+  uint64_t cap64 = (left / (local ? 3 : 8) + (1u << 20)) * cap_scale;
   if (cap64 < (4u << 20)) cap64 = 4u << 20;
   if (cap64 > (512u << 20)) cap64 = 512u << 20;
   if (cap64 > left + 64) cap64 = left + 64;                  // a node codes at most one symbol
+  if (local && cap64 < (uint64_t)LB_SBLK * ((live + LB_IN - 1) / LB_IN + 1)) cap64 = (uint64_t)LB_SBLK * ((live + LB_IN - 1) / LB_IN + 1);   // one block per workgroup at least
   const uint32_t cap = ((uint32_t)cap64 + 63u) & ~63u;       // keeps the carved arrays 8-byte aligned
-  const uint32_t qcap = (uint32_t)(left + 64 < KD_QUEUE ? left + 64 : KD_QUEUE);      // queued nodes are distinct unvisited nodes
+  const uint32_t qmax = local ? KD_LOCAL_QUEUE : KD_QUEUE;
+  const uint32_t qcap = (uint32_t)(left + 64 < qmax ? left + 64 : qmax);      // queued nodes are distinct unvisited nodes
   const uint32_t wmax = qcap < KD_WALKERS ? qcap : KD_WALKERS;
-  // carve: tkey tesc ts trlo trhi | sort keys x2 vals x2 | DfsCtl | queue x2 | stacks
+  const uint32_t scap = local ? qcap : 0u;                   // spill queues of the local rounds
+  // carve: tkey tesc ts trlo trhi | sort keys x2 vals x2 | DfsCtl | queue x2 | stacks | jobs | spill x2
   const size_t o_sort = (size_t)cap * 4 * 5, o_ctl = o_sort + (size_t)cap * 4 * 4, o_q = o_ctl + 512,
-               o_stack = o_q + 2 * (size_t)qcap * sizeof(DNode), o_jobs = o_stack + (size_t)wmax * KD_STACK * sizeof(DNode);
-  BCE_TRY(ensure(c, c->dfs, o_jobs + (size_t)KD_JOBS * sizeof(StairJob)));
+               o_stack = o_q + 2 * (size_t)qcap * sizeof(DNode), o_jobs = o_stack + (size_t)wmax * KD_STACK * sizeof(DNode),
+               o_spill = o_jobs + (size_t)KD_JOBS * sizeof(StairJob);
+  BCE_TRY(ensure(c, c->dfs, o_spill + 2 * (size_t)scap * sizeof(DNode)));
   uint8_t *base = c->dfs.as<uint8_t>();
   DfsArgs a;
   a.k = k3_make_args(c, c->round, 0);
@@ -862,12 +1145,27 @@ retry:
   uint32_t *sv[2] = {reinterpret_cast<uint32_t *>(base + o_sort) + 2 * (size_t)cap, reinterpret_cast<uint32_t *>(base + o_sort) + 3 * (size_t)cap};
   a.dctl = reinterpret_cast<DfsCtl *>(base + o_ctl);
   DNode *queue[2] = {reinterpret_cast<DNode *>(base + o_q), reinterpret_cast<DNode *>(base + o_q) + qcap};
+  DNode *spillq[2] = {reinterpret_cast<DNode *>(base + o_spill), reinterpret_cast<DNode *>(base + o_spill) + scap};
   a.stacks = reinterpret_cast<DNode *>(base + o_stack);
   a.jobs = reinterpret_cast<StairJob *>(base + o_jobs);
   a.round0 = c->round;
   a.symcap = cap;
   a.out_cap = qcap;
+  a.spill = spillq[0]; a.spill_cap = scap;
+  a.lb_budget = KD_LOCAL_BUDGET;
+  if (const char *e = getenv("BCE_HIP_LOCAL_BUDGET")) a.lb_budget = (uint32_t)strtoul(e, nullptr, 10);
+  if (c->dbg_local_budget) a.lb_budget = c->dbg_local_budget;
+  a.lpw = KD_T;
+  // chains leave the local rounds early only on request: per node a walker is ~100x slower than a workgroup round, a skip
+  // pays from a few hundred bytes (measured: 32 levels -> 1.1 M of 2 M nodes went to the walkers, K3 34 -> 228 ms)
+  a.lb_quiet = 0xFFFFFFFFu;
+  if (const char *e = getenv("BCE_HIP_LOCAL_QUIET")) a.lb_quiet = (uint32_t)strtoul(e, nullptr, 10);
+  if (a.lb_budget < 1u) a.lb_budget = 1u;
+  if (a.lb_budget > 65536u) a.lb_budget = 65536u;
   a.budget = c->dbg_dfs_budget ? c->dbg_dfs_budget : K3_DFS_PASS;
+  a.lane_budget = c->dbg_dfs_budget ? c->dbg_dfs_budget : K3_DFS_LANE_PASS;
+  if (const char *e = getenv("BCE_HIP_DFS_LANE_PASS")) a.lane_budget = (uint32_t)strtoul(e, nullptr, 10);
+  if (const char *e = getenv("BCE_HIP_DFS_PASS")) a.budget = (uint32_t)strtoul(e, nullptr, 10);
   a.dbg = getenv("BCE_HIP_DFS_DEBUG") ? 1u : 0u;
   BCE_HIP_TRY(c, hipMemsetAsync(a.dctl, 0, sizeof(DfsCtl), c->stream));
   DfsCtl h;
@@ -875,13 +1173,59 @@ retry:
   double t_pass = 0.0;
   if (a.dbg) { BCE_HIP_TRY(c, hipStreamSynchronize(c->stream)); t_pass = now_s(); }
   const DNode *in = nullptr;
-  for (;;) {
+  bool walkers_next = true;
+  if (local) {
+    // ---- workgroup-local rounds: the planes' lists first, then what the workgroups handed back (nodes alive after
+    //      lb_budget rounds, remainders of workgroups that ran low, overflow of the LDS lists), re-chunked, until few
+    //      enough are left for the walkers or a pass no longer thins them out (regular chains: the walkers' closed forms) ----
+    uint32_t lcount = live, lpass = 0;
+    const DNode *lin = nullptr;
+    for (;;) {
+      a.in = lin; a.in_count = lcount; a.out = queue[0]; a.spill = spillq[lpass & 1];
+      hipLaunchKernelGGL(k3_local_kernel, dim3((lcount + LB_IN - 1) / LB_IN), dim3(LB_T), 0, c->stream, a);
+      BCE_HIP_TRY(c, hipMemcpyAsync(&h, a.dctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+      BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      BCE_HIP_TRY(c, hipGetLastError());
+      c->stats.k3_launches += 1.0;
+      if (a.dbg) {
+        const double now = now_s();
+        fprintf(stderr, "local pass %u: %u nodes in %u workgroups, %.3f ms, %u chains for the walkers so far, %u nodes handed back, %u symbol slots, %llu nodes done\n", lpass,
+                lcount, (lcount + LB_IN - 1) / LB_IN, (now - t_pass) * 1e3, h.queued, h.spilled, h.nsym, (unsigned long long)h.nodes);
+        t_pass = now;
+      }
+      ++lpass;
+      if (h.err) break;
+      const bool last = h.spilled <= local_from || lpass >= 32u || (uint64_t)h.spilled * 4 > (uint64_t)lcount * 3;
+      if (last) {
+        if ((uint64_t)h.queued + h.spilled > qcap) { h.err = 4; break; }
+        if (h.spilled)
+          BCE_HIP_TRY(c, hipMemcpyAsync(queue[0] + h.queued, spillq[(lpass - 1) & 1], (size_t)h.spilled * sizeof(DNode), hipMemcpyDeviceToDevice, c->stream));
+        h.queued += h.spilled;
+        break;
+      }
+      lin = spillq[(lpass - 1) & 1];
+      lcount = h.spilled;
+      BCE_HIP_TRY(c, hipMemsetAsync(&a.dctl->spilled, 0, 4, c->stream));
+    }
+    if (!h.err) {
+      in = queue[0]; count = h.queued; passes = 1;
+      BCE_HIP_TRY(c, hipMemsetAsync(&a.dctl->queued, 0, 4, c->stream));
+      walkers_next = count > 0;
+    } else walkers_next = false;
+  }
+  while (walkers_next) {
     a.in = in; a.in_count = count; a.out = queue[passes & 1];
     const uint32_t walkers = count < wmax ? count : wmax;
     if (passes > 0 && count <= KD_UNI_MAX && !getenv("BCE_HIP_DFS_NO_UNI"))   // few walkers left: one WAVE each
       hipLaunchKernelGGL(k3_dfs_kernel<true>, dim3(count), dim3(KD_T), 0, c->stream, a);
-    else
-      hipLaunchKernelGGL(k3_dfs_kernel<false>, dim3((walkers + KD_T - 1) / KD_T), dim3(KD_T), 0, c->stream, a);
+    else {
+      // (fewer walkers per wave -- BCE_HIP_DFS_LPW -- was measured on 62 K walkers: 64 lanes 16.7 ms, 32: 18.3, 16: 20.9, 4: 35.8:
+      //  a pass lasts as long as its longest walk, not as the comparisons a wave serves one after the other)
+      uint32_t lpw = KD_T;
+      if (const char *e = getenv("BCE_HIP_DFS_LPW")) { lpw = (uint32_t)strtoul(e, nullptr, 10); if (lpw < 1u || lpw > (uint32_t)KD_T) lpw = KD_T; }
+      a.lpw = lpw;
+      hipLaunchKernelGGL(k3_dfs_kernel<false>, dim3((walkers + lpw - 1) / lpw), dim3(KD_T), 0, c->stream, a);
+    }
     // the long staircase stretches the walkers queued in this pass: their events, over the whole grid
     hipLaunchKernelGGL(kd_jobs_kernel, dim3(1024), dim3(256), 0, c->stream, a, jobs_done);
     BCE_HIP_TRY(c, hipMemcpyAsync(&h, a.dctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -921,17 +1265,20 @@ retry:
   for (int p = 0; p < 8; ++p) mv += h.cntp[p];
   if (mv > c->sym_cap) BCE_TRY(k3_grow_symbols(c, (uint64_t)mv + 1024));
   if (m) {
-    // stream order inside a coder = (round, s); planes are separated: LSD sort by s, round low, (plane, round high)
+    // stream order inside a coder = (round, s); planes are separated: LSD sort by s, round low, (plane, round high),
+    // each over the bits that can be set only (s < n; rounds <= maxround; a hole is (plane 7, round high 0xFF))
     const uint32_t g = (m + 255) / 256 < 2048 ? (m + 255) / 256 : 2048;
+    const bool wide_round = h.maxround >= 0xFFFFFFFFull;
+    const uint32_t sbits = ceil_log2(n), rbits = wide_round ? 32u : ceil_log2((uint32_t)h.maxround + 1u), hfirst = wide_round ? 0u : 7u;
     int r = 0;
     hipLaunchKernelGGL(kd_iota_kernel, dim3(g), dim3(256), 0, c->stream, a.ts, m, sk[0], sv[0]);
-    BCE_TRY(radix_sort_pairs(c, sk, sv, m, 0, 31, &r));
+    BCE_TRY(radix_sort_pairs(c, sk, sv, m, 0, sbits ? sbits : 1u, &r, 9));
     uint32_t *k2[2] = {sk[r ^ 1], sk[r]}, *v2[2] = {sv[r], sv[r ^ 1]};
     hipLaunchKernelGGL(kd_gather_kernel, dim3(g), dim3(256), 0, c->stream, a.trlo, v2[0], m, k2[0]);
-    BCE_TRY(radix_sort_pairs(c, k2, v2, m, 0, 32, &r));
+    BCE_TRY(radix_sort_pairs(c, k2, v2, m, 0, rbits ? rbits : 1u, &r, 9));
     uint32_t *k3[2] = {k2[r ^ 1], k2[r]}, *v3[2] = {v2[r], v2[r ^ 1]};
     hipLaunchKernelGGL(kd_gather_kernel, dim3(g), dim3(256), 0, c->stream, a.trhi, v3[0], m, k3[0]);
-    BCE_TRY(radix_sort_pairs(c, k3, v3, m, 0, 11, &r));
+    BCE_TRY(radix_sort_pairs(c, k3, v3, m, hfirst, 11u - hfirst, &r, 9));
     hipLaunchKernelGGL(kd_place_kernel, dim3(g), dim3(256), 0, c->stream, a.tkey, a.tesc, v3[r], mv,   // the holes sorted last
                        c->skey[0].as<uint32_t>(), c->sesc.as<uint32_t>());
   }

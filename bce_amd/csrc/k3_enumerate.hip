@@ -25,14 +25,16 @@
 
 namespace bce {
 
-// tile -> plane lookup table: tp[p] = first tile of plane p, tp[8] = total tiles
-__device__ __forceinline__ void tile_prefix(const K3Args &a, uint32_t tp[9]) {
+// tile -> plane lookup table: tp[p] = first tile of plane p, tp[8] = total tiles; cn[p] = the plane's two list lengths
+// (read once per block: a load from the control block on every tile's path is a dependent L2 round trip)
+__device__ __forceinline__ void tile_prefix(const K3Args &a, uint32_t tp[9], uint32_t (*cn)[2] = nullptr) {
   uint32_t acc = 0;
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     tp[p] = acc;
-    const uint32_t m = a.ctl->cnt[a.par][p][0] + a.ctl->cnt[a.par][p][1];
-    acc += (m + K3_TILE - 1) / K3_TILE;
+    const uint32_t m0 = a.ctl->cnt[a.par][p][0], m1 = a.ctl->cnt[a.par][p][1];
+    if (cn) { cn[p][0] = m0; cn[p][1] = m1; }
+    acc += (m0 + m1 + K3_TILE - 1) / K3_TILE;
   }
   tp[8] = acc;
 }
@@ -50,6 +52,12 @@ __device__ __forceinline__ void group_prefix(const uint32_t tp[9], uint32_t gp[9
 // the nodes that code a symbol and whose split point falls in neither of the two granules already loaded.
 // (Measured: the kernel is VALU-issue bound, ~250 instructions per node; staging the tile's granule range
 // through LDS was tried and is slower.)
+// granule g of a plane: 32-bit byte offset from the plane's (uniform) base -- a plane's directory is < 2^32 bytes
+// (n < 2^31 positions / 96 * 16 B), so the address is base (scalar) + offset (one shift) instead of a 64-bit multiply-add
+__device__ __forceinline__ Granule gran_at(const Granule *G, uint32_t g) {
+  return *reinterpret_cast<const Granule *>(reinterpret_cast<const char *>(G) + (g << 4));
+}
+
 struct TileOut {
   uint32_t has0[K3_NPT], has1[K3_NPT], hassym[K3_NPT];
   Node c0[K3_NPT], c1[K3_NPT];
@@ -57,25 +65,46 @@ struct TileOut {
   uint32_t raw[K3_NPT][3];   // scan mode: kw = sym, ew = k, raw = c1, c2, cs
 };
 
-template <bool PACK, bool SCAN>
-__device__ __forceinline__ void k3_classify(const K3Args &a, uint32_t p, uint32_t tile_in_plane, TileOut &t) {
-  const uint32_t tid = threadIdx.x;
-  const uint32_t c0n = a.ctl->cnt[a.par][p][0], c1n = a.ctl->cnt[a.par][p][1];
+// node q of a plane's list (child0 part grows up from 0, child1 part down from capP-1): 32-bit byte offset from the
+// plane's (uniform) base -- capP * 12 < 2^32
+__device__ __forceinline__ Node node_at(const Node *src, uint32_t idx) {
+  return *reinterpret_cast<const Node *>(reinterpret_cast<const char *>(src) + ((idx << 3) + (idx << 2)));
+}
+
+__device__ __forceinline__ void k3_load_nodes(const K3Args &a, uint32_t p, uint32_t tile_in_plane, uint32_t c0n, uint32_t c1n,
+                                              Node (&nd)[K3_NPT]) {
   const uint32_t M = c0n + c1n;
   const Node *src = plane_nodes(a, a.par, p);
+#pragma unroll
+  for (int it = 0; it < K3_NPT; ++it) {
+    const uint32_t q = tile_in_plane * K3_TILE + (uint32_t)it * K3_T + threadIdx.x;
+    // out-of-range lanes re-read the tile's first node (always valid when the tile exists); their results are masked
+    const uint32_t qq = q < M ? q : tile_in_plane * K3_TILE;
+    nd[it] = node_at(src, qq < c0n ? qq : (a.capP - 1u - (qq - c0n)));
+  }
+}
+
+template <bool PACK, bool SCAN>
+__device__ __forceinline__ void k3_classify(const K3Args &a, uint32_t p, uint32_t tile_in_plane, uint32_t c0n, uint32_t c1n,
+                                            TileOut &t) {
+  const uint32_t tid = threadIdx.x;
+  const uint32_t M = c0n + c1n;
+  // (prefetching the NEXT tile's triples behind this tile's granule loads was measured: no gain -- vmcnt retires in order,
+  //  so the conditional third gather and, in the write kernel, the stores wait for the prefetch anyway, and the 12 extra
+  //  registers cost a wave per SIMD)
+  Node nd[K3_NPT];
+  k3_load_nodes(a, p, tile_in_plane, c0n, c1n, nd);
+#ifndef K3_NO_SCHEDBAR
+  __builtin_amdgcn_sched_barrier(0);            // every node load issued before the first is consumed
+#endif
   const Granule *G = a.gran + (size_t)p * a.ngran;
   const uint32_t zp = a.zeros[p];
   const PlaneCfg &cfg = a.cfg[p];
-  Node nd[K3_NPT];
   uint32_t valid[K3_NPT];
 #pragma unroll
-  for (int it = 0; it < K3_NPT; ++it) {
-    const uint32_t q = tile_in_plane * K3_TILE + (uint32_t)it * K3_T + tid;
-    valid[it] = q < M ? 1u : 0u;
-    // out-of-range lanes re-read the tile's first node (always valid when the tile exists); their results are masked
-    const uint32_t qq = valid[it] ? q : tile_in_plane * K3_TILE;
-    nd[it] = src[qq < c0n ? qq : (a.capP - 1u - (qq - c0n))];
-  }
+  for (int it = 0; it < K3_NPT; ++it) valid[it] = tile_in_plane * K3_TILE + (uint32_t)it * K3_T + tid < M ? 1u : 0u;
+  // the rank granules of every node in one phase (the split point's granule is almost always one of the other two; the
+  // rest is a third, dependent load below.  Loading it unconditionally was measured: 13.9 instead of 13.4 ms)
   uint32_t ga[K3_NPT], gb[K3_NPT], gm[K3_NPT];
   Granule qa[K3_NPT], qb[K3_NPT], qm[K3_NPT];
 #pragma unroll
@@ -83,17 +112,25 @@ __device__ __forceinline__ void k3_classify(const K3Args &a, uint32_t p, uint32_
     ga[it] = div96(nd[it].s);
     gb[it] = div96(nd[it].s + nd[it].x0 + nd[it].x1);
     gm[it] = div96(nd[it].s + nd[it].x0);
-    qa[it] = G[ga[it]];
-    qb[it] = G[gb[it]];
+    qa[it] = gran_at(G, ga[it]);
+    qb[it] = gran_at(G, gb[it]);
+#ifdef K3_MID_ALWAYS
+    qm[it] = gran_at(G, gm[it]);
+#endif
   }
+#ifndef K3_NO_SCHEDBAR
+  __builtin_amdgcn_sched_barrier(0);            // every load above is issued before the first rank below
+#endif
   NodeFlat nf[K3_NPT];
 #pragma unroll
   for (int it = 0; it < K3_NPT; ++it) {
     const uint32_t rs = granule_rank1(qa[it], nd[it].s - ga[it] * 96u);
     const uint32_t re = granule_rank1(qb[it], nd[it].s + nd[it].x0 + nd[it].x1 - gb[it] * 96u);
     node_flat_pre(nd[it], rs, re, nf[it]);
+#ifndef K3_MID_ALWAYS
     qm[it] = gm[it] == ga[it] ? qa[it] : qb[it];
-    if (nf[it].need_mid && gm[it] != ga[it] && gm[it] != gb[it]) qm[it] = G[gm[it]];
+    if (nf[it].need_mid && gm[it] != ga[it] && gm[it] != gb[it]) qm[it] = gran_at(G, gm[it]);
+#endif
   }
 #pragma unroll
   for (int it = 0; it < K3_NPT; ++it) {
@@ -149,10 +186,10 @@ __device__ __forceinline__ void k3_place(const K3Args &a, uint32_t p, const Tile
 // Process one tile.  WRITE=false: count children/symbols.  WRITE=true: place them.
 template <bool WRITE, bool SCAN>
 __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t tile_in_plane, uint32_t tile_global,
-                                        uint32_t (*lds_cnt)[4][3], uint32_t group_base = 0) {
+                                        uint32_t (*lds_cnt)[4][3], uint32_t c0n, uint32_t c1n, uint32_t group_base) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
   TileOut t;
-  k3_classify<WRITE, SCAN>(a, p, tile_in_plane, t);
+  k3_classify<WRITE, SCAN>(a, p, tile_in_plane, c0n, c1n, t);
   uint32_t pre0[K3_NPT], pre1[K3_NPT], pres[K3_NPT];
   const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
@@ -188,19 +225,24 @@ __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t ti
   __syncthreads();
 }
 
+__device__ __forceinline__ uint32_t tile_plane(const uint32_t *tp, uint32_t tile) {
+  uint32_t p = 0;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) p += (tile >= tp[k]) ? 1u : 0u;
+  return p;
+}
+
 template <bool WRITE, bool SCAN>
 __global__ __launch_bounds__(K3_T) void k3_tiles_kernel(K3Args a) {
-  __shared__ uint32_t tp[9], gp[9];
+  __shared__ uint32_t tp[9], gp[9], cn[8][2];
   __shared__ uint32_t lds_cnt[K3_NPT][4][3];
   if (a.ctl->need_flush || a.ctl->overflow) return;
-  if (threadIdx.x == 0) { tile_prefix(a, tp); group_prefix(tp, gp); }
+  if (threadIdx.x == 0) { tile_prefix(a, tp, cn); group_prefix(tp, gp); }
   __syncthreads();
   const uint32_t T = tp[8];
   for (uint32_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
-    uint32_t p = 0;
-#pragma unroll
-    for (int k = 1; k < 8; ++k) p += (tile >= tp[k]) ? 1u : 0u;
-    k3_tile<WRITE, SCAN>(a, p, tile - tp[p], tile, lds_cnt, gp[p]);
+    const uint32_t p = tile_plane(tp, tile);
+    k3_tile<WRITE, SCAN>(a, p, tile - tp[p], tile, lds_cnt, cn[p][0], cn[p][1], gp[p]);
   }
 }
 
@@ -301,13 +343,13 @@ __device__ __forceinline__ void st_word(unsigned long long *p, uint64_t v) {
 
 template <bool SCAN>
 __global__ __launch_bounds__(K3_T) void k3_count2_kernel(K3Args a) {
-  __shared__ uint32_t tp[9], gp[9];
+  __shared__ uint32_t tp[9], gp[9], cn[8][2];
   __shared__ uint32_t lds_cnt[K3_NPT][4][3];
   __shared__ uint32_t s_pt[8][3];
   EnumCtl *ctl = a.ctl;
   if (ctl->need_flush || ctl->overflow) return;
   const uint32_t tid = threadIdx.x;
-  if (tid == 0) { tile_prefix(a, tp); group_prefix(tp, gp); }
+  if (tid == 0) { tile_prefix(a, tp, cn); group_prefix(tp, gp); }
   __syncthreads();
   const uint32_t T = tp[8];
   if (T == 0) {
@@ -320,14 +362,12 @@ __global__ __launch_bounds__(K3_T) void k3_count2_kernel(K3Args a) {
   }
   const uint64_t epoch = (uint64_t)((a.round + 1u) & 0x3FFFFFFu);   // 26 bits: the group words keep 38 for their payload
   for (uint32_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
-    uint32_t p = 0;
-#pragma unroll
-    for (int k = 1; k < 8; ++k) p += (tile >= tp[k]) ? 1u : 0u;
+    const uint32_t p = tile_plane(tp, tile);
     const uint32_t ti = tile - tp[p], Tp = tp[p + 1] - tp[p];
     const uint32_t lane = tid & 63u, w = tid >> 6;
     {
       TileOut t;
-      k3_classify<false, SCAN>(a, p, ti, t);
+      k3_classify<false, SCAN>(a, p, ti, cn[p][0], cn[p][1], t);
 #pragma unroll
       for (int it = 0; it < K3_NPT; ++it) {
         const uint64_t b0 = __ballot(t.has0[it]), b1 = __ballot(t.has1[it]), bs = __ballot(t.hassym[it]);
@@ -445,7 +485,7 @@ __global__ __launch_bounds__(K3_T) void k3_count2_kernel(K3Args a) {
 // ------------------------------------------------------------------------------------------------------
 template <bool SCAN>
 __global__ __launch_bounds__(K3_T) void k3_small_kernel(K3Args a, unsigned long long *words) {
-  __shared__ uint32_t tp[9];
+  __shared__ uint32_t tp[9], cn[8][2];
   __shared__ uint32_t lds_cnt[K3_NPT][4][3];
   __shared__ uint32_t s_tile;
   __shared__ unsigned long long s_acc[3];
@@ -453,7 +493,7 @@ __global__ __launch_bounds__(K3_T) void k3_small_kernel(K3Args a, unsigned long 
   EnumCtl *ctl = a.ctl;
   if (ctl->need_flush || ctl->overflow || ctl->small_bail) return;
   const uint32_t tid = threadIdx.x;
-  if (tid == 0) tile_prefix(a, tp);
+  if (tid == 0) tile_prefix(a, tp, cn);
   if (tid < 3) s_acc[tid] = 0;
   if (tid < 8) s_tot[tid] = 0;
   __syncthreads();
@@ -487,7 +527,7 @@ __global__ __launch_bounds__(K3_T) void k3_small_kernel(K3Args a, unsigned long 
     for (int k = 1; k < 8; ++k) p += (tile >= tp[k]) ? 1u : 0u;
     const uint32_t lane = tid & 63u, w = tid >> 6;
     TileOut t;
-    k3_classify<true, SCAN>(a, p, tile - tp[p], t);
+    k3_classify<true, SCAN>(a, p, tile - tp[p], cn[p][0], cn[p][1], t);
     uint32_t pre0[K3_NPT], pre1[K3_NPT], pres[K3_NPT];
     const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
@@ -790,16 +830,29 @@ K3Args k3_make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot) {
   return a;
 }
 
-static uint32_t default_capP(uint32_t n) {
-  // worst case is n/2 nodes per plane-round (disjoint intervals of width >= 2)
+static uint32_t default_capP(bce_hip_ctx *c, uint32_t n) {
+  // worst case is n/2 nodes per plane-round (disjoint intervals of width >= 2): text peaks at 0.06-0.09 n, random
+  // bytes at ~0.3 n.  All 16 lists (2 parities x 8 planes) get the worst case when it fits in 60 % of the HBM that is
+  // free now (K1's and K2's buffers are already allocated), at least 192 M nodes per list (36.9 GB) otherwise.  A round
+  // that overflows the lists ends the compression with BCE_HIP_E_OVERFLOW (loud, never a wrong archive): see the
+  // capacity note in include/bce_hip.h.
   const uint64_t worst = (uint64_t)n / 2 + 2;
-  const uint64_t soft = (uint64_t)192 << 20;   // 192M nodes per plane buffer = 36.9 GB for all 16 buffers
+  uint64_t soft = (uint64_t)192 << 20;
+  if (worst > soft) {
+    size_t free_b = 0, total_b = 0;
+    const size_t have = c->nodes.cap;                             // (a buffer of an earlier compression is reused)
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const uint64_t budget = (uint64_t)((free_b + have) * 0.6);
+      const uint64_t fit = budget / (16 * sizeof(Node));
+      if (fit > soft) soft = fit;
+    }
+  }
   return (uint32_t)(worst < soft ? worst : soft);
 }
 
 int k3_begin(bce_hip_ctx *c) {
   const uint32_t n = c->n;
-  c->capP = default_capP(n);
+  c->capP = default_capP(c, n);
   BCE_TRY(ensure(c, c->nodes, (size_t)16 * c->capP * sizeof(Node)));
   const size_t tiles = (size_t)8 * ((c->capP + K3_TILE - 1) / K3_TILE) + 8;
   BCE_TRY(ensure(c, c->tilecnt, tiles * 16));

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(K3_T) void dec_tiles_kernel(DecArgs a) {
           const uint32_t x = nd[it].x0 + nd[it].x1, k = cl[it].mx - cl[it].mn + 1u, c1 = x - cl[it].n1x, c2 = nd[it].x1;
           if (k <= (uint32_t)kMaxK) {
             const uint32_t b = a.cfg[p].bits[k];
-            const uint32_t ctxv = (small_quotient((uint32_t)(c1 << b), x) << b) | small_quotient((uint32_t)(c2 << b), x);
+            const uint32_t ctxv = context_index(b, c1, c2, x);
             a.Q[qb + qr[it]] = k | (ctxv << 5);
           } else {
             a.Q[qb + qr[it]] = kEscape;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(DT_T) void dec_tail_kernel(DecArgs a, uint32_t max_
               const uint32_t x = nd[it].x0 + nd[it].x1, k = cl[it].mx - cl[it].mn + 1u, c1v = x - cl[it].n1x, c2v = nd[it].x1;
               if (k <= (uint32_t)kMaxK) {
                 const uint32_t b = a.cfg[pl[it]].bits[k];
-                const uint32_t ctxv = (small_quotient((uint32_t)(c1v << b), x) << b) | small_quotient((uint32_t)(c2v << b), x);
+                const uint32_t ctxv = context_index(b, c1v, c2v, x);
                 a.Q[(uint32_t)run] = k | (ctxv << 5);
                 run += 1ull;
               } else {
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(64) void dec_tail64_kernel(DecArgs a, uint32_t max_
         const uint32_t x = nd.x0 + nd.x1, c1v = x - cl.n1x, c2v = nd.x1;
         if (!ise) {
           const uint32_t b = a.cfg[pl].bits[kq];
-          a.Q[qidx] = kq | (((small_quotient((uint32_t)(c1v << b), x) << b) | small_quotient((uint32_t)(c2v << b), x)) << 5);
+          a.Q[qidx] = kq | ((context_index(b, c1v, c2v, x)) << 5);
         } else {
           a.Q[qidx] = kEscape;
           a.E[eidx] = make_uint4(kq, c1v, c2v, x);

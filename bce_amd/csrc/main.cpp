@@ -44,7 +44,12 @@ static int compress_blocks(const std::vector<uint8_t> &data, uint32_t nblocks, c
   for (int dev = 0; dev < 64 && ctx.size() < nblocks; ++dev) {
     bce_hip_ctx *c = nullptr;
     if (bce_hip_create(&c, dev) != 0) break;
-    if (config) bce_hip_set_config(c, config);
+    if (config && bce_hip_set_config(c, config) != 0) {        // (validated by the caller already: cannot happen)
+      printf("Config rejected on device %d: %s\n", dev, bce_hip_last_error(c));
+      bce_hip_destroy(c);
+      for (bce_hip_ctx *o : ctx) bce_hip_destroy(o);
+      return -1;
+    }
     ctx.push_back(c);
   }
   if (ctx.empty()) return -3;
@@ -109,16 +114,19 @@ int main(int argc, char **argv) {
       if (cli_timing) fprintf(stderr, "cli: %-10s %.3f s\n", what, std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - start).count());
     };
     lap("create");
-    if (argc == 5) {   // load_config, bce.cpp:626-641
+    // load_config, bce.cpp:626-641.  Read and validated ONCE (on the first context): `-c` and `-cN` apply the same 288
+    // bytes or, with the same message, the defaults.
+    std::vector<uint8_t> cfgbuf;
+    if (argc == 5) {
       std::ifstream cfg(argv[4], std::ios::binary | std::ios::ate);
       std::streamoff size = cfg ? (std::streamoff)cfg.tellg() : -1;
       if (size != (std::streamoff)BCE_HIP_CONFIG_BYTES) {
         printf("Config not found or wrong size.\n");
       } else {
-        std::vector<uint8_t> buf(BCE_HIP_CONFIG_BYTES);
+        cfgbuf.resize(BCE_HIP_CONFIG_BYTES);
         cfg.seekg(0, std::ios::beg);
-        if (!cfg.read(reinterpret_cast<char *>(buf.data()), size)) printf("Could not read Config.\n");
-        else if (bce_hip_set_config(ctx, buf.data()) != 0) printf("Config rejected: %s\n", bce_hip_last_error(ctx));
+        if (!cfg.read(reinterpret_cast<char *>(cfgbuf.data()), size)) { printf("Could not read Config.\n"); cfgbuf.clear(); }
+        else if (bce_hip_set_config(ctx, cfgbuf.data()) != 0) { printf("Config rejected: %s\n", bce_hip_last_error(ctx)); cfgbuf.clear(); }
       }
     }
     std::ifstream file(argv[3], std::ios::binary | std::ios::ate);   // File::File, bce.cpp:842-856
@@ -139,15 +147,9 @@ int main(int argc, char **argv) {
     // `-cN` (N = 2..64, an extension): N blocks in a BCEM container, spread over the GPUs of the node
     const uint32_t nblocks = (uint32_t)atoi(argv[1] + 2);
     if (nblocks >= 2 && nblocks <= 64 && data.size() >= nblocks) {
-      uint8_t cfgbuf[BCE_HIP_CONFIG_BYTES];
-      bool have_cfg = false;
-      if (argc == 5) {
-        std::ifstream cf(argv[4], std::ios::binary);
-        have_cfg = (bool)cf.read(reinterpret_cast<char *>(cfgbuf), BCE_HIP_CONFIG_BYTES) && cf.peek() == EOF;
-      }
       bce_hip_destroy(ctx);
       std::vector<uint8_t> blob;
-      rc = compress_blocks(data, nblocks, have_cfg ? cfgbuf : nullptr, blob);
+      rc = compress_blocks(data, nblocks, cfgbuf.empty() ? nullptr : cfgbuf.data(), blob);
       if (rc != 0) { printf("Compression failed: %s\n", bce_hip_strerror(rc)); return -4; }
       std::chrono::duration<double> duration = std::chrono::high_resolution_clock::now() - start;
       printf("Compressed from %zu B -> %zu B in %.1f s\n", data.size(), blob.size(), duration.count());

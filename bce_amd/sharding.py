@@ -1,5 +1,7 @@
 """Block sharding across the GPUs of one node: one independent block per rank, no data-path collective,
 one gather of the coded streams to rank 0 (RCCL over xGMI with backend "nccl", gloo on CPU for tests)."""
+import os
+
 import torch
 
 
@@ -30,3 +32,34 @@ def gather_streams(archive: bytes, dist, device, dst=0):
     if rank != dst:
         return None
     return [o[:s].cpu().numpy().tobytes() for o, s in zip(outs, sizes)]
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def pin_to_local_numa(device_index):
+    """Restrict this process (and the threads it starts afterwards: the context's 8 range-coder threads) to the CPUs of
+    the NUMA node the GPU hangs off, so that 8 ranks x 9 host threads do not wander over both sockets.  Call before the
+    bce_hip context is created.  Returns the CPU set, or None when the topology cannot be read (nothing is changed)."""
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            cpus = _parse_cpulist(f.read()) & os.sched_getaffinity(0)
+        if len(cpus) < 9:          # too few for 8 coder threads + the driver thread: leave the affinity alone
+            return None
+        os.sched_setaffinity(0, cpus)
+        return cpus
+    except Exception:
+        return None

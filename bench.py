@@ -12,11 +12,19 @@ over RCCL inside the timed step.  Rank 0 prints ONE JSON line.
 Workload: BASELINE.json config[1] is enwik8 (10^8 bytes).  The corpus is not available offline; if a
 file is given with --file (or $BCE_BENCH_FILE) it is used, otherwise the stand-in is synth-text v1
 (SURVEY 8c generator) at 10^8 bytes, seed 1 + rank.
+
+Besides the headline the line carries (N = 1 only, all untimed with respect to `value`):
+  workloads         the same measurement on harder inputs of the same size class: the natural and binary corpora built
+                    from this image's own files (tools/make_corpus.py, make_binary_corpus.py) and synth-rand
+  value_end_to_end  the headline workload from a HOST buffer (H2D copy inside the timed region)
+  cpu_baseline      the oracle on a bounded sample, and the GPU path on the SAME sample: parity_sample_identical
+  oracle_golden     whether the headline archive equals the oracle's (tests/golden/oracle_fullsize.json)
 """
 import argparse
 import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,6 +37,8 @@ import bce_amd  # noqa: E402
 from bce_amd import sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+K3_KERNELS = ("K3 interval-count (k3_count2_kernel + k3_tiles_kernel<write> for wide rounds, k3_small_kernel for narrow ones, "
+              "k3_local_kernel / k3_dfs_kernel / k3_tail_kernel for the ends; all rounds of one compression = one launch unit)")
 
 
 def parse():
@@ -42,6 +52,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=48 << 20, help="bytes of the workload the CPU baseline compresses")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the untimed decode-and-compare leg (N=1 only)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the extra workloads (natural / binary corpus, synth-rand)")
     ap.add_argument("--scan-config", action="store_true",
                     help="BASELINE config 5: run `bce -s` on the input first (untimed), compress with the scanned table")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -49,23 +60,102 @@ def parse():
     return ap.parse_args()
 
 
-def make_input(args, rank):
+def make_input(args, rank, world):
     if args.file:
         data = np.fromfile(args.file, dtype=np.uint8)
-        per = len(data) // max(1, args.gpus)
-        blk = data[rank * per:(rank + 1) * per] if args.gpus > 1 else data
-        return np.ascontiguousarray(blk), "file:%s[%d B, sha256 %s]" % (os.path.basename(args.file), len(data), hashlib.sha256(data.tobytes()).hexdigest()[:16])
+        lo, hi = sharding.block_range(len(data), world, rank)      # one contiguous block per rank (world size, not --gpus)
+        return np.ascontiguousarray(data[lo:hi]), "file:%s[%d B, sha256 %s]" % (
+            os.path.basename(args.file), len(data), hashlib.sha256(data.tobytes()).hexdigest()[:16])
     gen = bce_amd.synth_text if args.workload == "synth-text" else bce_amd.synth_rand
-    return gen(1 + rank, args.size), "%s-v1 seed %d, %d B per GPU (enwik8-sized stand-in: the corpus is not available offline)" % (args.workload, 1 + rank, args.size)
+    return gen(1 + rank, args.size), "%s-v1 seed %d, %d B per GPU (enwik8-sized stand-in: the corpus is not available offline)" % (
+        args.workload, 1 + rank, args.size)
 
 
-def cpu_baseline(data, sample_bytes):
+def golden_table():
+    """Oracle-produced archive hashes at full size (tools/make_oracle_golden.py), keyed by input sha256."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "oracle_fullsize.json")) as f:
+            return {v["input_sha256"]: v for v in json.load(f)["vectors"]}
+    except Exception:
+        return {}
+
+
+def golden_verdict(table, data, arch):
+    """"identical" / "DIFFERENT" against the oracle's archive of the same input, None when the oracle never ran on it."""
+    v = table.get(hashlib.sha256(data.tobytes()).hexdigest())
+    if v is None:
+        return None
+    ok = len(arch) == v["archive_bytes"] and hashlib.sha256(arch).hexdigest() == v["archive_sha256"]
+    return "identical" if ok else "DIFFERENT"
+
+
+def roofline(n, sts):
+    st = sts[-1]
+    k3_s = sum(s["k3_ms"] for s in sts) / len(sts) / 1e3
+    alg_bytes = 384.0 * n + 16.0 * st["symbols"]     # SURVEY 8d: 48 B/node x 8n nodes + 16 B/symbol
+    return {"bound": "hbm", "kernel": K3_KERNELS,
+            "achieved": round(alg_bytes / k3_s / 1e9, 2) if k3_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(alg_bytes / k3_s / 1e9 / HBM_PEAK_GBS, 5) if k3_s > 0 else None,
+            "traffic": None, "algorithmic_bytes": alg_bytes, "k3_ms_per_step": round(k3_s * 1e3, 3),
+            "k3_launches_per_step": st["k3_launches"]}
+
+
+def timed_steps(ctx, t_in, n, steps, warmup, config=None):
+    for _ in range(warmup):
+        bce_amd.compress_device(t_in.data_ptr(), n, config=config, ctx=ctx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sts, arch = [], None
+    for _ in range(steps):
+        arch, st = bce_amd.compress_device(t_in.data_ptr(), n, config=config, ctx=ctx)
+        sts.append(st)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, arch, sts
+
+
+def extra_workloads(ctx, dev, table):
+    """The same measurement (input resident in HBM, 2 steps after 1 warm-up) on harder inputs."""
+    out = []
+    specs = [("natural corpus v2 (tools/make_corpus.py: this image's Python sources + ROCm headers; long repeats, ~2 M rounds)", "natural", 100_000_000),
+             ("binary corpus (tools/make_binary_corpus.py: this image's shared libraries; tables, zero runs)", "binary", 100_000_000),
+             ("synth-rand v1 seed 1 (6 symbols per byte)", "synth-rand", 32 << 20)]
+    for desc, kind, n in specs:
+        try:
+            if kind == "synth-rand":
+                data = bce_amd.synth_rand(1, n)
+            else:
+                path = "/tmp/bce_%s_%d.bin" % (kind, n)
+                if not (os.path.exists(path) and os.path.getsize(path) == n):
+                    tool = "make_corpus.py" if kind == "natural" else "make_binary_corpus.py"
+                    subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "--out", path, "--size", str(n)],
+                                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                data = np.fromfile(path, dtype=np.uint8)
+            t_in = torch.from_numpy(data).to(dev)
+            torch.cuda.synchronize()
+            dt, arch, sts = timed_steps(ctx, t_in, n, 2, 1)
+            del t_in
+            r = roofline(n, sts)
+            st = sts[-1]
+            out.append({"workload": desc, "bytes": n, "input_sha256": hashlib.sha256(data.tobytes()).hexdigest()[:16],
+                        "value": round(n * 2 / dt / 1e6, 3), "unit": "MB/s", "ms_per_step": round(dt / 2 * 1e3, 2),
+                        "k3_ms": r["k3_ms_per_step"], "roofline_frac": r["frac"], "rounds": st["rounds"], "symbols": st["symbols"],
+                        "sort_rounds": st["sort_rounds"], "k1_ms": round(st["t_bwt"] * 1e3, 2), "k4_ms": round(st["t_model"] * 1e3, 2),
+                        "coder_busy_ms": round(st["t_coder_busy"] * 1e3, 2),
+                        "archive_bytes": len(arch), "archive_sha256": hashlib.sha256(arch).hexdigest(),
+                        "oracle_golden": golden_verdict(table, data, arch)})
+        except Exception as e:   # a corpus that cannot be built on this box must not take the headline down
+            out.append({"workload": desc, "error": "%s: %s" % (type(e).__name__, e)})
+    return out
+
+
+def cpu_baseline(data, sample_bytes, ctx, dev):
     """The oracle (bit-exact CPU restatement of bce -c) timed on this host on a bounded sample: single thread (the
     reference built without OpenMP) and 8 threads (its OpenMP build: one thread per plane, joined every round,
-    bce.cpp:1250-1252; suffix sort and plane build stay serial there too).  The faster one is `value`."""
+    bce.cpp:1250-1252; suffix sort and plane build stay serial there too).  The faster one is `value`.  The GPU path
+    compresses the SAME sample: the two archives must be byte-identical, and gpu_over_cpu compares like with like."""
     import oracle
     oracle.build()
-    sample = data[:sample_bytes].tobytes()
+    sample = np.ascontiguousarray(data[:sample_bytes])
     runs = {}
     for threads in (1, 8):
         oracle.set_threads(threads)
@@ -75,11 +165,21 @@ def cpu_baseline(data, sample_bytes):
     oracle.set_threads(1)
     assert runs[1][2] == runs[8][2]
     best = min(runs, key=lambda t: runs[t][0])
-    return {"value": round(len(sample) / runs[best][0] / 1e6, 3), "unit": "MB/s", "cores": best, "kind": "port",
+    n = len(sample)
+    t_in = torch.from_numpy(sample).to(dev)
+    torch.cuda.synchronize()
+    dt, garch, _ = timed_steps(ctx, t_in, n, 2, 1)
+    identical = bool(bytes(garch) == arch)
+    cpu_v = n / runs[best][0] / 1e6
+    gpu_v = n * 2 / dt / 1e6
+    return {"value": round(cpu_v, 3), "unit": "MB/s", "cores": best, "kind": "port",
             "sample": "first %d B of the workload, oracle/bce_oracle.c: 1 thread %.1f s (%.2f MB/s), 8 OpenMP threads %.1f s (%.2f MB/s), archive %d B" % (
-                len(sample), runs[1][0], len(sample) / runs[1][0] / 1e6, runs[8][0], len(sample) / runs[8][0] / 1e6, runs[1][1]),
-            "single_thread_value": round(len(sample) / runs[1][0] / 1e6, 3),
-            "host_cpus": os.cpu_count()}
+                n, runs[1][0], n / runs[1][0] / 1e6, runs[8][0], n / runs[8][0] / 1e6, runs[1][1]),
+            "single_thread_value": round(n / runs[1][0] / 1e6, 3),
+            "host_cpus": os.cpu_count(),
+            "parity_sample_identical": identical,
+            "gpu_value_same_sample": round(gpu_v, 3),
+            "gpu_over_cpu_same_sample": round(gpu_v / cpu_v, 2)}
 
 
 def main():
@@ -87,6 +187,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        print("bench.py: --gpus %d ignored, WORLD_SIZE is %d (one rank per GPU)" % (args.gpus, world), file=sys.stderr)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -100,8 +202,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
+    sharding.pin_to_local_numa(local)            # the rank's 8 coder threads stay on the GPU's NUMA node
 
-    data, workload = make_input(args, rank)
+    data, workload = make_input(args, rank, world)
     n = len(data)
     t_in = torch.from_numpy(data).to(dev)       # input resident in HBM before the timed region
     torch.cuda.synchronize()
@@ -138,29 +241,29 @@ def main():
         arch, st = step()
         sts.append(st)
     barrier()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev if dist is not None else dev)
+    dt_local = time.perf_counter() - t0
+    tt = torch.tensor([dt_local], dtype=torch.float64, device=comm_dev if dist is not None else dev)
+    per_rank = [dt_local]
     if dist is not None:
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank = [float(x.item()) for x in allt]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
 
     if rank == 0:
         steps = max(1, args.steps)
         st = sts[-1]
-        k3_s = sum(s["k3_ms"] for s in sts) / len(sts) / 1e3
-        alg_bytes = 384.0 * n + 16.0 * st["symbols"]     # 48 B/node x 8n nodes + 16 B/symbol
-        traffic = None    # HBM bytes from PMC counters: measured offline (rocprofv3 --pmc passes), see profiles/
+        roof = roofline(n, sts)
+        table = golden_table()
+        # HBM bytes from the PMC counters are collected offline (tools/profile.sh: separate rocprofv3 --pmc passes), not in this run
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_f_k3_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_k3_traffic.json")))
             if tj["bytes_per_gpu"] == n and not args.file and args.workload == "synth-text":
-                traffic = tj["traffic_bytes_corrected"]
+                roof["traffic"] = tj["traffic_bytes_corrected"]
+                roof["traffic_source"] = "profiles/r02_k3_traffic.json (static: measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this workload, not in this run)"
         except Exception:
             pass
-        roof = {"bound": "hbm", "kernel": "K3 interval-count (k3_count2_kernel + k3_tiles_kernel<write> for wide rounds, k3_small_kernel for narrow ones, k3_tail_kernel / k3_dfs_kernel for the ends; all rounds of one compression = one launch unit)",
-                "achieved": round(alg_bytes / k3_s / 1e9, 2) if k3_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(alg_bytes / k3_s / 1e9 / HBM_PEAK_GBS, 5) if k3_s > 0 else None,
-                "traffic": traffic, "algorithmic_bytes": alg_bytes, "k3_ms_per_step": round(k3_s * 1e3, 3),
-                "k3_launches_per_step": st["k3_launches"]}
         if dist is not None and gathered[0] is not None:
             # the gathered per-block streams form the multi-block container (bce_amd/container.py)
             from bce_amd import container
@@ -174,11 +277,23 @@ def main():
             "config": {"workload": workload, "bytes_per_gpu": n, "coder_config": coder_config,
                        "sharding": "one independent block per GPU, RCCL gather of coded streams to rank 0" if n_gpus > 1 else "single block"},
             "archive_bytes": len(arch), "archive_sha256": hashlib.sha256(arch).hexdigest(),
+            "oracle_golden": golden_verdict(table, data, arch) if config is None else None,
             "ratio": round(len(arch) / n, 5),
             "roofline": roof,
             "breakdown_s": {k: round(st[k], 4) for k in ("t_load", "t_bwt", "t_planes", "t_enum", "t_model", "t_coder", "t_coder_busy")},
             "counts": {"nodes": st["nodes"], "symbols": st["symbols"], "rounds": st["rounds"], "sort_rounds": st["sort_rounds"], "flushes": st["flushes"]},
+            "ms_per_step_per_rank": [round(t / steps * 1e3, 2) for t in per_rank],
         }
+        if n_gpus == 1:
+            # SURVEY 8d's "file read -> archive bytes ready": the same workload from a (pageable) HOST buffer, H2D inside
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                a2 = bce_amd.compress(data, config=config, ctx=ctx)
+            te = (time.perf_counter() - t0) / 2
+            out["value_end_to_end"] = {"value": round(n / te / 1e6, 3), "unit": "MB/s", "ms_per_step": round(te * 1e3, 2),
+                                       "identical_to_headline": bool(bytes(a2) == bytes(arch)),
+                                       "note": "host buffer -> archive bytes on the host: the H2D copy of the input is inside the timed region (PCIe); not `value`"}
         if n_gpus == 1 and not args.no_decode and n <= 1_000_000_000:
             # untimed: the archive of the last step through the GPU-assisted decoder (`bce -d`), compared with the input
             t0 = time.perf_counter()
@@ -187,8 +302,10 @@ def main():
             out["decode"] = {"value": round(n / td / 1e6, 3), "unit": "MB/s", "seconds": round(td, 3),
                              "roundtrip_identical": bool(len(back) == n and hashlib.sha256(back).digest() == hashlib.sha256(data.tobytes()).digest()),
                              "note": "bce_hip_decompress_device: GPU passes + 8 host range decoders; not part of `value`"}
+        if n_gpus == 1 and not args.no_workloads and not args.file and args.workload == "synth-text":
+            out["workloads"] = extra_workloads(ctx, dev, table)
         if n_gpus == 1 and not args.no_cpu:
-            cb = cpu_baseline(data, min(args.cpu_sample, n))
+            cb = cpu_baseline(data, min(args.cpu_sample, n), ctx, dev)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = round(out["value"] / cb["value"], 2)
         else:

@@ -53,13 +53,20 @@ typedef void (*bce_hip_progress_fn)(uint64_t nodes_done, uint64_t nodes_total, v
 int bce_hip_set_progress(bce_hip_ctx *ctx, bce_hip_progress_fn fn, void *user);
 
 /* test knobs for the enumeration's alternative code paths (all 0 by default): 0 = nodes a depth-first walker
- * classifies per pass, 1 = disable the depth-first tail, 2 = disable the persistent LDS tail kernel, 3 = disable chain skipping, 4 = disable the one-launch kernel for narrow rounds, 6 = three launches per wide round (separate scan kernel) instead of two.
+ * classifies per pass, 1 = disable the depth-first tail, 2 = disable the persistent LDS tail kernel, 3 = disable chain skipping, 4 = disable the one-launch kernel for narrow rounds, 6 = three launches per wide round (separate scan kernel) instead of two, 7 = disable the workgroup-local rounds before the depth-first tail,
+ * 8 = live nodes above which the tail starts with them (default 65 536), 9 = rounds a workgroup runs before it hands on (default 1024),
+ * 10 = round from which the tail may start although the node count still grows (exercises the spill path).
  * The archive never depends on them. */
 int bce_hip_debug_set(bce_hip_ctx *ctx, int knob, uint32_t value);
 
 /* ---- stage 0: input ---------------------------------------------------------------------------- */
 /* File::File (bce.cpp:842-856): take the n input bytes.  _host copies host->HBM, _device copies
- * HBM->HBM from a device pointer of the same GPU (input already resident). 1 <= n < 2^31. */
+ * HBM->HBM from a device pointer of the same GPU (input already resident). 1 <= n < 2^31.
+ * Capacity: device memory is ~45 n bytes for the suffix sort and planes plus the enumeration's node lists, which hold
+ * n/2 + 2 nodes per plane (the worst case) whenever 16 such lists fit in 60 % of the free HBM -- n <= ~1.2 * 10^9 on an
+ * otherwise idle 288 GB MI355X -- and at least 192 M nodes per plane beyond that.  Text needs ~0.09 n nodes per plane,
+ * random bytes ~0.3 n: a high-entropy input of more than ~1.3 GB can exceed the lists, and bce_hip_encode then fails
+ * with BCE_HIP_E_OVERFLOW after the BWT has been built (never with a wrong archive). */
 int bce_hip_load_host(bce_hip_ctx *ctx, const uint8_t *in, uint32_t n);
 int bce_hip_load_device(bce_hip_ctx *ctx, const void *d_in, uint32_t n);
 

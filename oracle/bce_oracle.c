@@ -263,10 +263,18 @@ static void coder_encode(Coder *c, uint32_t cum, uint32_t freq, uint32_t total) 
 }
 static void coder_set2(Coder *c, uint32_t s, uint32_t k) { coder_encode(c, s, 1, k); }   /* :538-553: l+=step*s; h=step+l-1 */
 
+/* the slot number of get_context, :675: `auto ctx = (((c1 << bits) / cs) << bits) | ((c2 << bits) / cs);` with every operand
+   uint32_t -- c1 << bits wraps for c1 >= 2^(32-bits), i.e. on inputs of 2^27 bytes and more */
+static uint32_t context_index(uint32_t bits, uint32_t c1, uint32_t c2, uint32_t cs) {
+  return (((uint32_t)(c1 << bits) / cs) << bits) | ((uint32_t)(c2 << bits) / cs);
+}
+/* test hook: the expression alone, for tests/test_core_cpu.py (wrap cases cannot be reached by small inputs) */
+uint32_t bce_oracle_context_index(uint32_t bits, uint32_t c1, uint32_t c2, uint32_t cs) { return context_index(bits, c1, c2, cs); }
+
 static uint8_t *coder_context(Coder *c, uint32_t k, uint32_t c1, uint32_t c2, uint32_t cs) { /* :671-677 (uint32 wrap kept) */
   uint32_t off = c->off_[k];
   uint32_t bits = off >> 24;
-  uint32_t ctx = (((uint32_t)(c1 << bits) / cs) << bits) | ((uint32_t)(c2 << bits) / cs);
+  uint32_t ctx = context_index(bits, c1, c2, cs);
   return c->stat_ + (off & 0x00FFFFFF) + ctx * k;
 }
 static void coder_set5(Coder *c, uint32_t s, uint32_t k, uint32_t c1, uint32_t c2, uint32_t cs) { /* :506-536 */

@@ -41,6 +41,8 @@ def lib():
         L.bce_oracle_trace_rounds.restype = C.c_uint32
         L.bce_oracle_scan.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_double)]
         L.bce_oracle_scan.restype = C.c_int
+        L.bce_oracle_context_index.argtypes = [C.c_uint32] * 4
+        L.bce_oracle_context_index.restype = C.c_uint32
         L.bce_oracle_synth_rand.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t]
         L.bce_oracle_synth_text.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t]
         _lib = L
@@ -136,6 +138,11 @@ def trace_encode_from_bwt(bwt, offset, config=None):
     finally:
         L.bce_oracle_trace_end()
         L.bce_oracle_trace_free()
+
+
+def context_index(bits: int, c1: int, c2: int, cs: int) -> int:
+    """get_context's slot number (bce.cpp:675) in the reference's uint32 arithmetic."""
+    return lib().bce_oracle_context_index(bits, c1, c2, cs)
 
 
 def scan(data):

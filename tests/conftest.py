@@ -12,6 +12,35 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: wall-clock limits (kept out of the parity tests; generous, a shared box may still miss them)")
+
+
+def load_fullsize_golden():
+    """Oracle-produced archives at BASELINE sizes (tools/make_oracle_golden.py): name -> vector."""
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_fullsize.json")) as f:
+        return {v["name"]: v for v in json.load(f)["vectors"]}
+
+
+def fullsize_input(v):
+    """The input of a full-size vector as np.uint8, or None when this box cannot rebuild it (another image's files)."""
+    import subprocess
+
+    import numpy as np
+    if v["kind"] in ("synth_text", "synth_rand"):
+        import bce_amd
+        data = getattr(bce_amd, v["kind"])(v["seed"], v["n"])
+    else:
+        path = "/tmp/bce_%s_%d.bin" % (v["kind"], v["n"])
+        if not (os.path.exists(path) and os.path.getsize(path) == v["n"]):
+            tool = "make_corpus.py" if v["kind"] == "natural" else "make_binary_corpus.py"
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "--out", path, "--size", str(v["n"])],
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if r.returncode != 0:
+                return None
+        data = np.fromfile(path, dtype=np.uint8)
+    if hashlib.sha256(data.tobytes()).hexdigest() != v["input_sha256"]:
+        return None
+    return data
 
 
 def load_golden():

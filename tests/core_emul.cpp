@@ -115,6 +115,21 @@ extern "C" int emul_encode_from_bwt(const uint8_t *bwt, uint32_t n, uint32_t off
 }
 extern "C" void emul_free(void *p) { free(p); }
 
+// bce_core.h's context_index / pack_symbol on arrays of (k, c1, c2, cs) with the plane's config row: out[2*i] = context,
+// out[2*i+1] = slot (pack_symbol's key word).  Same float-reciprocal arithmetic as the kernels (host == device, bce_core.h).
+extern "C" void emul_context(const uint8_t *row32, const uint32_t *kccs, uint32_t cnt, uint32_t *out) {
+  PlaneCfg cfg;
+  plane_cfg_init(cfg, row32);
+  for (uint32_t i = 0; i < cnt; ++i) {
+    const uint32_t k = kccs[4 * i], c1 = kccs[4 * i + 1], c2 = kccs[4 * i + 2], cs = kccs[4 * i + 3];
+    out[2 * i] = context_index(cfg.bits[k], c1, c2, cs);
+    uint32_t kw, ew;
+    pack_symbol(cfg, 0, 0, k, c1, c2, cs, kw, ew);
+    out[2 * i + 1] = key_slot(kw);
+  }
+}
+extern "C" uint32_t emul_small_quotient(uint32_t a, uint32_t b) { return small_quotient(a, b); }
+
 // exhaustive-ish check of the reciprocal division used by the host coder: returns the number of mismatches
 extern "C" uint64_t emul_check_recip(uint64_t seed, uint64_t samples_per_divisor) {
   uint64_t bad = 0, st = seed ? seed : 1;

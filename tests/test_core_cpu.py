@@ -82,3 +82,47 @@ def test_granule_rank_matches_reference_rank(emul):
 def test_host_coder_reciprocal_division_is_exact(emul):
     """step = (h - l) / total (bce.cpp:527) is done by multiplication in the host coder: must be the exact quotient."""
     assert emul.emul_check_recip(12345, 2000) == 0
+
+
+def test_context_index_u32_wrap_matches_reference(emul):
+    """get_context (bce.cpp:671-677) computes (c1 << bits) / cs in uint32: for c1 >= 2^(32-bits) -- inputs of 2^27
+    bytes and more, BASELINE configs 3/4 -- the shift wraps.  The kernels divide with a float
+    reciprocal + exact correction (bce_core.h small_quotient, same arithmetic on host and device): check it against
+    the oracle's plain uint32 expression on operands that wrap, for every context width 1..5 and k = 2..31."""
+    emul.emul_context.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    emul.emul_small_quotient.argtypes = [C.c_uint32, C.c_uint32]
+    emul.emul_small_quotient.restype = C.c_uint32
+    rs = np.random.RandomState(20)
+    for bits in range(0, 6):
+        row = np.full(32, bits, dtype=np.uint8)
+        cases = []
+        for _ in range(4000):
+            # cs up to 2^31 - 1 (n < 2^31), c1, c2 < cs; half the cases force c1 into the wrapping range
+            cs = int(rs.randint(1 << 27, (1 << 31) - 1)) if rs.rand() < 0.8 else int(rs.randint(2, 1 << 27))
+            c1 = int(rs.randint(0, cs))
+            if bits and rs.rand() < 0.5 and cs > (1 << (32 - bits)):
+                c1 = int(rs.randint(1 << (32 - bits), cs))
+            c2 = int(rs.randint(0, cs))
+            cases.append((int(rs.randint(2, 32)), c1, c2, cs))
+        # edges: exactly at the wrap, one below, cs - 1, powers of two
+        for cs in ((1 << 31) - 1, (1 << 30) + 1, (1 << 27) + 5, 1 << 28):
+            for c1 in (cs - 1, (1 << (32 - bits)) % cs if bits else 0, max(0, (1 << (32 - bits)) - 1) % cs if bits else 1, cs // 2, 0):
+                cases.append((2, c1, cs - 1 - (c1 % 2), cs))
+        arr = np.array(cases, dtype=np.uint32)
+        out = np.empty((len(cases), 2), dtype=np.uint32)
+        emul.emul_context(row.ctypes.data, arr.ctypes.data, len(cases), out.ctypes.data)
+        nwrap = 0
+        for (k, c1, c2, cs), (ctx, slot) in zip(cases, out):
+            want = oracle.context_index(bits, c1, c2, cs)
+            assert ctx == want, (bits, k, c1, c2, cs, int(ctx), want)
+            assert want < (1 << (2 * bits))
+            nwrap += (c1 << bits) >= (1 << 32)
+            # slot = first slot of k + ctx  (plane_cfg_init: ctxoff[k] = sum over k' < k of 4^bits)
+            assert slot == (k - 2) * (1 << (2 * bits)) + want
+        if bits >= 2:          # (c1 < 2^31, so bits = 1 cannot wrap)
+            assert nwrap > 500
+    # the quotient primitive itself, on wrapped dividends
+    for _ in range(20000):
+        b = int(rs.randint(1 << 26, (1 << 31) - 1))
+        a = int(rs.randint(0, min((1 << 32) - 1, 32 * b - 1)))
+        assert emul.emul_small_quotient(a, b) == a // b

@@ -54,16 +54,18 @@ def test_full_pipeline_properties(gen, n):
         assert bce_amd.decompress(arch1) == data.tobytes()
 
 
-# BASELINE.json configs[1] / configs[2] sizes (enwik8 = 10^8 B, enwik9 = 10^9 B; synth-text stand-ins): the archive
-# hash is the one bench.py prints and DESIGN.md quotes, and the archive decodes back to the input.
-@pytest.mark.parametrize("n,sha_prefix", [(100_000_000, "9fefebab077374ba"), (1_000_000_000, "383c3b3c0acab6db")])
-def test_baseline_sizes_round_trip(n, sha_prefix):
+# BASELINE.json configs[2] size (enwik9 = 10^9 B; synth-text stand-in).  The oracle would need ~7 minutes and 13 GB for this
+# input, so this one archive has no oracle hash: the pin below is the GPU path's own output (a regression pin, named as
+# such) and the PROPERTY is the round trip.  Oracle-compared archives: 10^8 B and 1.5 * 10^8 B (> 2^27, the uint32
+# context wrap) in tests/test_gpu_fullsize.py.
+def test_enwik9_size_round_trip():
+    n, own_sha_prefix = 1_000_000_000, "383c3b3c0acab6db"
     data = bce_amd.synth_text(1, n)
     t = dev_input(data)
     arch, st = bce_amd.compress_device(t.data_ptr(), n)
     del t
     torch.cuda.empty_cache()
     assert st["nodes"] == 8 * n - 8
-    assert hashlib.sha256(arch).hexdigest().startswith(sha_prefix)
+    assert hashlib.sha256(arch).hexdigest().startswith(own_sha_prefix)
     back = bce_amd.decompress_device(arch)
     assert len(back) == n and hashlib.sha256(back).hexdigest() == hashlib.sha256(data.tobytes()).hexdigest()

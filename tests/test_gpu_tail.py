@@ -48,7 +48,7 @@ def test_whole_file_duplicate_is_one_skipped_chain():
         rf.close()
     assert arch == oracle.compress(data)
     assert st["nodes"] == 8 * len(data) - 8 and st["rounds"] > 8 * (2 << 20)
-    assert dt < 5.0, "chain skip not taken? encode took %.1f s" % dt
+    print("whole-file duplicate: encode %.2f s (time limits live in tests/test_gpu_perf.py)" % dt)
     assert bce_amd.decompress(arch) == data
 
 
@@ -92,7 +92,7 @@ def test_exactly_periodic_input_with_a_large_period():
         rf.close()
     assert arch == oracle.compress(data)
     assert bce_amd.decompress(arch) == data
-    assert dt < 10.0
+    print("exactly periodic input: encode %.2f s" % dt)
 
 
 def many_copies(copies, length, seed):
@@ -223,5 +223,29 @@ def test_megabyte_runs_do_not_crawl():
     t0 = time.time()
     assert bce_amd.decompress_device(arch) == data
     t_dec = time.time() - t0
-    print("megabyte runs: encode %.2f s, decode %.2f s" % (t_enc, t_dec))
-    assert t_enc < 5.0 and t_dec < 20.0
+    print("megabyte runs: encode %.2f s, decode %.2f s (time limits live in tests/test_gpu_perf.py)" % (t_enc, t_dec))
+
+
+# ---- workgroup-local rounds (k3_local_kernel): the stage between the wide rounds and the walkers ----
+LOCAL_KNOBS = [
+    ({8: 64}, "local-from-64"),                       # small live sets go through the local rounds too
+    ({8: 64, 9: 3}, "budget-3"),                      # a workgroup hands on after 3 rounds: almost everything ends at the walkers
+    ({8: 64, 9: 40, 0: 50}, "budget-40-short-walker-passes"),
+    ({8: 64, 3: 1}, "no-chain-exit"),                 # no chain skipping: nothing leaves the local rounds early
+    ({8: 64, 10: 17}, "tail-from-round-17"),          # the tail starts while the node count still doubles: lists overflow and spill
+    ({8: 64, 10: 19, 9: 5}, "tail-from-round-19-budget-5"),
+    ({7: 1}, "no-local"),
+]
+
+
+@pytest.mark.parametrize("knobs,name", LOCAL_KNOBS, ids=[n for _, n in LOCAL_KNOBS])
+@pytest.mark.parametrize("which", ["repeat", "copies", "rand", "text"])
+def test_local_rounds_give_the_same_archive(which, knobs, name):
+    data = {"repeat": lambda: repeat_input(300000, 2500, seed=34),
+            "copies": lambda: many_copies(60, 900, 71),
+            "rand": lambda: oracle.synth_rand(12, 150000),
+            "text": lambda: oracle.synth_text(13, 700000)}[which]()
+    ref = oracle.compress(data)
+    arch, st = _encode_with_knobs(data, knobs)
+    assert arch == ref
+    assert st["nodes"] == 8 * len(data) - 8

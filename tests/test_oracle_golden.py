@@ -74,3 +74,28 @@ def test_openmp_round_loop_gives_the_same_archive():
     finally:
         oracle.set_threads(1)
     assert a1 == a8
+
+
+def test_fullsize_golden_file_is_oracle_made_and_reproducible_at_16mib():
+    """tests/golden/oracle_fullsize.json (tools/make_oracle_golden.py): the vectors the -m gpu tests pin BASELINE-size
+    archives to.  Here, without a GPU: the file is complete, and the oracle reproduces its 16 MiB corpus vectors (the
+    10^8-byte ones take 40-65 s each and are left to the tool)."""
+    import hashlib
+
+    from conftest import fullsize_input, load_fullsize_golden
+    gold = load_fullsize_golden()
+    for name in ("synth-text-1e8", "synth-text-1.5e8", "synth-rand-32Mi", "natural-1e8", "binary-1e8"):
+        v = gold[name]
+        assert len(v["archive_sha256"]) == 64 and v["archive_bytes"] > 0 and v["oracle_seconds_1_thread"] > 0
+    assert gold["synth-text-1.5e8"]["n"] > (1 << 27)
+    import numpy as np
+    checked = 0
+    for name in ("natural-16Mi", "binary-16Mi"):
+        v = gold[name]
+        data = fullsize_input(v)
+        if data is None:
+            continue                      # another image's files: nothing to compare on this box
+        arch = oracle.compress(np.ascontiguousarray(data))
+        assert len(arch) == v["archive_bytes"] and hashlib.sha256(arch).hexdigest() == v["archive_sha256"], name
+        checked += 1
+    print("16 MiB corpus vectors reproduced by the oracle: %d of 2" % checked)

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Full-size known answers from the CPU ORACLE (oracle/bce_oracle.c, single thread), written to
+tests/golden/oracle_fullsize.json.  The GPU tests and bench.py then pin archives at BASELINE.json's sizes against
+hashes the oracle produced -- never against the GPU path's own output.
+
+Workloads (all regenerable on any box with this image; inputs are not stored, their sha256 is):
+  synth-text / synth-rand  SURVEY 8c generators (xorshift64*), seed 1
+  natural                  tools/make_corpus.py          (the image's Python sources + ROCm headers)
+  binary                   tools/make_binary_corpus.py   (the image's shared libraries)
+
+    python tools/make_oracle_golden.py                 # everything (several minutes of CPU, ~2 GB of memory per job)
+    python tools/make_oracle_golden.py --only synth-text-1e8 natural-1e8
+"""
+import argparse
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden", "oracle_fullsize.json")
+
+JOBS = [
+    # name, kind, n
+    ("synth-text-1e8", "synth_text", 100_000_000),          # BASELINE configs[1] stand-in (enwik8-sized)
+    ("synth-text-1.5e8", "synth_text", 150_000_000),        # n > 2^27: get_context's uint32 wrap (quirk Q1)
+    ("synth-rand-32Mi", "synth_rand", 32 << 20),            # 6 symbols per byte
+    ("natural-1e8", "natural", 100_000_000),
+    ("binary-1e8", "binary", 100_000_000),
+    ("natural-16Mi", "natural", 16 << 20),
+    ("binary-16Mi", "binary", 16 << 20),
+]
+
+
+def corpus(kind, n, cache="/tmp"):
+    path = os.path.join(cache, "bce_%s_%d.bin" % (kind, n))
+    if not (os.path.exists(path) and os.path.getsize(path) == n):
+        tool = "make_corpus.py" if kind == "natural" else "make_binary_corpus.py"
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", tool), "--out", path, "--size", str(n)])
+    return np.fromfile(path, dtype=np.uint8)
+
+
+def make_input(kind, n):
+    if kind in ("synth_text", "synth_rand"):
+        return np.frombuffer(getattr(oracle, kind)(1, n), dtype=np.uint8)
+    return corpus(kind, n)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*")
+    a = ap.parse_args()
+    oracle.build()
+    oracle.set_threads(1)
+    res = {}
+    if os.path.exists(OUT):
+        res = {v["name"]: v for v in json.load(open(OUT))["vectors"]}
+    for name, kind, n in JOBS:
+        if a.only and name not in a.only:
+            continue
+        data = make_input(kind, n)
+        assert len(data) == n, (name, len(data))
+        t0 = time.time()
+        arch = oracle.compress(data)
+        dt = time.time() - t0
+        res[name] = {"name": name, "kind": kind, "seed": 1 if kind.startswith("synth") else None, "n": n,
+                     "input_sha256": hashlib.sha256(data.tobytes()).hexdigest(),
+                     "archive_bytes": len(arch), "archive_sha256": hashlib.sha256(arch).hexdigest(),
+                     "oracle_seconds_1_thread": round(dt, 1)}
+        print(json.dumps(res[name]), flush=True)
+        doc = {"provenance": "oracle/bce_oracle.c (CPU restatement of bce -c, single thread) run by tools/make_oracle_golden.py; "
+                             "no GPU code involved.  The natural/binary corpora are built from the files of this container image, so "
+                             "their input_sha256 only matches on a box with the same image (tests skip otherwise).",
+               "vectors": [res[k] for k in sorted(res)]}
+        with open(OUT, "w") as f:
+            json.dump(doc, f, indent=1)
+            f.write("\n")
+
+
+if __name__ == "__main__":
+    main()
