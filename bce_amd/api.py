@@ -54,6 +54,8 @@ SYMBOLS = [
     ("bce_hip_bwt", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     ("bce_hip_set_bwt", C.c_int, [C.c_void_p, _u8p, C.c_uint32, C.c_uint32]),
     ("bce_hip_get_bwt", C.c_int, [C.c_void_p, _u8p]),
+    ("bce_hip_divbwt", C.c_int, [C.c_void_p, _u8p, _u8p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("bce_hip_inverse_bwt", C.c_int, [C.c_void_p, _u8p, _u8p, C.c_uint32, C.c_uint32]),
     ("bce_hip_build_planes", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     ("bce_hip_get_plane_bits", C.c_int, [C.c_void_p, C.c_int, _u8p]),
     ("bce_hip_rank1", C.c_int, [C.c_void_p, C.c_int, _u32p, C.c_uint32, _u32p]),

@@ -232,6 +232,24 @@ int bce_hip_get_bwt(bce_hip_ctx *c, uint8_t *out) {
   return BCE_HIP_OK;
 }
 
+int bce_hip_divbwt(bce_hip_ctx *c, const uint8_t *in, uint8_t *out, uint32_t n, uint32_t *primary) {
+  if (!c || !in || !out || !primary || n == 0) return BCE_HIP_E_ARG;
+  return bce_guarded(c, [&]() -> int {
+    BCE_HIP_TRY(c, hipSetDevice(c->device));
+    c->coder->drain();
+    return k1_divbwt(c, in, out, n, primary);
+  });
+}
+
+int bce_hip_inverse_bwt(bce_hip_ctx *c, const uint8_t *in, uint8_t *out, uint32_t n, uint32_t primary) {
+  if (!c || !in || !out || n == 0) return BCE_HIP_E_ARG;
+  return bce_guarded(c, [&]() -> int {
+    BCE_HIP_TRY(c, hipSetDevice(c->device));
+    c->coder->drain();
+    return kd_inverse_bw_transform(c, in, out, n, primary);
+  });
+}
+
 int bce_hip_build_planes(bce_hip_ctx *c, uint32_t zeros[8]) {
   BCE_TRY(check_stage(c, 2));
   BCE_HIP_TRY(c, hipSetDevice(c->device));

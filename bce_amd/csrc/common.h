@@ -180,6 +180,8 @@ inline uint32_t ceil_log2(uint32_t v) { uint32_t b = 0; while ((1ull << b) < v) 
 
 // ---- stage implementations (one .hip file each) ----
 int k1_bwt(bce_hip_ctx *c);                         // k1_bwt.hip
+int k1_divbwt(bce_hip_ctx *c, const uint8_t *T_host, uint8_t *U_host, uint32_t n, uint32_t *pidx);   // the libdivsufsort seam
+int kd_inverse_bw_transform(bce_hip_ctx *c, const uint8_t *T_host, uint8_t *U_host, uint32_t n, uint32_t idx);   // kd_decode.hip
 int k2_build_planes(bce_hip_ctx *c);                // k2_planes.hip
 int k2_get_plane_bits(bce_hip_ctx *c, int plane, uint8_t *out);
 int k2_rank1(bce_hip_ctx *c, int plane, const uint32_t *idx, uint32_t count, uint32_t *out);

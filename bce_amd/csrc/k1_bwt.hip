@@ -56,6 +56,23 @@ __global__ __launch_bounds__(K1_T) void k1_init_kernel(const uint8_t *__restrict
   }
 }
 
+// The same for T$ with a unique smallest sentinel (the libdivsufsort seam, k1_divbwt): m = n + 1 rotations, 9-bit symbols
+// (0 = $, byte + 1 otherwise), three of them per key.  Rotations of T$ compare like the suffixes of T$.
+__global__ __launch_bounds__(K1_T) void k1_init_sentinel_kernel(const uint8_t *__restrict__ T, uint32_t m,
+                                                                uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  for (uint64_t i = (uint64_t)blockIdx.x * K1_T + threadIdx.x; i < m; i += (uint64_t)gridDim.x * K1_T) {
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < 3; ++b) {
+      uint64_t q = i + b;
+      if (q >= m) q -= m;
+      k = (k << 9) | (q == m - 1u ? 0u : (uint32_t)T[q] + 1u);
+    }
+    keys[i] = k;
+    vals[i] = (uint32_t)i;
+  }
+}
+
 // keys[j] = rank[SA[j] - h], vals[j] = SA[j] - h   (indices mod n)
 __global__ __launch_bounds__(K1_T) void k1_gather_prev_kernel(const uint32_t *__restrict__ sa,
                                                               const uint32_t *__restrict__ rank, uint32_t n,
@@ -261,20 +278,9 @@ static uint32_t grid_for(uint32_t n) {
   return (uint32_t)(b < 4096 ? (b ? b : 1) : 4096);
 }
 
-int k1_bwt(bce_hip_ctx *c) {
-  const uint32_t n = c->n;
-  uint8_t *T = c->text.as<uint8_t>();
-  BCE_TRY(ensure(c, c->bwt, n));
-  uint8_t *bwt = c->bwt.as<uint8_t>();
-  c->stats.sort_rounds = 0;
-  c->k1_unique = false;
-  c->k1_valid = false;
-  if (n == 1) {
-    BCE_HIP_TRY(c, hipMemcpyAsync(bwt, T, 1, hipMemcpyDeviceToDevice, c->stream));
-    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->offset = 0;
-    return BCE_HIP_OK;
-  }
+// Sort the n cyclic rotations of T (sentinel = false), or the n = |T| + 1 rotations of T$ (sentinel = true: T holds n - 1
+// bytes).  Leaves the order in c->sa[c->sa_res] and its inverse (the rank of the group head for tied rotations) in c->rank.
+static int k1_sort_rotations(bce_hip_ctx *c, const uint8_t *T, uint32_t n, bool sentinel) {
   const size_t b4 = (size_t)n * 4;
   for (int i = 0; i < 2; ++i) { BCE_TRY(ensure(c, c->sa[i], b4)); BCE_TRY(ensure(c, c->key[i], b4)); }
   BCE_TRY(ensure(c, c->rank, b4));
@@ -290,9 +296,14 @@ int k1_bwt(bce_hip_ctx *c) {
 
   uint32_t *key[2] = {c->key[0].as<uint32_t>(), c->key[1].as<uint32_t>()};
   uint32_t *val[2] = {c->sa[0].as<uint32_t>(), c->sa[1].as<uint32_t>()};
-  hipLaunchKernelGGL(k1_init_kernel, dim3(g), dim3(K1_T), 0, c->stream, T, n, key[0], val[0]);
   int res = 0;
-  BCE_TRY(radix_sort_pairs(c, key, val, n, 0, 32, &res));
+  if (sentinel) {
+    hipLaunchKernelGGL(k1_init_sentinel_kernel, dim3(g), dim3(K1_T), 0, c->stream, T, n, key[0], val[0]);
+    BCE_TRY(radix_sort_pairs(c, key, val, n, 0, 27, &res, 9));
+  } else {
+    hipLaunchKernelGGL(k1_init_kernel, dim3(g), dim3(K1_T), 0, c->stream, T, n, key[0], val[0]);
+    BCE_TRY(radix_sort_pairs(c, key, val, n, 0, 32, &res));
+  }
   uint32_t groups = 0;
   auto rerank = [&](const uint32_t *k1s, const uint32_t *k2s, const uint32_t *sa) -> int {
     BCE_HIP_TRY(c, hipMemsetAsync(scalars, 0, 4, c->stream));
@@ -307,7 +318,7 @@ int k1_bwt(bce_hip_ctx *c) {
   BCE_TRY(rerank(key[res], nullptr, val[res]));
   const uint32_t bits = ceil_log2(n);
   const uint32_t dg = 9;   // digit width of the rank sorts (7..9 measured equal)
-  uint64_t h = 4;
+  uint64_t h = sentinel ? 3 : 4;
   uint32_t *act[2] = {c->act[0].as<uint32_t>(), c->act[1].as<uint32_t>()};
   uint32_t m = n;                 // active elements; the list is implicit (identity) while every element is active
   bool have_list = false;
@@ -375,19 +386,75 @@ int k1_bwt(bce_hip_ctx *c) {
     c->stats.sort_rounds++;
     have_list = false;
   }
+  // all rotations distinct <=> rank[] is the inverse of the suffix array (used by the depth-first tail of K3)
+  c->k1_unique = (groups >= n) || (have_list && m == 0);
+  c->sa_res = res;
+  return BCE_HIP_OK;
+}
+
+int k1_bwt(bce_hip_ctx *c) {
+  const uint32_t n = c->n;
+  uint8_t *T = c->text.as<uint8_t>();
+  BCE_TRY(ensure(c, c->bwt, n));
+  uint8_t *bwt = c->bwt.as<uint8_t>();
+  c->stats.sort_rounds = 0;
+  c->k1_unique = false;
+  c->k1_valid = false;
+  if (n == 1) {
+    BCE_HIP_TRY(c, hipMemcpyAsync(bwt, T, 1, hipMemcpyDeviceToDevice, c->stream));
+    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->offset = 0;
+    return BCE_HIP_OK;
+  }
+  BCE_TRY(k1_sort_rotations(c, T, n, false));
+  const uint32_t g = grid_for(n);
+  uint32_t *scalars = c->blk.as<uint32_t>() + k1_plan(n).nb;   // [0] groups, [1] offset
+  const uint32_t *sa = c->sa[c->sa_res].as<uint32_t>();
   BCE_HIP_TRY(c, hipMemsetAsync(scalars + 1, 0xFF, 4, c->stream));
-  hipLaunchKernelGGL(k1_bwt_kernel, dim3(g), dim3(K1_T), 0, c->stream, T, val[res], n, bwt);
-  hipLaunchKernelGGL(k1_offset_kernel, dim3(g), dim3(K1_T), 0, c->stream, rank, n, scalars + 1);
+  hipLaunchKernelGGL(k1_bwt_kernel, dim3(g), dim3(K1_T), 0, c->stream, T, sa, n, bwt);
+  hipLaunchKernelGGL(k1_offset_kernel, dim3(g), dim3(K1_T), 0, c->stream, c->rank.as<uint32_t>(), n, scalars + 1);
   uint32_t off = 0;
   BCE_HIP_TRY(c, hipMemcpyAsync(&off, scalars + 1, 4, hipMemcpyDeviceToHost, c->stream));
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
   BCE_HIP_TRY(c, hipGetLastError());
   if (off >= n) { snprintf(c->err, sizeof c->err, "k1: no rank-0 rotation found"); return BCE_HIP_E_INTERNAL; }
   c->offset = off;
-  // all rotations distinct <=> rank[] is the inverse of the suffix array (used by the depth-first tail of K3)
-  c->k1_unique = (groups >= n) || (have_list && m == 0);
-  c->sa_res = res;
   c->k1_valid = true;
+  return BCE_HIP_OK;
+}
+
+// ---- the libdivsufsort seam (include/divsufsort_hip.h; bce.cpp:901) -------------------------------------------------------
+// divbwt(T, U, A, n): the BWT of T[0, n) with an implicit smallest sentinel -- U[0] = T[n-1], then T[SA[i] - 1] for the
+// suffixes in sorted order, the one with SA[i] = 0 left out; returns its 1-based position (the primary index).  Here: the
+// rotation sort above on T$ (unique sentinel: rotations compare like suffixes), then one gather.
+__global__ __launch_bounds__(K1_T) void k1_divbwt_gather_kernel(const uint8_t *__restrict__ T, const uint32_t *__restrict__ sa,
+                                                                uint32_t m, uint32_t pidx, uint8_t *__restrict__ U) {
+  for (uint64_t j = (uint64_t)blockIdx.x * K1_T + threadIdx.x; j < m; j += (uint64_t)gridDim.x * K1_T) {
+    const uint32_t p = sa[j];                    // sa[0] = m - 1: the rotation that starts with $
+    if (p != 0u) U[j < pidx ? j : j - 1u] = T[p - 1u];
+  }
+}
+
+int k1_divbwt(bce_hip_ctx *c, const uint8_t *T_host, uint8_t *U_host, uint32_t n, uint32_t *pidx_out) {
+  if (n == 0 || n >= 0x7FFFFFFFu) return BCE_HIP_E_ARG;
+  const uint32_t m = n + 1u;
+  BCE_TRY(ensure(c, c->text, m));
+  BCE_TRY(ensure(c, c->bwt, m));
+  uint8_t *T = c->text.as<uint8_t>();
+  BCE_HIP_TRY(c, hipMemcpyAsync(T, T_host, n, hipMemcpyHostToDevice, c->stream));
+  c->stage = 0; c->k1_valid = false; c->enum_active = false;          // the context's compression state is gone
+  c->stats.sort_rounds = 0;
+  BCE_TRY(k1_sort_rotations(c, T, m, true));
+  uint32_t pidx = 0;
+  BCE_HIP_TRY(c, hipMemcpyAsync(&pidx, c->rank.as<uint32_t>(), 4, hipMemcpyDeviceToHost, c->stream));   // row of suffix 0
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (pidx == 0 || pidx > n) { snprintf(c->err, sizeof c->err, "divbwt: primary index %u out of range", pidx); return BCE_HIP_E_INTERNAL; }
+  hipLaunchKernelGGL(k1_divbwt_gather_kernel, dim3(grid_for(m)), dim3(K1_T), 0, c->stream, T, c->sa[c->sa_res].as<uint32_t>(), m,
+                     pidx, c->bwt.as<uint8_t>());
+  BCE_HIP_TRY(c, hipMemcpyAsync(U_host, c->bwt.p, n, hipMemcpyDeviceToHost, c->stream));
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  BCE_HIP_TRY(c, hipGetLastError());
+  *pidx_out = pidx;
   return BCE_HIP_OK;
 }
 

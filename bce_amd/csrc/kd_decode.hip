@@ -938,6 +938,85 @@ __global__ void expand_cycle_kernel(const uint8_t *__restrict__ V, uint32_t lc, 
   }
 }
 
+// ---- the libdivsufsort seam: inverse_bw_transform(T, U, A, n, idx) (include/divsufsort_hip.h; bce.cpp:1091) ----
+// T = the BWT divbwt produces (n bytes, the suffix-0 row left out at 1-based position idx).  With the row put back as a
+// sentinel the n + 1 rows are the BWT of the rotations of T$: LF by one stable radix pass on 9-bit symbols (0 = $), then
+// the decoder's walk from row 0 -- the rotation that starts with $, preceded by the last text byte -- backwards through
+// the text.  One cycle of n + 1 rows always (the sentinel is unique).
+__global__ void seam_rows_kernel(const uint8_t *__restrict__ U, uint32_t n, uint32_t idx, uint8_t *__restrict__ rows,
+                                 uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
+    const uint32_t b = i == idx ? 0u : (uint32_t)U[i < idx ? i : i - 1u];
+    rows[i] = (uint8_t)b;
+    keys[i] = i == idx ? 0u : b + 1u;
+    vals[i] = i;
+  }
+}
+
+}  // namespace
+
+int kd_inverse_bw_transform(bce_hip_ctx *c, const uint8_t *T_host, uint8_t *U_host, uint32_t n, uint32_t idx) {
+  if (n == 0 || n >= 0x7FFFFFFFu || idx == 0 || idx > n) return BCE_HIP_E_ARG;
+  const uint32_t m_rows = n + 1u;
+  const size_t b4 = (size_t)m_rows * 4;
+  BCE_TRY(ensure(c, c->text, m_rows));
+  BCE_TRY(ensure(c, c->bwt, m_rows));
+  BCE_TRY(ensure(c, c->ptmp[0], m_rows));
+  for (int i = 0; i < 2; ++i) { BCE_TRY(ensure(c, c->sa[i], b4)); BCE_TRY(ensure(c, c->key[i], b4)); }
+  BCE_TRY(ensure(c, c->rank, b4));
+  c->stage = 0; c->k1_valid = false; c->enum_active = false;          // the context's compression state is gone
+  uint8_t *d_in = c->ptmp[0].as<uint8_t>(), *rows = c->bwt.as<uint8_t>();
+  BCE_HIP_TRY(c, hipMemcpyAsync(d_in, T_host, n, hipMemcpyHostToDevice, c->stream));
+  uint32_t *key[2] = {c->key[0].as<uint32_t>(), c->key[1].as<uint32_t>()};
+  uint32_t *val[2] = {c->sa[0].as<uint32_t>(), c->sa[1].as<uint32_t>()};
+  uint32_t *lf = c->rank.as<uint32_t>();
+  const uint32_t gn = (uint32_t)((((uint64_t)m_rows + 255) / 256) < 8192 ? (((uint64_t)m_rows + 255) / 256) : 8192);
+  hipLaunchKernelGGL(seam_rows_kernel, dim3(gn), dim3(256), 0, c->stream, d_in, n, idx, rows, key[0], val[0]);
+  int res = 0;
+  BCE_TRY(radix_sort_pairs(c, key, val, m_rows, 0, 9, &res, 9));
+  hipLaunchKernelGGL(lf_scatter_kernel, dim3(gn), dim3(256), 0, c->stream, val[res], m_rows, lf);
+  uint32_t sh = 0;
+  while (((uint64_t)m_rows >> sh) > (1u << 19)) ++sh;          // at most 2^19 walkers
+  const uint32_t m = (uint32_t)((((uint64_t)m_rows - 1) >> sh) + 1);
+  BCE_TRY(ensure(c, c->key[0], (size_t)3 * m * 4 + 16 > b4 ? (size_t)3 * m * 4 + 16 : b4));
+  uint32_t *d_len = c->key[0].as<uint32_t>(), *d_end = d_len + m, *d_dest = d_len + 2 * (size_t)m;
+  hipLaunchKernelGGL(walk_len_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, lf, m, sh, d_len, d_end);
+  std::vector<uint32_t> h_len(m), h_end(m), h_dest(m, 0);
+  BCE_HIP_TRY(c, hipMemcpyAsync(h_len.data(), d_len, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+  BCE_HIP_TRY(c, hipMemcpyAsync(h_end.data(), d_end, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  BCE_HIP_TRY(c, hipGetLastError());
+  uint64_t lc = 0;
+  {
+    uint32_t cur = 0;
+    std::vector<uint8_t> visited(m, 0);
+    std::vector<uint32_t> order;
+    do {
+      const uint32_t j = cur >> sh;
+      if (visited[j]) return BCE_HIP_E_ARG;                      // not the BWT of anything (T / idx inconsistent)
+      visited[j] = 1;
+      order.push_back(j);
+      lc += h_len[j];
+      cur = h_end[j];
+    } while (cur != 0);
+    uint64_t pos = lc;
+    for (uint32_t j : order) { h_dest[j] = (uint32_t)pos; pos -= h_len[j]; }
+    for (uint32_t j = 0; j < m; ++j) if (!visited[j]) h_len[j] = 0;
+  }
+  if (lc != m_rows) return BCE_HIP_E_ARG;                        // several LF cycles: T / idx inconsistent
+  BCE_HIP_TRY(c, hipMemcpyAsync(d_dest, h_dest.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+  BCE_HIP_TRY(c, hipMemcpyAsync(d_len, h_len.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+  // the walk's positions are those of $T: shifted by n (= -1 mod n + 1) the text lands at [0, n), the sentinel's slot at n
+  hipLaunchKernelGGL(walk_write_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, lf, rows, m, sh, d_len, d_dest, m_rows, n,
+                     c->text.as<uint8_t>());
+  BCE_HIP_TRY(c, hipMemcpyAsync(U_host, c->text.p, n, hipMemcpyDeviceToHost, c->stream));
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  BCE_HIP_TRY(c, hipGetLastError());
+  return BCE_HIP_OK;
+}
+
+namespace {
+
 // ---- the host's part of a round: the eight plane decoders answer their queries, in parallel ----
 struct QueryPool {
   std::vector<Decoder> *dec = nullptr;

@@ -81,6 +81,14 @@ int bce_hip_set_bwt(bce_hip_ctx *ctx, const uint8_t *bwt, uint32_t n, uint32_t o
 /* Copy the BWT bytes back (n bytes). */
 int bce_hip_get_bwt(bce_hip_ctx *ctx, uint8_t *bwt_out);
 
+/* The libdivsufsort seam itself (bce.cpp:901, :1091): the two functions of that library's C ABI which the reference calls,
+ * with their argument meaning, on a context (include/divsufsort_hip.h + libdivsufsort_hip.so wrap them under their
+ * original names and signatures, so that an unmodified bce.cpp links against them).  Host buffers; in == out allowed.
+ * divbwt: BWT of in[0, n) with an implicit smallest sentinel, *primary = 1-based row of suffix 0.  The context's
+ * compression state is dropped by either call. */
+int bce_hip_divbwt(bce_hip_ctx *ctx, const uint8_t *in, uint8_t *out, uint32_t n, uint32_t *primary);
+int bce_hip_inverse_bwt(bce_hip_ctx *ctx, const uint8_t *in, uint8_t *out, uint32_t n, uint32_t primary);
+
 /* ---- stage 2 (K2): wavelet-matrix bit planes + rank directory ----------------------------------- */
 /* RankFile ctor body + Rank::build (bce.cpp:944-970, 138-145).  zeros[j] = rank0_j(n). */
 int bce_hip_build_planes(bce_hip_ctx *ctx, uint32_t zeros[8]);

@@ -126,6 +126,26 @@ static int32_t oracle_divbwt(const uint8_t *T, uint8_t *U, int32_t m) {
   return pidx;
 }
 
+/* test hooks for the libdivsufsort seam (tests/test_gpu_seam.py): the restated divbwt, and its inverse by the textbook
+   LF walk (bce.cpp:1091 calls inverse_bw_transform(T, T, NULL, n, 1)) */
+int32_t bce_oracle_divbwt(const uint8_t *T, uint8_t *U, int32_t n) { return oracle_divbwt(T, U, n); }
+int bce_oracle_inverse_bwt(const uint8_t *T, uint8_t *U, int32_t n, int32_t idx) {
+  if (n <= 0 || idx <= 0 || idx > n) return -1;
+  /* rows of the BWT of T$: 0..n, row idx holds the sentinel; LF(row) = C[sym] + occurrences before the row */
+  uint32_t C[258] = {0};
+  uint32_t *lf = (uint32_t *)malloc(((size_t)n + 1) * sizeof(uint32_t));
+  uint8_t *tmp = (uint8_t *)malloc((size_t)n);
+  if (!lf || !tmp) { free(lf); free(tmp); return -2; }
+  for (int32_t r = 0; r <= n; ++r) { uint32_t sy = r == idx ? 0u : (uint32_t)T[r < idx ? r : r - 1] + 1u; C[sy + 1]++; }
+  for (int k = 1; k < 258; ++k) C[k] += C[k - 1];
+  for (int32_t r = 0; r <= n; ++r) { uint32_t sy = r == idx ? 0u : (uint32_t)T[r < idx ? r : r - 1] + 1u; lf[r] = C[sy]++; }
+  uint32_t row = 0;
+  for (int32_t i = n - 1; i >= 0; --i) { tmp[i] = T[row < (uint32_t)idx ? row : row - 1]; row = lf[row]; }
+  memcpy(U, tmp, (size_t)n);
+  free(lf); free(tmp);
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * File::rotate (bce.cpp:858-894): index of the first minimal cyclic rotation; buffer rotated so
  * that the minimal rotation's first byte ends up LAST.  Returns offset_ (= i).

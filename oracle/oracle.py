@@ -41,6 +41,10 @@ def lib():
         L.bce_oracle_trace_rounds.restype = C.c_uint32
         L.bce_oracle_scan.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_double)]
         L.bce_oracle_scan.restype = C.c_int
+        L.bce_oracle_divbwt.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.bce_oracle_divbwt.restype = C.c_int32
+        L.bce_oracle_inverse_bwt.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.bce_oracle_inverse_bwt.restype = C.c_int
         L.bce_oracle_context_index.argtypes = [C.c_uint32] * 4
         L.bce_oracle_context_index.restype = C.c_uint32
         L.bce_oracle_synth_rand.argtypes = [C.c_uint64, C.c_void_p, C.c_size_t]
@@ -138,6 +142,24 @@ def trace_encode_from_bwt(bwt, offset, config=None):
     finally:
         L.bce_oracle_trace_end()
         L.bce_oracle_trace_free()
+
+
+def divbwt(data):
+    """libdivsufsort's divbwt(T, U, NULL, n) as restated for the oracle -> (U bytes, primary index)."""
+    a, p = _buf(data)
+    out = np.empty(len(a), dtype=np.uint8)
+    pidx = lib().bce_oracle_divbwt(p, out.ctypes.data_as(C.c_void_p), len(a))
+    return out.tobytes(), pidx
+
+
+def inverse_bwt(bwt, idx) -> bytes:
+    """The inverse (inverse_bw_transform(T, U, NULL, n, idx)) by the textbook LF walk."""
+    a, p = _buf(bwt)
+    out = np.empty(len(a), dtype=np.uint8)
+    rc = lib().bce_oracle_inverse_bwt(p, out.ctypes.data_as(C.c_void_p), len(a), idx)
+    if rc != 0:
+        raise ValueError("oracle inverse_bwt failed rc=%d" % rc)
+    return out.tobytes()
 
 
 def context_index(bits: int, c1: int, c2: int, cs: int) -> int:

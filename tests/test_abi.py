@@ -26,6 +26,17 @@ def test_library_exports_every_declared_symbol():
     assert bound == set(names)
 
 
+def test_divsufsort_seam_library_exports_the_two_reference_calls():
+    """include/divsufsort_hip.h: the libdivsufsort entry points bce.cpp:901 / :1091 call, under their original names."""
+    src = open(os.path.join(ROOT, "include", "divsufsort_hip.h")).read()
+    assert "saidx_t divbwt(const sauchar_t *T, sauchar_t *U, saidx_t *A, saidx_t n);" in src
+    assert "saint_t inverse_bw_transform(const sauchar_t *T, sauchar_t *U, saidx_t *A, saidx_t n, saidx_t idx);" in src
+    lib = C.CDLL(os.path.join(ROOT, "bce_amd", "lib", "libdivsufsort_hip.so"))
+    assert hasattr(lib, "divbwt") and hasattr(lib, "inverse_bw_transform")
+    lib.divbwt.restype = C.c_int32
+    assert lib.divbwt(None, None, None, 4) == -1           # argument check only: no GPU touched
+
+
 def test_strerror_and_generators_without_gpu():
     lib = bce_amd.load_library()
     assert lib.bce_hip_strerror(0) == b"ok"
