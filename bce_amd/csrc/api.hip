@@ -1,6 +1,7 @@
 // api.hip -- the C ABI of libbcehip.so (include/bce_hip.h): context lifetime, stage entry points and
 // the host-side driver of BCE::encode (bce.cpp:1117-1167).
 #include <new>
+#include <utility>
 
 #include "common.h"
 #include "host_coder.h"
@@ -51,7 +52,15 @@ int flush_symbols(bce_hip_ctx *c, uint64_t nsym) {
     c->coder->wait(&slot.batch);                 // the slot's previous batch must be fully coded (so its copy is done)
     c->stats.t_coder += now_s() - t0;
     account_slot(c, slot);
+    const uint32_t seq0 = c->flush_seq;
     BCE_TRY(k4_flush_async(c, nsym, slot));
+    if (c->flush_seq != seq0) {
+      // the flush runs beside the main stream and reads skey[0] / sesc: the next rounds write the other pair, which
+      // the flush BEFORE this one was the last to read
+      std::swap(c->skey[0], c->skey_alt);
+      std::swap(c->sesc, c->sesc_alt);
+      if (seq0 > 0) BCE_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_k4_done[(seq0 - 1u) & 1u], 0));
+    }
     // BCE_HIP_SYNC_FLUSH=1 (profiling): wait for the copy before queuing more rounds.  rocprofv3's kernel trace
     // serialises the copy stream's blit kernel with the compute stream and charges the 2.4 ms to the K3 kernel behind it.
     if (c->sync_flush) BCE_HIP_TRY(c, hipEventSynchronize(slot.ev_copy));
@@ -100,6 +109,20 @@ static int create_body(bce_hip_ctx **out, int device) {
     return BCE_HIP_E_DEVICE;
   }
   c->sync_flush = getenv("BCE_HIP_SYNC_FLUSH") != nullptr;
+  // (measured on MI355X: K3 and K4 each fill the chip, so running them side by side moves no end-to-end number -- natural
+  //  corpus 114.4 vs 113.8 ms, binary 192 vs 190 -- while the K3 kernels take 14 -> 18 ms on text: off unless asked for)
+  c->overlap = getenv("BCE_HIP_OVERLAP") != nullptr;
+  {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);      // K4 yields to K3 wherever the two compete
+    if (hipStreamCreateWithPriority(&c->k4_stream, hipStreamNonBlocking, least) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_k3_batch, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_k4_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_k4_done[1], hipEventDisableTiming) != hipSuccess) {
+      bce_hip_destroy(c);
+      return BCE_HIP_E_DEVICE;
+    }
+  }
   try { c->coder = new HostCoder(); }
   catch (...) { c->coder = nullptr; }
   if (!c->coder) { bce_hip_destroy(c); return BCE_HIP_E_NOMEM; }
@@ -112,11 +135,12 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->coder) c->coder->drain();
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->k4_stream) (void)hipStreamSynchronize(c->k4_stream);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   DevBuf *bufs[] = {&c->text, &c->bwt, &c->sa[0], &c->sa[1], &c->key[0], &c->key[1], &c->rank, &c->k2, &c->nrk, &c->act[0], &c->act[1],
                     &c->rs_hist, &c->blk, &c->ptmp[0], &c->ptmp[1], &c->gran, &c->nodes, &c->ctl, &c->tilecnt,
                     &c->tileoff, &c->runs, &c->smwords, &c->k3tw, &c->k3grp, &c->truns, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
-                    &c->sesc, &c->stat, &c->dcfg, &c->k4w, &c->scanrec, &c->dfs};
+                    &c->sesc, &c->stat, &c->dcfg, &c->k4w, &c->scanrec, &c->dfs, &c->skey_alt, &c->sesc_alt, &c->rs_hist_k4};
   for (DevBuf *b : bufs) release(*b);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   if (c->h_runs) (void)hipHostFree(c->h_runs);
@@ -128,6 +152,9 @@ void bce_hip_destroy(bce_hip_ctx *c) {
     if (sl.ev_copy) (void)hipEventDestroy(sl.ev_copy);
   }
   if (c->ev_k4) (void)hipEventDestroy(c->ev_k4);
+  if (c->ev_k3_batch) (void)hipEventDestroy(c->ev_k3_batch);
+  for (hipEvent_t e : c->ev_k4_done) if (e) (void)hipEventDestroy(e);
+  if (c->k4_stream) (void)hipStreamDestroy(c->k4_stream);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -178,6 +205,7 @@ int bce_hip_debug_set(bce_hip_ctx *c, int knob, uint32_t value) {
     case 8: c->dbg_local_from = value; break;
     case 9: c->dbg_local_budget = value; break;
     case 10: c->dbg_tail_round = value; break;
+    case 11: c->overlap = value != 0; break;
     case 2: c->dbg_no_tail = value; break;
     case 3: c->dbg_no_skip = value; break;
     default: return BCE_HIP_E_ARG;

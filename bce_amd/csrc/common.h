@@ -67,6 +67,14 @@ struct bce_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;             // device-to-host copies of the model outputs, overlapping the next rounds
+  // K4 (model flushes) on a stream of its own, lowest priority: the next K3 rounds run beside it.  K3 writes its symbol
+  // records into skey[0] / sesc, K4 reads the pair of the flush before (skey_alt / sesc_alt): the two are swapped at
+  // every flush.  Off by default (BCE_HIP_OVERLAP=1 or debug knob 11 switch it on): see bce_hip_create.
+  hipStream_t k4_stream = nullptr;
+  hipEvent_t ev_k3_batch = nullptr;              // the rounds whose symbols a flush takes are done (main stream)
+  hipEvent_t ev_k4_done[2] = {nullptr, nullptr}; // flush f's kernels have read their symbol buffers (k4 stream), f & 1
+  bool overlap = false;
+  uint32_t flush_seq = 0;                        // flushes issued by this context (parity selects ev_k4_done)
   hipEvent_t copy_busy = nullptr;                // last copy out of `sout` (the next K4 must not overwrite it earlier)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_k4 = nullptr;
   char err[256] = {0};
@@ -105,6 +113,7 @@ struct bce_hip_ctx {
   bce::DevBuf truns;                             // run table of the persistent tail kernel [K3_TAIL_MAXROUNDS][8]
   void *h_truns = nullptr;
   bce::DevBuf skey[2], sval[2], sout, sesc;       // K3->K4: symbol keys (skey[0]) + escape words (sesc); sort ping-pong; outputs
+  bce::DevBuf skey_alt, sesc_alt, rs_hist_k4;     // the other pair of symbol buffers (see k4_stream); K4's radix histograms
   uint64_t sym_cap = 0;
   bool scan_mode = false;                        // `bce -s`: K3 emits raw (sym,k,c1,c2,cs) tuples into scanrec
   bce::DevBuf scanrec;
@@ -205,5 +214,8 @@ int k4_flush_async(bce_hip_ctx *c, uint64_t nsym, FlushSlot &slot);   // outputs
 // Result is left in key[res]/val[res]; returns res (0 or 1) through *res.
 int radix_sort_pairs(bce_hip_ctx *c, uint32_t *key[2], uint32_t *val[2], uint32_t n, uint32_t first_bit, uint32_t bits, int *res,
                      uint32_t max_digit_bits = 8);
+int radix_sort_pairs_on(bce_hip_ctx *c, hipStream_t stream, DevBuf &hist, uint32_t *key[2], uint32_t *val[2], uint32_t n,
+                        uint32_t first_bit, uint32_t bits, int *res, uint32_t max_digit_bits = 8);
+bool k4_in_flight(bce_hip_ctx *c);                  // a model flush may still be running beside the main stream
 
 }  // namespace bce

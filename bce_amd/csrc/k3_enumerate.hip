@@ -879,6 +879,10 @@ int k3_begin(bce_hip_ctx *c) {
   c->sym_cap = cap;
   BCE_TRY(ensure(c, c->skey[0], (size_t)cap * 4));
   BCE_TRY(ensure(c, c->sesc, (size_t)cap * 4));
+  if (c->overlap && !c->scan_mode) {                           // the pair K4 reads while K3 fills the other (common.h: k4_stream)
+    BCE_TRY(ensure(c, c->skey_alt, (size_t)cap * 4));
+    BCE_TRY(ensure(c, c->sesc_alt, (size_t)cap * 4));
+  }
   if (c->scan_mode) BCE_TRY(ensure(c, c->scanrec, (size_t)cap * 20));
   // roots: (0, C[i], n - C[i]) with C[i] = zeros(plane (i+7)%8), only where both are non-zero (bce.cpp:1237-1240)
   EnumCtl ctl;
@@ -914,7 +918,10 @@ int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint) {
   // idle blocks per launch (tiles are grid-strided: the size only affects speed).
   uint64_t want = nodes_hint ? (nodes_hint * 2 + K3_TILE - 1) / K3_TILE + 16 : 2048;
   const uint32_t grid = (uint32_t)(want < 2048 ? want : 2048);
-  const bool fused = !c->dbg_no_fused;
+  // The two-launch round's group owners spin on tiles of OTHER blocks, which is only free of stalls while every block of
+  // the grid is resident.  A model flush running beside us (k4_stream) takes CU slots away: those batches use the three
+  // launches (count, scan, write), which wait for nothing.
+  const bool fused = !c->dbg_no_fused && !k4_in_flight(c);
   // k3_count2_kernel's group owners wait for tiles of other blocks: keep every block resident (a block that is not
   // yet running would only start when a running one EXITS, and an owner waiting for it idles until then)
   if (fused && !c->k3_count2_grid) {
@@ -1024,8 +1031,13 @@ int k3_grow_symbols(bce_hip_ctx *c, uint64_t cap) {
   if (cap >= (1ull << 31)) return BCE_HIP_E_OVERFLOW;
   // the buffer is empty (sym_total == 0): nothing to preserve
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (c->k4_stream) BCE_HIP_TRY(c, hipStreamSynchronize(c->k4_stream));    // a flush may still be reading the other pair
   BCE_TRY(ensure(c, c->skey[0], (size_t)cap * 4));
   BCE_TRY(ensure(c, c->sesc, (size_t)cap * 4));
+  if (c->overlap && !c->scan_mode) {
+    BCE_TRY(ensure(c, c->skey_alt, (size_t)cap * 4));
+    BCE_TRY(ensure(c, c->sesc_alt, (size_t)cap * 4));
+  }
   if (c->scan_mode) BCE_TRY(ensure(c, c->scanrec, (size_t)cap * 20));
   c->sym_cap = cap;
   EnumCtl *d = c->ctl.as<EnumCtl>();

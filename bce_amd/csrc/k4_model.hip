@@ -30,7 +30,10 @@
 //   3. (cum, freq, total) go back to the record's ORIGINAL index; the host range coders read them in
 //      stream order.
 // Counter state persists in HBM between flushes, so flushes can be arbitrarily small.
+#include <algorithm>
+
 #include "common.h"
+#include "scan_util.h"
 
 namespace bce {
 
@@ -223,53 +226,64 @@ __global__ __launch_bounds__(K4_T) void k4_long_kernel(K4Args a) {
     uint64_t gbase = (uint64_t)e.x / 64 + 1;
     (void)k4_replay(a, e.x, gbase * 64, runid, k, C, cb, lane, ltm);
     if (k == 2) {
-      // ---- binary slots (every really long run is one): the window's symbols are a 64-bit mask, so the walk
-      // is wave-uniform mask arithmetic -- counts are popcounts, the halving position is "the n-th zero or the
-      // n-th one", found with mbcnt + one ballot.  64 windows' masks/infos are fetched per coalesced load.
+      // ---- binary slots (every really long run is one: 0.5-1.4 M records of a 16 M flush).  Lane = window, 64 windows
+      // (4096 events) per step: with the inclusive prefix sums of the windows' zero / one counts, "the next window in
+      // which a counter reaches 0xFF" is one ballot, so the serial work is per HALVING (one every 128-255 events: a
+      // counter is <= 127 after one), not per window; the windows in between only add.  The exact event inside the
+      // window is "the n-th zero or the n-th one" of its 64-bit mask (mbcnt + one ballot).  ~5x the window-by-window
+      // walk this replaces (0.2 us per window, 4.5 ms for the longest run of a flush). ----
       uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)C, 0), c1 = (uint32_t)__builtin_amdgcn_readlane((int)C, 1);
       uint64_t gb = gbase;
       unsigned long long nbits = gb + lane < nwin ? a.bitsW[gb + lane] : 0ull;
       uint32_t ninfo = gb + lane < nwin ? a.winfo[gb + lane] : 0xFFFFFFFFu;
-      bool running = true;
-      while (running) {
+      for (;;) {
         const unsigned long long cbits = nbits;
         const uint32_t cinfo = ninfo;
         const uint64_t g2 = gb + 64;
         nbits = g2 + lane < nwin ? a.bitsW[g2 + lane] : 0ull;        // next group in flight
         ninfo = g2 + lane < nwin ? a.winfo[g2 + lane] : 0xFFFFFFFFu;
-        uint32_t my_state = 0, my_halt = K4_NOT_LONG;
-        bool mine = false;
-        for (int i = 0; i < 64; ++i) {
-          const uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)cinfo, i);   // uniform index: v_readlane, not ds_bpermute
-          if ((info >> 7) != runid) { running = false; break; }      // also ends at nwin (info = ~0)
-          const uint32_t f = info & 127u;
-          const unsigned long long fm = f >= 64 ? ~0ull : ((1ull << f) - 1ull);
-          const unsigned long long B = (((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(cbits >> 32), i) << 32) |
-                                        (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cbits, i)) & fm;
-          const uint32_t h1 = (uint32_t)__popcll(B), h0 = f - h1;
-          const uint32_t s0 = c0, s1 = c1;
-          uint32_t halt = K4_NO_HALVE;
-          if (c0 + h0 >= 0xFFu || c1 + h1 >= 0xFFu) {
-            const uint32_t pb = __builtin_amdgcn_mbcnt_hi((uint32_t)(B >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)B, 0u));
-            const bool bit = (B >> lane) & 1ull;
-            const bool hit = lane < f && (bit ? (c1 + pb + 1u == 0xFFu) : (c0 + (lane - pb) + 1u == 0xFFu));
-            const uint64_t hm = __ballot(hit);
-            const uint32_t t = (uint32_t)__ffsll((long long)hm) - 1u;
-            const unsigned long long le = (2ull << t) - 1ull;
-            const uint32_t cle1 = (uint32_t)__popcll(B & le), cle0 = t + 1u - cle1;
-            c0 = ((c0 + cle0) >> 1) + (h0 - cle0);                    // halve (bce.cpp:531-533), then the rest
-            c1 = ((c1 + cle1) >> 1) + (h1 - cle1);
-            halt = t;
-          } else {
-            c0 += h0; c1 += h1;
-          }
-          if (lane == (uint32_t)i) { my_state = s0 | (s1 << 8); my_halt = halt; mine = true; }
-          if (f < 64) { running = false; break; }                     // the run ends inside this window
+        const uint64_t vm = __ballot((cinfo >> 7) == runid);          // (also false beyond nwin: info = ~0)
+        const uint32_t nv = ~vm ? (uint32_t)__ffsll((long long)~vm) - 1u : 64u;   // the run's windows of this group: lanes [0, nv)
+        if (nv == 0) break;
+        const bool inrun = lane < nv;
+        const uint32_t f = inrun ? (cinfo & 127u) : 0u;               // 64, except in the window where the run ends
+        const unsigned long long B = cbits & (f >= 64u ? ~0ull : ((1ull << f) - 1ull));
+        const uint32_t h1 = (uint32_t)__popcll(B), h0 = f - h1;
+        const uint32_t I0 = wave_incl_sum(h0), I1 = wave_incl_sum(h1), E0 = I0 - h0, E1 = I1 - h1;
+        uint32_t o0 = 0, o1 = 0;                                      // zeros / ones of this group behind the base state (c0, c1)
+        int last = -1;                                                // window of the latest halving
+        uint32_t st = 0, halt = K4_NO_HALVE;
+        for (;;) {
+          // a counter is <= 127 right after a halving and a window holds 64 events: never two halvings in one window
+          const bool cross = inrun && (int)lane > last && (c0 + I0 - o0 >= 0xFFu || c1 + I1 - o1 >= 0xFFu);
+          const uint64_t m = __ballot(cross);
+          const int i = m ? __ffsll((long long)m) - 1 : 64;
+          if (inrun && (int)lane > last && (int)lane <= i) st = (c0 + E0 - o0) | ((c1 + E1 - o1) << 8);   // state at my window's start
+          if (!m) break;
+          const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)E0, i), e1 = (uint32_t)__builtin_amdgcn_readlane((int)E1, i);
+          const uint32_t s0 = c0 + e0 - o0, s1 = c1 + e1 - o1, fi = (uint32_t)__builtin_amdgcn_readlane((int)f, i);
+          const unsigned long long Bi = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(B >> 32), i) << 32) |
+                                        (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)B, i);
+          const uint32_t pb = __builtin_amdgcn_mbcnt_hi((uint32_t)(Bi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Bi, 0u));
+          const bool bit = (Bi >> lane) & 1ull;
+          const bool hit = lane < fi && (bit ? (s1 + pb + 1u == 0xFFu) : (s0 + (lane - pb) + 1u == 0xFFu));
+          const uint64_t hm = __ballot(hit);                          // != 0: a counter crosses in this window
+          const uint32_t t = (uint32_t)__ffsll((long long)hm) - 1u;
+          const unsigned long long le = (2ull << t) - 1ull;
+          const uint32_t cle1 = (uint32_t)__popcll(Bi & le), cle0 = t + 1u - cle1;
+          c0 = (s0 + cle0) >> 1;                                      // halve (bce.cpp:531-533): the state right behind event t
+          c1 = (s1 + cle1) >> 1;
+          o0 = e0 + cle0; o1 = e1 + cle1;
+          if ((int)lane == i) halt = t;
+          last = i;
         }
-        if (mine) {
-          *reinterpret_cast<uint16_t *>(a.stateW + (gb + lane) * 32) = (uint16_t)my_state;
-          a.haltW[gb + lane] = (uint8_t)my_halt;
+        if (inrun) {
+          *reinterpret_cast<uint16_t *>(a.stateW + (gb + lane) * 32) = (uint16_t)st;
+          a.haltW[gb + lane] = (uint8_t)halt;
         }
+        c0 += (uint32_t)__builtin_amdgcn_readlane((int)I0, (int)nv - 1) - o0;   // the state behind the group's last window
+        c1 += (uint32_t)__builtin_amdgcn_readlane((int)I1, (int)nv - 1) - o1;
+        if (nv < 64u || (uint32_t)__builtin_amdgcn_readlane((int)f, (int)nv - 1) < 64u) break;   // the run ends in this group
         gb += 64;
       }
       if (lane == 0) { ctr[0] = (uint8_t)c0; ctr[1] = (uint8_t)c1; }
@@ -384,18 +398,25 @@ int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
     BCE_HIP_TRY(c, hipHostMalloc((void **)&slot.h_out, cap * 8 + 16, hipHostMallocDefault));
     slot.cap = cap;
   }
+  // the stream the flush runs on: its own (beside the next K3 rounds) or the main one
+  const bool own = c->overlap && c->k4_stream && !c->scan_mode;
+  hipStream_t ks = own ? c->k4_stream : c->stream;
+  if (own) {
+    BCE_HIP_TRY(c, hipEventRecord(c->ev_k3_batch, c->stream));          // the symbols are complete ...
+    BCE_HIP_TRY(c, hipStreamWaitEvent(ks, c->ev_k3_batch, 0));
+  }
   if (!slot.ev_start) BCE_HIP_TRY(c, hipEventCreate(&slot.ev_start));
   // blocking sync: the coder thread that waits for the copy sleeps instead of spinning next to the busy coders
   if (!slot.ev_copy) BCE_HIP_TRY(c, hipEventCreateWithFlags(&slot.ev_copy, hipEventBlockingSync));
-  if (c->copy_busy) BCE_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_busy, 0));   // `sout` is still being copied out
-  BCE_HIP_TRY(c, hipEventRecord(slot.ev_start, c->stream));
+  if (c->copy_busy) BCE_HIP_TRY(c, hipStreamWaitEvent(ks, c->copy_busy, 0));   // `sout` is still being copied out
+  BCE_HIP_TRY(c, hipEventRecord(slot.ev_start, ks));
   uint32_t *key[2] = {c->skey[0].as<uint32_t>(), c->skey[1].as<uint32_t>()};
   uint32_t *val[2] = {c->sval[0].as<uint32_t>(), c->sval[1].as<uint32_t>()};
   uint64_t gb = ((uint64_t)nsym + K4_T - 1) / K4_T;
   const uint32_t grid = (uint32_t)(gb < 8192 ? gb : 8192);
-  hipLaunchKernelGGL(k4_iota_kernel, dim3(grid), dim3(K4_T), 0, c->stream, nsym, val[0]);
+  hipLaunchKernelGGL(k4_iota_kernel, dim3(grid), dim3(K4_T), 0, ks, nsym, val[0]);
   int res = 0;
-  BCE_TRY(radix_sort_pairs(c, key, val, nsym, kSymRunShift, kSymRunBits, &res, 8));
+  BCE_TRY(radix_sort_pairs_on(c, ks, own ? c->rs_hist_k4 : c->rs_hist, key, val, nsym, kSymRunShift, kSymRunBits, &res, 8));
   // per-window work arrays, carved from one buffer: histT | stateW | winfo | queue | haltW | qcount
   const size_t nwin = ((size_t)nsym + 63) / 64;
   auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -418,21 +439,52 @@ int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   a.qcount = reinterpret_cast<uint32_t *>(wbuf + o_qc);
   for (int p = 0; p < 8; ++p) a.stat_off[p] = c->stat_off[p];
   a.nsym = nsym;
-  BCE_HIP_TRY(c, hipMemsetAsync(a.qcount, 0, 16, c->stream));
+  BCE_HIP_TRY(c, hipMemsetAsync(a.qcount, 0, 16, ks));
   uint64_t wb = ((uint64_t)nwin + (K4_T / 64) - 1) / (K4_T / 64);
   const uint32_t sgrid = (uint32_t)(wb < 16384 ? (wb ? wb : 1) : 16384);
-  hipLaunchKernelGGL(k4_window_kernel, dim3(sgrid), dim3(K4_T), 0, c->stream, a);
-  hipLaunchKernelGGL(k4_long_kernel, dim3(1024), dim3(K4_T), 0, c->stream, a);
-  hipLaunchKernelGGL(k4_emit_kernel, dim3(sgrid), dim3(K4_T), 0, c->stream, a);
+  hipLaunchKernelGGL(k4_window_kernel, dim3(sgrid), dim3(K4_T), 0, ks, a);
+  if (getenv("BCE_HIP_K4_DEBUG")) {
+    // the long runs of this flush: how many, how long, which alphabet; and the time of k4_long_kernel alone
+    BCE_HIP_TRY(c, hipStreamSynchronize(ks));
+    uint32_t nq = 0;
+    BCE_HIP_TRY(c, hipMemcpy(&nq, a.qcount, 4, hipMemcpyDeviceToHost));
+    std::vector<uint2> q(nq);
+    std::vector<uint32_t> hk(nsym);
+    if (nq) BCE_HIP_TRY(c, hipMemcpy(q.data(), a.queue, (size_t)nq * 8, hipMemcpyDeviceToHost));
+    BCE_HIP_TRY(c, hipMemcpy(hk.data(), a.keys, (size_t)nsym * 4, hipMemcpyDeviceToHost));
+    std::vector<std::pair<uint32_t, uint32_t>> runs;       // (length, k)
+    uint64_t in_long = 0;
+    for (const uint2 &e : q) {
+      uint32_t len = 0;
+      while (e.x + len < nsym && (hk[e.x + len] >> kSymRunShift) == (e.y >> kSymRunShift)) ++len;
+      runs.push_back({len, key_k(e.y)});
+      in_long += len;
+    }
+    std::sort(runs.rbegin(), runs.rend());
+    const double t0 = now_s();
+    hipLaunchKernelGGL(k4_long_kernel, dim3(1024), dim3(K4_T), 0, ks, a);
+    BCE_HIP_TRY(c, hipStreamSynchronize(ks));
+    fprintf(stderr, "k4 flush: %u records, %u long runs holding %llu records, k4_long %.3f ms; longest:", nsym, nq, (unsigned long long)in_long, (now_s() - t0) * 1e3);
+    for (size_t i = 0; i < runs.size() && i < 6; ++i) fprintf(stderr, " %u (k=%u)", runs[i].first, runs[i].second);
+    fprintf(stderr, "\n");
+  } else
+  hipLaunchKernelGGL(k4_long_kernel, dim3(1024), dim3(K4_T), 0, ks, a);
+  hipLaunchKernelGGL(k4_emit_kernel, dim3(sgrid), dim3(K4_T), 0, ks, a);
   BCE_HIP_TRY(c, hipGetLastError());
   // the copy runs on its own stream so that the next rounds (K3) overlap it
-  BCE_HIP_TRY(c, hipEventRecord(c->ev_k4, c->stream));
+  BCE_HIP_TRY(c, hipEventRecord(c->ev_k4, ks));
+  if (own) { BCE_HIP_TRY(c, hipEventRecord(c->ev_k4_done[c->flush_seq & 1u], ks)); ++c->flush_seq; }   // ... and have been read
   BCE_HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_k4, 0));
   BCE_HIP_TRY(c, hipMemcpyAsync(slot.h_out, c->sout.p, (size_t)nsym * 8, hipMemcpyDeviceToHost, c->copy_stream));
   BCE_HIP_TRY(c, hipEventRecord(slot.ev_copy, c->copy_stream));
   c->copy_busy = slot.ev_copy;
   slot.timed = true;
   return BCE_HIP_OK;
+}
+
+bool k4_in_flight(bce_hip_ctx *c) {
+  if (!c->overlap || !c->k4_stream || c->flush_seq == 0) return false;
+  return hipEventQuery(c->ev_k4_done[(c->flush_seq - 1u) & 1u]) != hipSuccess;
 }
 
 int k4_flush(bce_hip_ctx *c, uint64_t nsym, FlushSlot &slot) {

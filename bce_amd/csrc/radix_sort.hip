@@ -210,12 +210,19 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
 
 int radix_sort_pairs(bce_hip_ctx *c, uint32_t *key[2], uint32_t *val[2], uint32_t n, uint32_t first_bit, uint32_t bits,
                      int *res, uint32_t max_digit_bits) {
+  return radix_sort_pairs_on(c, c->stream, c->rs_hist, key, val, n, first_bit, bits, res, max_digit_bits);
+}
+
+// The same on a stream and with a histogram buffer of the caller's (K4's flushes sort on their own stream while K3's
+// tail sorts its tagged symbols on the main one).
+int radix_sort_pairs_on(bce_hip_ctx *c, hipStream_t stream, DevBuf &hbuf, uint32_t *key[2], uint32_t *val[2], uint32_t n,
+                        uint32_t first_bit, uint32_t bits, int *res, uint32_t max_digit_bits) {
   *res = 0;
   if (n <= 1 || bits == 0) return BCE_HIP_OK;
   if (max_digit_bits < 1 || max_digit_bits > (uint32_t)RS_MAXBITS) max_digit_bits = 8;
   const RsPlan pl = rs_plan(n);
-  BCE_TRY(ensure(c, c->rs_hist, ((size_t)RS_MAXBINS * pl.nb + RS_MAXBINS) * sizeof(uint32_t)));
-  uint32_t *hist = c->rs_hist.as<uint32_t>();
+  BCE_TRY(ensure(c, hbuf, ((size_t)RS_MAXBINS * pl.nb + RS_MAXBINS) * sizeof(uint32_t)));
+  uint32_t *hist = hbuf.as<uint32_t>();
   uint32_t *rowtotal = hist + (size_t)RS_MAXBINS * pl.nb;
   // balanced digits: as few passes as the digit width allows, all of (almost) equal width
   const uint32_t npass = (bits + max_digit_bits - 1) / max_digit_bits;
@@ -226,10 +233,10 @@ int radix_sort_pairs(bce_hip_ctx *c, uint32_t *key[2], uint32_t *val[2], uint32_
     const int nbits = (int)((left + pleft - 1) / pleft);
     const uint32_t shift = first_bit + done;
     const uint32_t nbins = 1u << nbits;
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(pl.nb), dim3(RS_THREADS), 0, c->stream, key[cur], n, pl.per_block, pl.nb,
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(pl.nb), dim3(RS_THREADS), 0, stream, key[cur], n, pl.per_block, pl.nb,
                        (int)shift, nbits, hist);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3(nbins), dim3(RS_THREADS), 0, c->stream, hist, pl.nb, rowtotal);
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(pl.nb), dim3(RS_THREADS), 0, c->stream, key[cur], val[cur],
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(nbins), dim3(RS_THREADS), 0, stream, hist, pl.nb, rowtotal);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(pl.nb), dim3(RS_THREADS), 0, stream, key[cur], val[cur],
                        key[cur ^ 1], val[cur ^ 1], n, pl.per_block, pl.nb, (int)shift, nbits, hist, rowtotal);
     cur ^= 1;
     done += (uint32_t)nbits;

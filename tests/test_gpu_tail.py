@@ -235,6 +235,8 @@ LOCAL_KNOBS = [
     ({8: 64, 10: 17}, "tail-from-round-17"),          # the tail starts while the node count still doubles: lists overflow and spill
     ({8: 64, 10: 19, 9: 5}, "tail-from-round-19-budget-5"),
     ({7: 1}, "no-local"),
+    ({11: 1}, "k4-beside-k3"),                        # model flushes on their own stream: double-buffered symbols, three-launch rounds
+    ({11: 1, 8: 64}, "k4-beside-k3-local"),
 ]
 
 
@@ -249,3 +251,20 @@ def test_local_rounds_give_the_same_archive(which, knobs, name):
     arch, st = _encode_with_knobs(data, knobs)
     assert arch == ref
     assert st["nodes"] == 8 * len(data) - 8
+
+
+def test_model_flushes_beside_the_rounds_with_many_small_flushes():
+    """Knob 11 with a small symbol buffer: dozens of flushes, each running on the K4 stream while the next rounds fill the
+    other pair of symbol buffers (the wide rounds fall back to three launches while a flush is in flight)."""
+    data = oracle.synth_text(17, 3 << 20)
+    ref = oracle.compress(data)
+    ctx = bce_amd.api._Ctx(0)
+    try:
+        ctx.check(ctx.lib.bce_hip_debug_set(ctx.h, 11, 1), "bce_hip_debug_set")
+        for cap in (200000, 1 << 20):
+            rf = bce_amd.RankFile(data, ctx=ctx)
+            arch = bce_amd.BCE(symbol_capacity=cap).encode(rf)
+            assert arch == ref
+            assert bce_amd.stats(rf)["flushes"] >= 3
+    finally:
+        ctx.close()
