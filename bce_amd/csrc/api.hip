@@ -7,7 +7,31 @@
 #include "host_coder.h"
 #include "scan_coder.h"
 
+#include <dlfcn.h>
+
 using namespace bce;
+
+namespace bce {
+namespace {
+struct RoctxApi {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  RoctxApi() {
+    for (const char *lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      void *h = dlopen(lib, RTLD_NOW | RTLD_LOCAL);
+      if (!h) continue;
+      push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (push && pop) return;
+      push = nullptr; pop = nullptr;
+    }
+  }
+};
+const RoctxApi &roctx() { static const RoctxApi api; return api; }
+}  // namespace
+RoctxRange::RoctxRange(const char *name) : on_(roctx().push != nullptr) { if (on_) roctx().push(name); }
+RoctxRange::~RoctxRange() { if (on_) roctx().pop(); }
+}  // namespace bce
 
 namespace {
 
@@ -53,6 +77,7 @@ int flush_symbols(bce_hip_ctx *c, uint64_t nsym) {
     c->stats.t_coder += now_s() - t0;
     account_slot(c, slot);
     const uint32_t seq0 = c->flush_seq;
+    RoctxRange range("bce K4 model flush");
     BCE_TRY(k4_flush_async(c, nsym, slot));
     if (c->flush_seq != seq0) {
       // the flush runs beside the main stream and reads skey[0] / sesc: the next rounds write the other pair, which
@@ -233,6 +258,7 @@ int bce_hip_bwt(bce_hip_ctx *c, uint32_t *offset) {
   BCE_TRY(check_stage(c, 1));
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   const double t0 = now_s();
+  RoctxRange range("bce K1 rotation sort + BWT");
   BCE_TRY(k1_bwt(c));
   c->stats.t_bwt = now_s() - t0;
   c->stage = 2;
@@ -282,6 +308,7 @@ int bce_hip_build_planes(bce_hip_ctx *c, uint32_t zeros[8]) {
   BCE_TRY(check_stage(c, 2));
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   const double t0 = now_s();
+  RoctxRange range("bce K2 planes + rank directory");
   BCE_TRY(k2_build_planes(c));
   c->stats.t_planes = now_s() - t0;
   c->stage = 3;
@@ -407,6 +434,7 @@ static int encode_body(bce_hip_ctx *c) {
         ctl.sym_total = 0;
         bool dfs_done = false;
         BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        RoctxRange range("bce K3 tail (local rounds + walkers)");
         BCE_TRY(k3_dfs_tail(c, ctl, kDfsEnter[dfs_try], &dfs_done));
         BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         BCE_HIP_TRY(c, hipEventSynchronize(c->ev1));
@@ -421,6 +449,7 @@ static int encode_body(bce_hip_ctx *c) {
     }
     const uint32_t first = c->round;
     uint32_t executed = 0;
+    RoctxRange range("bce K3 rounds");
     BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     if ((!c->dbg_no_tail || cur_nodes == 0) && cur_nodes <= K3_TAIL_ENTER) {       // (no node at all, e.g. one byte repeated: only this kernel says "done" then)
       // narrow phase: the persistent single-workgroup kernel loops over rounds on the device

@@ -175,6 +175,18 @@ inline int bce_guarded(bce_hip_ctx *c, F &&body) {
   catch (...) { if (c) snprintf(c->err, sizeof c->err, "unknown exception"); return BCE_HIP_E_INTERNAL; }
 }
 
+// roctx ranges around the kernel families (the reference's M_TIME stage lines, bce.cpp:886-891,974-979,1159-1164, as
+// profiler markers: rocprofv3 --marker-trace shows K1 / K2 / K3 batches / K4 flushes on the host timeline).  The marker
+// library is looked up at run time -- librocprofiler-sdk-roctx.so, else libroctx64.so -- and absent = no-op.
+struct RoctxRange {
+  explicit RoctxRange(const char *name);
+  ~RoctxRange();
+  RoctxRange(const RoctxRange &) = delete;
+  RoctxRange &operator=(const RoctxRange &) = delete;
+ private:
+  bool on_;
+};
+
 inline double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }

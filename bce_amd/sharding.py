@@ -19,12 +19,12 @@ def gather_streams(archive: bytes, dist, device, dst=0):
     xGMI link to the root, so the direct gather uses them concurrently; the payload (~0.2-0.3 x block) is small.
     """
     world, rank = dist.get_world_size(), dist.get_rank()
-    a = torch.frombuffer(bytearray(archive), dtype=torch.uint8).to(device)
+    a = (torch.frombuffer(bytearray(archive), dtype=torch.uint8) if len(archive) else torch.empty(0, dtype=torch.uint8)).to(device)
     sz = torch.tensor([a.numel()], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(sz) for _ in range(world)]
     dist.all_gather(sizes, sz)
     sizes = [int(s.item()) for s in sizes]
-    mx = max(sizes)
+    mx = max(max(sizes), 1)
     pad = torch.zeros(mx, dtype=torch.uint8, device=device)
     pad[:a.numel()] = a
     outs = [torch.empty(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None

@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=48 << 20, help="bytes of the workload the CPU baseline compresses")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the untimed decode-and-compare leg (N=1 only)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (H2D inside) leg")
     ap.add_argument("--no-workloads", action="store_true", help="skip the extra workloads (natural / binary corpus, synth-rand)")
     ap.add_argument("--scan-config", action="store_true",
                     help="BASELINE config 5: run `bce -s` on the input first (untimed), compress with the scanned table")
@@ -284,7 +285,7 @@ def main():
             "counts": {"nodes": st["nodes"], "symbols": st["symbols"], "rounds": st["rounds"], "sort_rounds": st["sort_rounds"], "flushes": st["flushes"]},
             "ms_per_step_per_rank": [round(t / steps * 1e3, 2) for t in per_rank],
         }
-        if n_gpus == 1:
+        if n_gpus == 1 and not args.no_e2e:
             # SURVEY 8d's "file read -> archive bytes ready": the same workload from a (pageable) HOST buffer, H2D inside
             torch.cuda.synchronize()
             t0 = time.perf_counter()

@@ -77,3 +77,64 @@ def test_container_roundtrip_and_errors():
         container.unpack_blocks(b"XXXX" + blob[4:])
     with pytest.raises(ValueError):
         container.unpack_blocks(blob + b"x")
+
+
+def _ragged_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bce_amd import sharding
+    sizes = [0, 1, 70001][:world]
+    mine = np.random.RandomState(100 + rank).randint(0, 256, sizes[rank]).astype(np.uint8).tobytes()
+    for _ in range(2):                                  # twice: the helper keeps no state between steps
+        streams = sharding.gather_streams(mine, dist, torch.device("cpu"))
+    if rank == 0:
+        want = [np.random.RandomState(100 + r).randint(0, 256, sizes[r]).astype(np.uint8).tobytes() for r in range(world)]
+        q.put(streams == want)
+    else:
+        assert streams is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_streams_ragged_sizes_world3():
+    """An empty stream, a one-byte stream and a long one: the padded gather must hand each back exactly."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_through_the_hip_path():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), rehearsed on ONE GPU with
+    the gloo backend: every rank compresses its block on the GPU, rank 0 gathers the HIP archives through
+    sharding.gather_streams -- the code path the nccl backend takes over RCCL -- and packs the container."""
+    import json
+    import subprocess
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--size", "3000000", "--backend", "gloo", "--no-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert len(j["ms_per_step_per_rank"]) == 2 and all(t > 0 for t in j["ms_per_step_per_rank"])
+    assert j["config"]["bytes_per_gpu"] == 3000000
+    # rank 0's block is synth-text seed 1: its archive must be the oracle's
+    import hashlib
+
+    import oracle
+    assert j["archive_sha256"] == hashlib.sha256(oracle.compress(oracle.synth_text(1, 3000000))).hexdigest()

@@ -59,12 +59,10 @@ def main():
                       "16 B/lane rank gathers (uncalibrated width), so the corrected figure is an upper estimate and the raw "
                       "one a lower bound.",
         "collected": "tools/profile.sh: rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace, separate "
-                     "passes, bench.py --steps 1 --warmup 0 --no-cpu",
+                     "passes, bench.py --steps 1 --warmup 0 --no-cpu --no-decode --no-workloads",
     }
     with open(os.path.join(outdir, "%s_k3_traffic.json" % tag), "w") as f:
         json.dump(tj, f, indent=1)
-    for f in glob.glob(os.path.join(outdir, "stats", "**", "*kernel_stats.csv"), recursive=True):
-        shutil.copy(f, os.path.join(outdir, "%s_kernel_stats.csv" % tag))
     print(json.dumps({k: tj[k] for k in ("traffic_bytes_raw", "traffic_bytes_corrected", "algorithmic_bytes")}))
 
 
