@@ -134,6 +134,7 @@ static int create_body(bce_hip_ctx **out, int device) {
     return BCE_HIP_E_DEVICE;
   }
   c->sync_flush = getenv("BCE_HIP_SYNC_FLUSH") != nullptr;
+  if (getenv("BCE_HIP_NO_FUSED")) c->dbg_no_fused = 1;             // three launches per wide round (as debug knob 6)
   // (measured on MI355X: K3 and K4 each fill the chip, so running them side by side moves no end-to-end number -- natural
   //  corpus 114.4 vs 113.8 ms, binary 192 vs 190 -- while the K3 kernels take 14 -> 18 ms on text: off unless asked for)
   c->overlap = getenv("BCE_HIP_OVERLAP") != nullptr;
@@ -419,9 +420,9 @@ static int encode_body(bce_hip_ctx *c) {
   bool have_ctl = false, wide_once = false;
   const uint32_t early_max = 4;                   // early small flushes: 1M, 2M, 4M, 8M records (0..5 measured: +3 % on text, neutral on random data)
   // depth-first tail: first attempt when the live set is small, a second one (if the first ran out of room) when tiny
-  // (first attempt: from 2 M live nodes down the tail starts with workgroup-local rounds, k3_local_kernel; without them
+  // (first attempt: from 1 M live nodes down (512 K .. 8 M measured: 1 M is best on text, source code and executables) the tail starts with workgroup-local rounds, k3_local_kernel; without them
   //  the walkers alone take over at 65 536)
-  uint32_t kDfsEnter[2] = {c->dbg_no_local ? 65536u : (2u << 20), 2048u};
+  uint32_t kDfsEnter[2] = {c->dbg_no_local ? 65536u : (1u << 20), 2048u};
   if (const char *e = getenv("BCE_HIP_DFS_ENTER")) kDfsEnter[0] = (uint32_t)strtoul(e, nullptr, 10);
   int dfs_try = 0;
   for (;;) {

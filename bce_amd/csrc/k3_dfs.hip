@@ -827,12 +827,27 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
 #endif
 constexpr int LB_T = LB_T_VALUE;               // (one wave per workgroup -- LB_T_VALUE 64 -- was measured: 11.4 instead of 4.4 ms for the
                                                //  first pass over the natural corpus)
-constexpr int LB_NPT = LB_T == 64 ? 2 : 3;
-constexpr uint32_t LB_CAP = LB_T == 64 ? 128 : 736;   // nodes per LDS list (<= LB_T * LB_NPT)
-constexpr uint32_t LB_IN = LB_CAP / 2;         // nodes a workgroup starts with
-constexpr uint32_t LB_MIN = LB_T == 64 ? 8 : 48;      // fewer nodes than this: handed back (re-chunked with others, or the walkers)
-constexpr uint32_t LB_SBLK = LB_T == 64 ? 256 : 1024; // tagged-symbol slots a workgroup reserves at a time
-constexpr uint32_t LB_XCAP = LB_T == 64 ? 32 : 96;    // nodes on their way to the walkers, buffered in LDS
+// One node per thread: 63 VGPRs = 7 waves per SIMD.  Measured on the natural corpus (K3 in all): 3 nodes per thread, lists of
+// 736 started half full (115 VGPRs, 4 waves) 25.7 ms; 2 per thread 26.7; 1 per thread, 256-node lists started with 128 /
+// 160 / 192 / 224 / 256 nodes: 25.0 / 22.8 / 22.0 / 21.5 / 22.2; 512 threads x 1: 21.9; 128 threads x 1: 28.7.
+#ifndef LB_NPT_VALUE
+#define LB_NPT_VALUE 1
+#endif
+#ifndef LB_CAP_VALUE
+#define LB_CAP_VALUE (LB_T_VALUE * LB_NPT_VALUE)
+#endif
+#ifndef LB_IN_VALUE
+#define LB_IN_VALUE (LB_CAP_VALUE - LB_CAP_VALUE / 8)
+#endif
+constexpr int LB_NPT = LB_NPT_VALUE;
+constexpr uint32_t LB_CAP = LB_CAP_VALUE;      // nodes per LDS list (<= LB_T * LB_NPT)
+constexpr uint32_t LB_IN = LB_IN_VALUE;        // nodes a workgroup starts with
+#ifndef LB_MIN_VALUE
+#define LB_MIN_VALUE (LB_T_VALUE == 64 ? 8 : 48)
+#endif
+constexpr uint32_t LB_MIN = LB_MIN_VALUE;      // fewer nodes than this: handed back (re-chunked with others, or the walkers)
+constexpr uint32_t LB_SBLK = 256;              // tagged-symbol slots a workgroup reserves at a time (what is left of a block at the end is holes)
+constexpr uint32_t LB_XCAP = 64;               // nodes on their way to the walkers, buffered in LDS
 
 struct LNode { uint32_t s, x0, x1, meta; };    // meta: [2:0] plane, [8:3] pass-through levels in a row (saturating), [31:9] round - round0
 constexpr uint32_t LB_RSH = 9;
@@ -1097,7 +1112,7 @@ __global__ void kd_place_kernel(const uint32_t *__restrict__ tkey, const uint32_
 // far has been flushed), `ctl` is current.  On success the symbol buffer holds the tail's symbols in stream order,
 // run_log holds one run per plane, and *done = true.  On an error (more symbols than the tagged buffer holds, queue
 // full) nothing has been changed and the caller continues with the round-based kernels.
-constexpr uint32_t KD_LOCAL_FROM = 65536;       // live nodes above which the tail starts with workgroup-local rounds
+constexpr uint32_t KD_LOCAL_FROM = 16384;       // live nodes above which the tail starts with workgroup-local rounds
 constexpr uint32_t KD_LOCAL_QUEUE = 16u << 20;  // walker queue / spill queue capacity in that case
 constexpr uint32_t KD_LOCAL_BUDGET = 256;       // rounds per workgroup and pass (BCE_HIP_LOCAL_BUDGET overrides; 1024 measured: 45 instead of 34 ms on the natural corpus)
 int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) {
@@ -1112,12 +1127,14 @@ int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) 
   // tagged symbols: the tail is mostly pass-through, a fraction of the nodes that are left is plenty; if it is
   // not (chains in which every byte codes a symbol or two), the walk is repeated with four times the room
   const uint64_t left = all > ctl.nodes_total ? all - ctl.nodes_total : 0;
-  const uint32_t local_from = c->dbg_local_from ? c->dbg_local_from : KD_LOCAL_FROM;
+  uint32_t local_from = c->dbg_local_from ? c->dbg_local_from : KD_LOCAL_FROM;
+  if (const char *e = getenv("BCE_HIP_LOCAL_FROM")) local_from = (uint32_t)strtoul(e, nullptr, 10);
   const bool local = live > local_from && !c->dbg_no_local;
   uint64_t cap_scale = 1;
 retry:
   // (the bushy part the local rounds take codes more symbols per node than the chains of the deep tail)
-  uint64_t cap64 = (left / (local ? 3 : 8) + (1u << 20)) * cap_scale;
+  // (+ the blocks of LB_SBLK slots the workgroups of the local rounds reserve and leave partly unused)
+  uint64_t cap64 = (left / (local ? 2 : 8) + (1u << 20)) * cap_scale + (local ? (uint64_t)LB_SBLK * 2 * ((live + LB_IN - 1) / LB_IN) : 0);
   if (cap64 < (4u << 20)) cap64 = 4u << 20;
   if (cap64 > (512u << 20)) cap64 = 512u << 20;
   if (cap64 > left + 64) cap64 = left + 64;                  // a node codes at most one symbol

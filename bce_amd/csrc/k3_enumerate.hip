@@ -845,6 +845,8 @@ static uint32_t default_capP(bce_hip_ctx *c, uint32_t n) {
       const uint64_t budget = (uint64_t)((free_b + have) * 0.6);
       const uint64_t fit = budget / (16 * sizeof(Node));
       if (fit > soft) soft = fit;
+      const uint64_t addressable = 0xFFFFFFFFull / sizeof(Node) - 16;       // node_at: 32-bit byte offsets inside one list
+      if (soft > addressable) soft = addressable;
     }
   }
   return (uint32_t)(worst < soft ? worst : soft);

@@ -64,8 +64,8 @@ int bce_hip_debug_set(bce_hip_ctx *ctx, int knob, uint32_t value);
 /* File::File (bce.cpp:842-856): take the n input bytes.  _host copies host->HBM, _device copies
  * HBM->HBM from a device pointer of the same GPU (input already resident). 1 <= n < 2^31.
  * Capacity: device memory is ~45 n bytes for the suffix sort and planes plus the enumeration's node lists, which hold
- * n/2 + 2 nodes per plane (the worst case) whenever 16 such lists fit in 60 % of the free HBM -- n <= ~1.2 * 10^9 on an
- * otherwise idle 288 GB MI355X -- and at least 192 M nodes per plane beyond that.  Text needs ~0.09 n nodes per plane,
+ * n/2 + 2 nodes per plane (the worst case) whenever 16 such lists fit in 60 % of the free HBM and a list stays below 4 GB
+ * (357 M nodes) -- n <= ~7 * 10^8 on an otherwise idle 288 GB MI355X -- and 192 M to 357 M nodes per plane beyond that.  Text needs ~0.09 n nodes per plane,
  * random bytes ~0.3 n: a high-entropy input of more than ~1.3 GB can exceed the lists, and bce_hip_encode then fails
  * with BCE_HIP_E_OVERFLOW after the BWT has been built (never with a wrong archive). */
 int bce_hip_load_host(bce_hip_ctx *ctx, const uint8_t *in, uint32_t n);
