@@ -1114,7 +1114,7 @@ __global__ void kd_place_kernel(const uint32_t *__restrict__ tkey, const uint32_
 // full) nothing has been changed and the caller continues with the round-based kernels.
 constexpr uint32_t KD_LOCAL_FROM = 16384;       // live nodes above which the tail starts with workgroup-local rounds
 constexpr uint32_t KD_LOCAL_QUEUE = 16u << 20;  // walker queue / spill queue capacity in that case
-constexpr uint32_t KD_LOCAL_BUDGET = 256;       // rounds per workgroup and pass (BCE_HIP_LOCAL_BUDGET overrides; 1024 measured: 45 instead of 34 ms on the natural corpus)
+constexpr uint32_t KD_LOCAL_BUDGET = 192;       // rounds per workgroup and pass (BCE_HIP_LOCAL_BUDGET overrides; natural corpus, K3 in all: 96: 23.3 ms, 128: 21.4, 192: 21.2, 256: 21.7, 384: 21.9)
 int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) {
   *done = false;
   if (c->scan_mode || c->dbg_no_dfs) return BCE_HIP_OK;
