@@ -193,7 +193,10 @@ inline double now_s() {
 
 constexpr uint32_t K3_TAIL_CAP = 1024;        // nodes the tail kernel holds in LDS (all 8 planes together)
 constexpr uint32_t K3_SMALL_MAXTILES = 2048;  // tile table of the one-launch round kernel
-constexpr uint32_t K3_SMALL_NODES = 1u << 19;   // rounds up to this many nodes use it
+#ifndef K3_SMALL_NODES_VALUE
+#define K3_SMALL_NODES_VALUE (1u << 19)
+#endif
+constexpr uint32_t K3_SMALL_NODES = K3_SMALL_NODES_VALUE;   // rounds up to this many nodes use it
 constexpr uint32_t K3_TAIL_ENTER = 512;       // the host switches to the tail kernel at or below this many nodes
 constexpr uint32_t K3_TAIL_MAXROUNDS = 65536; // rounds per tail launch (bounded by its run table)
 

@@ -86,7 +86,19 @@ def main():
                     knobs[k] = 1
             if rs.randint(0, 3) == 0:
                 knobs[0] = int(rs.choice([3, 40, 700]))
-        for k in (0, 1, 2, 3, 4, 6):
+        # round 2: the workgroup-local rounds (8 = from how many live nodes, 9 = rounds per pass, 10 = tail entered while the
+        # node count still grows: spills), 7 = without them, 11 = model flushes beside the rounds
+        if rs.randint(0, 2) == 0:
+            knobs[8] = int(rs.choice([16, 64, 300, 5000]))
+            if rs.randint(0, 2):
+                knobs[9] = int(rs.choice([1, 3, 17, 100]))
+            if rs.randint(0, 3) == 0:
+                knobs[10] = int(rs.choice([17, 18, 20, 23]))
+        elif rs.randint(0, 4) == 0:
+            knobs[7] = 1
+        if rs.randint(0, 4) == 0:
+            knobs[11] = 1
+        for k in (0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11):
             ctx.check(ctx.lib.bce_hip_debug_set(ctx.h, k, knobs.get(k, 0)), "bce_hip_debug_set")
         rf = bce_amd.RankFile(raw, ctx=ctx)
         cap = int(rs.choice([0, 0, 0, 700, 20000]))
