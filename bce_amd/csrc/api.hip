@@ -11,6 +11,10 @@
 
 using namespace bce;
 
+#ifndef K3_BATCH_MID
+#define K3_BATCH_MID 8u   // rounds queued per host sync while 1 M < nodes <= 4 M
+#endif
+
 namespace bce {
 namespace {
 struct RoctxApi {
@@ -485,7 +489,7 @@ static int encode_body(bce_hip_ctx *c) {
     } else {
       // wide rounds: sync often (the round dominates); medium rounds: queue many per sync
       wide_once = false;
-      uint32_t batch = cur_nodes > (1u << 20) ? 4u : (cur_nodes > (1u << 14) ? 16u : 64u);
+      uint32_t batch = cur_nodes > (1u << 22) ? 4u : (cur_nodes > (1u << 20) ? K3_BATCH_MID : (cur_nodes > (1u << 14) ? 16u : 64u));
       // ramp-up: the node count doubles per round; once a round or two reach the next early-flush size, stop there so
       // that the coders get their first (small) batches as early as possible
       if (!decaying && have_ctl && c->stats.flushes < early_max) {
