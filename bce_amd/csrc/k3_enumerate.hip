@@ -27,7 +27,9 @@ namespace bce {
 
 // tile -> plane lookup table: tp[p] = first tile of plane p, tp[8] = total tiles; cn[p] = the plane's two list lengths
 // (read once per block: a load from the control block on every tile's path is a dependent L2 round trip)
-__device__ __forceinline__ void tile_prefix(const K3Args &a, uint32_t tp[9], uint32_t (*cn)[2] = nullptr) {
+__device__ __forceinline__ void tile_prefix(const K3Args &a, uint32_t tp[9], uint32_t (*cn)[2] = nullptr, uint32_t *skip = nullptr) {
+  // (the flags ride in the same batch of loads as the counts: the kernel's prologue is one L2 round trip, not two)
+  if (skip) *skip = a.ctl->need_flush | a.ctl->overflow;
   uint32_t acc = 0;
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
@@ -188,6 +190,20 @@ template <bool WRITE, bool SCAN>
 __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t tile_in_plane, uint32_t tile_global,
                                         uint32_t (*lds_cnt)[4][3], uint32_t c0n, uint32_t c1n, uint32_t group_base) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+  // the tile's output offsets do not depend on the classification: their (dependent, L2) loads go out first instead of
+  // after the barrier below -- a round of 1-2 M nodes is ONE tile per block, so every round trip on the tile's path is
+  // per-round fixed cost (~45 us per round in all)
+  uint32_t o0 = 0, o1 = 0;
+  uint64_t os = 0;
+  if (WRITE) {
+    o0 = a.tileoff[(size_t)tile_global * 4 + 0];
+    o1 = a.tileoff[(size_t)tile_global * 4 + 1];
+    os = a.ctl->symbase[p] + a.tileoff[(size_t)tile_global * 4 + 2];
+    if (a.fused) {                                            // two-launch rounds: tile offsets are relative to their group
+      const uint32_t *g = a.goff + (size_t)(group_base + (tile_in_plane >> 8)) * 4;
+      o0 += g[0]; o1 += g[1]; os += g[2];
+    }
+  }
   TileOut t;
   k3_classify<WRITE, SCAN>(a, p, tile_in_plane, c0n, c1n, t);
   uint32_t pre0[K3_NPT], pre1[K3_NPT], pres[K3_NPT];
@@ -213,13 +229,6 @@ __device__ __forceinline__ void k3_tile(const K3Args &a, uint32_t p, uint32_t ti
       a.tilecnt[(size_t)tile_global * 4 + tid] = tt;
     }
   } else {
-    uint32_t o0 = a.tileoff[(size_t)tile_global * 4 + 0];
-    uint32_t o1 = a.tileoff[(size_t)tile_global * 4 + 1];
-    uint64_t os = a.ctl->symbase[p] + a.tileoff[(size_t)tile_global * 4 + 2];
-    if (a.fused) {                                            // two-launch rounds: tile offsets are relative to their group
-      const uint32_t *g = a.goff + (size_t)(group_base + (tile_in_plane >> 8)) * 4;
-      o0 += g[0]; o1 += g[1]; os += g[2];
-    }
     k3_place<SCAN>(a, p, t, pre0, pre1, pres, lds_cnt, o0, o1, os);
   }
   __syncthreads();
@@ -234,11 +243,11 @@ __device__ __forceinline__ uint32_t tile_plane(const uint32_t *tp, uint32_t tile
 
 template <bool WRITE, bool SCAN>
 __global__ __launch_bounds__(K3_T) void k3_tiles_kernel(K3Args a) {
-  __shared__ uint32_t tp[9], gp[9], cn[8][2];
+  __shared__ uint32_t tp[9], gp[9], cn[8][2], s_skip;
   __shared__ uint32_t lds_cnt[K3_NPT][4][3];
-  if (a.ctl->need_flush || a.ctl->overflow) return;
-  if (threadIdx.x == 0) { tile_prefix(a, tp, cn); group_prefix(tp, gp); }
+  if (threadIdx.x == 0) { tile_prefix(a, tp, cn, &s_skip); group_prefix(tp, gp); }
   __syncthreads();
+  if (s_skip) return;
   const uint32_t T = tp[8];
   for (uint32_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
     const uint32_t p = tile_plane(tp, tile);
@@ -343,14 +352,14 @@ __device__ __forceinline__ void st_word(unsigned long long *p, uint64_t v) {
 
 template <bool SCAN>
 __global__ __launch_bounds__(K3_T) void k3_count2_kernel(K3Args a) {
-  __shared__ uint32_t tp[9], gp[9], cn[8][2];
+  __shared__ uint32_t tp[9], gp[9], cn[8][2], s_skip;
   __shared__ uint32_t lds_cnt[K3_NPT][4][3];
   __shared__ uint32_t s_pt[8][3];
   EnumCtl *ctl = a.ctl;
-  if (ctl->need_flush || ctl->overflow) return;
   const uint32_t tid = threadIdx.x;
-  if (tid == 0) { tile_prefix(a, tp, cn); group_prefix(tp, gp); }
+  if (tid == 0) { tile_prefix(a, tp, cn, &s_skip); group_prefix(tp, gp); }
   __syncthreads();
+  if (s_skip) return;
   const uint32_t T = tp[8];
   if (T == 0) {
     // a queued round after the end: what the epilogue would do with nothing -- an empty run-table row and EMPTY
@@ -411,6 +420,46 @@ __global__ __launch_bounds__(K3_T) void k3_count2_kernel(K3Args a) {
       }
       if (tile == T - 1u) {
         // ---- the block of the round's last tile: scan the groups of every plane, then the round's bookkeeping ----
+        if (gp[8] <= (uint32_t)K3_T) {
+          // all groups of all planes in ONE scan (<= 256 groups = 65 536 tiles = 67 M nodes per round): the plane-local
+          // offset is the block-wide prefix minus the prefix at the plane's first group.  (Plane by plane this tail was
+          // eight scans and ~6 us of every round -- a quarter of the count kernel on rounds of 1-2 M nodes.)
+          __shared__ uint64_t sE01[K3_T + 1];
+          __shared__ uint32_t sEs[K3_T + 1];
+          const uint32_t NG = gp[8];
+          const bool ok = tid < NG;
+          uint64_t wa = 0, wb = 0;
+          if (ok) {
+            while (((wa = ld_word(&a.gwa[tid])) >> 38) != epoch) __builtin_amdgcn_s_sleep(1);
+            while (((wb = ld_word(&a.gwb[tid])) >> 38) != epoch) __builtin_amdgcn_s_sleep(1);
+          }
+          const uint64_t v01 = ok ? ((wa & 0x7FFFFu) | (((wa >> 19) & 0x7FFFFu) << 32)) : 0ull;
+          const uint32_t vs = ok ? (uint32_t)(wb & 0x7FFFFu) : 0u;
+          uint64_t t01;
+          uint32_t ts;
+          const uint64_t e01 = block_excl_scan_sum64<K3_T>(v01, &t01);
+          const uint32_t es = block_excl_scan_sum<K3_T>(vs, &ts);
+          sE01[tid] = e01; sEs[tid] = es;
+          if (tid == 0) { sE01[K3_T] = t01; sEs[K3_T] = ts; }
+          __syncthreads();
+          auto at01 = [&](uint32_t g) -> uint64_t { return g < NG ? sE01[g] : sE01[K3_T]; };
+          auto ats = [&](uint32_t g) -> uint32_t { return g < NG ? sEs[g] : sEs[K3_T]; };
+          if (ok) {
+            uint32_t q = 0;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) q += (tid >= gp[k]) ? 1u : 0u;
+            const uint64_t b01 = at01(gp[q]);
+            a.goff[(size_t)tid * 4 + 0] = (uint32_t)e01 - (uint32_t)b01;
+            a.goff[(size_t)tid * 4 + 1] = (uint32_t)(e01 >> 32) - (uint32_t)(b01 >> 32);
+            a.goff[(size_t)tid * 4 + 2] = es - ats(gp[q]);
+          }
+          if (tid < 8) {
+            const uint64_t lo = at01(gp[tid]), hi = at01(gp[tid + 1]);
+            s_pt[tid][0] = (uint32_t)hi - (uint32_t)lo;
+            s_pt[tid][1] = (uint32_t)(hi >> 32) - (uint32_t)(lo >> 32);
+            s_pt[tid][2] = ats(gp[tid + 1]) - ats(gp[tid]);
+          }
+        } else
         for (uint32_t q = 0; q < 8; ++q) {
           uint32_t c0 = 0, c1 = 0, cs = 0;
           for (uint32_t base = gp[q]; base < gp[q + 1]; base += K3_T) {
@@ -443,7 +492,7 @@ __global__ __launch_bounds__(K3_T) void k3_count2_kernel(K3Args a) {
           for (int q = 0; q < 8; ++q) {
             symsum += s_pt[q][2];
             nextn += (uint64_t)s_pt[q][0] + s_pt[q][1];
-            curn += (uint64_t)ctl->cnt[a.par][q][0] + ctl->cnt[a.par][q][1];
+            curn += (uint64_t)cn[q][0] + cn[q][1];
             if ((uint64_t)s_pt[q][0] + s_pt[q][1] > a.capP) ovf = true;
           }
           const uint64_t sym0 = ctl->sym_total;
