@@ -45,7 +45,7 @@ struct EnumCtl {
   uint64_t symbase[8];       // symbol-buffer base of each plane's records in this round
   uint32_t tail_rounds;      // rounds executed by the last k3_tail_kernel launch
   uint32_t small_bail;       // k3_small_kernel: the round (skip_round) does not fit its grid / tile table: run it wide
-  uint32_t sm_ticket;        // k3_small_kernel: next tile to hand out (dynamic order = look-back order)
+  uint32_t sm_ticket;        // (unused: k3_small_kernel took its tiles from this counter; one address takes ~88 atomics per us)
   uint32_t pad2;
 };
 
@@ -194,7 +194,7 @@ inline double now_s() {
 constexpr uint32_t K3_TAIL_CAP = 1024;        // nodes the tail kernel holds in LDS (all 8 planes together)
 constexpr uint32_t K3_SMALL_MAXTILES = 2048;  // tile table of the one-launch round kernel
 #ifndef K3_SMALL_NODES_VALUE
-#define K3_SMALL_NODES_VALUE (1u << 19)
+#define K3_SMALL_NODES_VALUE 2000000u   // (1/2 M: 19.8 ms of K3 on the natural corpus, 1 M: 19.7, 1.5 M: 19.4, 2 M: 19.3; its tile table holds 2048)
 #endif
 constexpr uint32_t K3_SMALL_NODES = K3_SMALL_NODES_VALUE;   // rounds up to this many nodes use it
 constexpr uint32_t K3_TAIL_ENTER = 512;       // the host switches to the tail kernel at or below this many nodes

@@ -536,7 +536,6 @@ template <bool SCAN>
 __global__ __launch_bounds__(K3_T) void k3_small_kernel(K3Args a, unsigned long long *words) {
   __shared__ uint32_t tp[9], cn[8][2];
   __shared__ uint32_t lds_cnt[K3_NPT][4][3];
-  __shared__ uint32_t s_tile;
   __shared__ unsigned long long s_acc[3];
   __shared__ unsigned long long s_tot[8];
   EnumCtl *ctl = a.ctl;
@@ -566,9 +565,11 @@ __global__ __launch_bounds__(K3_T) void k3_small_kernel(K3Args a, unsigned long 
     if (blockIdx.x == 0 && tid == 0) { ctl->skip_round = a.round; ctl->want_syms = M; ctl->need_flush = 1; }
     return;
   }
-  if (tid == 0) s_tile = atomicAdd(&ctl->sm_ticket, 1u);
-  __syncthreads();
-  const uint32_t tile = s_tile;
+  // tile = block index.  (A ticket drawn from one counter made the look-back order independent of the dispatch order, but
+  // one address takes ~88 atomics per us: 2000 tiles = 23 us before anything else happens.  Like k3_count2_kernel this
+  // now relies on workgroups being dispatched in index order per XCD: a block only ever waits for smaller indices, the
+  // smallest index that is not running yet never waits for a block that is not, so a slot always frees up for it.)
+  const uint32_t tile = blockIdx.x;
   const uint64_t epoch = (uint64_t)((a.round + 1u) & 0x7FFFFFFFu);
   if (tile < T) {
     uint32_t p = 0;
@@ -602,12 +603,23 @@ __global__ __launch_bounds__(K3_T) void k3_small_kernel(K3Args a, unsigned long 
                          __HIP_MEMORY_SCOPE_AGENT);
     }
     // look back: all earlier tiles give the symbol offset, those of my plane the child offsets
+    // (all of a thread's words -- at most K3_SMALL_MAXTILES / K3_T = 8 -- are requested together and only the ones that
+    //  are not there yet are polled again: one L2 round trip for the look-back, not one per word)
     uint64_t c0 = 0, c1 = 0, cs = 0;
-    for (uint32_t j = tid; j < tile; j += K3_T) {
-      uint64_t wv;
-      while (((wv = ld_word(&words[j])) >> 33) != epoch) __builtin_amdgcn_s_sleep(1);
-      cs += (wv >> 22) & 0x7FFu;
-      if (j >= tp[p]) { c0 += wv & 0x7FFu; c1 += (wv >> 11) & 0x7FFu; }
+    {
+      constexpr int LB = (int)(K3_SMALL_MAXTILES / K3_T);
+      uint64_t wv[LB];
+#pragma unroll
+      for (int q = 0; q < LB; ++q) { const uint32_t j = tid + (uint32_t)q * K3_T; wv[q] = j < tile ? ld_word(&words[j]) : 0ull; }
+#pragma unroll
+      for (int q = 0; q < LB; ++q) {
+        const uint32_t j = tid + (uint32_t)q * K3_T;
+        if (j < tile) {
+          while ((wv[q] >> 33) != epoch) { __builtin_amdgcn_s_sleep(1); wv[q] = ld_word(&words[j]); }
+          cs += (wv[q] >> 22) & 0x7FFu;
+          if (j >= tp[p]) { c0 += wv[q] & 0x7FFu; c1 += (wv[q] >> 11) & 0x7FFu; }
+        }
+      }
     }
     if (c0) atomicAdd(&s_acc[0], (unsigned long long)c0);
     if (c1) atomicAdd(&s_acc[1], (unsigned long long)c1);
@@ -615,17 +627,25 @@ __global__ __launch_bounds__(K3_T) void k3_small_kernel(K3Args a, unsigned long 
     __syncthreads();
     k3_place<SCAN>(a, p, t, pre0, pre1, pres, lds_cnt, (uint32_t)s_acc[0], (uint32_t)s_acc[1], sym0 + s_acc[2]);
   }
-  // ---- the block with the last ticket folds the round into the control block ----
-  // (every other block has drawn its ticket, hence read everything it reads from the control block)
+  // ---- the last block folds the round into the control block ----
+  // (it waits for every tile's word below, so every block WITH a tile has read what it reads from the control block; the
+  //  blocks without one only read fields this epilogue does not change -- flags, this parity's counts -- or ignore them)
   if (tile != gridDim.x - 1u) return;
-  for (uint32_t j = tid; j < T; j += K3_T) {
-    uint32_t p = 0;
+  {
+    constexpr int LB = (int)(K3_SMALL_MAXTILES / K3_T);
+    uint64_t wv[LB];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) p += (j >= tp[k]) ? 1u : 0u;
-    uint64_t wv;
-    while (((wv = ld_word(&words[j])) >> 33) != epoch) __builtin_amdgcn_s_sleep(1);
-    // per-plane totals fit 21-bit fields: a plane's children / symbols number at most its nodes < 2^21 (checked: M)
-    atomicAdd(&s_tot[p], (unsigned long long)((wv & 0x7FFu) | (((wv >> 11) & 0x7FFu) << 21) | (((wv >> 22) & 0x7FFu) << 42)));
+    for (int q = 0; q < LB; ++q) { const uint32_t j = tid + (uint32_t)q * K3_T; wv[q] = j < T ? ld_word(&words[j]) : 0ull; }
+#pragma unroll
+    for (int q = 0; q < LB; ++q) {
+      const uint32_t j = tid + (uint32_t)q * K3_T;
+      if (j < T) {
+        const uint32_t p = tile_plane(tp, j);
+        while ((wv[q] >> 33) != epoch) { __builtin_amdgcn_s_sleep(1); wv[q] = ld_word(&words[j]); }
+        // per-plane totals fit 21-bit fields: a plane's children / symbols number at most its nodes < 2^21 (checked: M)
+        atomicAdd(&s_tot[p], (unsigned long long)((wv[q] & 0x7FFu) | (((wv[q] >> 11) & 0x7FFu) << 21) | (((wv[q] >> 22) & 0x7FFu) << 42)));
+      }
+    }
   }
   __syncthreads();
   if (tid != 0) return;
@@ -644,7 +664,6 @@ __global__ __launch_bounds__(K3_T) void k3_small_kernel(K3Args a, unsigned long 
   atomicAdd((unsigned long long *)&ctl->nodes_total, (unsigned long long)M);
   ctl->next_nodes = (uint32_t)nextn;
   if (nextn == 0 && ctl->done_round == 0xFFFFFFFFu) ctl->done_round = a.round + 1u;
-  ctl->sm_ticket = 0;
 }
 
 // ------------------------------------------------------------------------------------------------------
