@@ -604,7 +604,8 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   uint64_t nodes = 0, maxround = 0;
   uint32_t visited = 0;
   uint32_t quiet = 8;                                         // pass-through nodes in a row (8 = one whole byte)
-  uint32_t sbase = 0, sused = KD_SBLK;                        // my block of tagged-symbol slots (none yet)
+  constexpr uint32_t SBLK = UNI ? 8u * KD_SBLK : KD_SBLK;     // (a wave-walker waits for the atomic's answer with nothing else to do: fewer, larger blocks)
+  uint32_t sbase = 0, sused = SBLK;                           // my block of tagged-symbol slots (none yet)
   uint32_t seen_err = 0;
   uint32_t skip_next = 0, skip_wait = 64u;                    // chain skip: back-off while it does not pay
   uint32_t stair_next = 0, stair_wait = KD_STAIR_RETRY;       // visited count from which I look for a staircase again; back-off
@@ -748,10 +749,15 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
       const Node nd{cur.s, cur.x0, cur.x1};
       const uint32_t ga = div96(nd.s), gb = div96(nd.s + nd.x0 + nd.x1), gm = div96(nd.s + nd.x0);
       const Granule qa = ldg(ga), qb = ldg(gb);
+      // wave-walker: a node is a chain of dependent loads and nothing else runs in the wave, so the split point's granule
+      // comes with the other two instead of in a round trip of its own when it turns out to be needed
+      Granule qm = UNI ? ldg(gm) : qa;
       NodeFlat nf;
       node_flat_pre(nd, granule_rank1(qa, nd.s - ga * 96u), granule_rank1(qb, nd.s + nd.x0 + nd.x1 - gb * 96u), nf);
-      Granule qm = gm == ga ? qa : qb;
-      if (nf.need_mid && gm != ga && gm != gb) qm = ldg(gm);
+      if (!UNI) {
+        qm = gm == ga ? qa : qb;
+        if (nf.need_mid && gm != ga && gm != gb) qm = ldg(gm);
+      }
       uint32_t has0, has1, sym, kq;
       Node c0, c1;
       node_flat_post(nd, k.zeros[p], nf, granule_rank1(qm, nd.s + nd.x0 - gm * 96u), has0, c0, has1, c1, sym, kq);
@@ -760,9 +766,9 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
       maxround = cur.round > maxround ? cur.round : maxround;
       quiet = (nf.need_mid || (has0 && has1)) ? 0u : quiet + 1u;
       if (nf.need_mid) {
-        if (sused == KD_SBLK) { sbase = uni_add(&a.dctl->nsym, KD_SBLK); sused = 0; }
+        if (sused == SBLK) { sbase = uni_add(&a.dctl->nsym, SBLK); sused = 0; }
         const uint32_t i = sbase + sused;
-        if (sbase + KD_SBLK > a.symcap) { a.dctl->err = 2; alive = false; sused = KD_SBLK; }
+        if (sbase + SBLK > a.symcap) { a.dctl->err = 2; alive = false; sused = SBLK; }
         else {
           ++sused;
           uint32_t kw, ew;
@@ -796,7 +802,7 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   }
   // the unused slots of my last block are holes: they sort behind every real symbol and are cut off by the host
   if (!writer) return;
-  for (uint32_t j = sused; j < KD_SBLK; ++j) { a.ts[sbase + j] = 0; a.trlo[sbase + j] = 0; a.trhi[sbase + j] = KD_HOLE; }
+  for (uint32_t j = sused; j < SBLK; ++j) { a.ts[sbase + j] = 0; a.trlo[sbase + j] = 0; a.trhi[sbase + j] = KD_HOLE; }
   if (a.dbg) atomicMax(&a.dctl->dbg_maxvis, visited);
   if (a.dbg && lane == 0) {
     atomicAdd((unsigned long long *)&a.dctl->dbg_cyc[0], (unsigned long long)(clock64() - cyc0));
@@ -818,34 +824,19 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
 // both list buffers in LDS, one classification per node (no count pass: the compaction is a block scan), no launch
 // and no grid-wide step between rounds.  Symbols are tagged (plane, round, s) like the walkers' and sorted into stream
 // order with theirs.  A workgroup stops after lb_budget rounds or when fewer than LB_MIN nodes are left and hands those
-// to the walkers' queue; a child that arrives at plane 0 after a whole byte of pass-through levels (the start of a
-// chain the walkers can skip) goes there at once.  Children that do not fit the LDS list are spilled to a global
-// queue that another launch of this kernel works off.
+// back through a global queue that the host re-chunks into the next launch of this kernel (or gives to the walkers when
+// few are left); children that do not fit the LDS list go the same way.  A child that arrives at plane 0 after lb_quiet
+// pass-through levels can be sent straight to the walkers (a chain they could skip): off by default, see k3_dfs_tail.
 // ------------------------------------------------------------------------------------------------------
-#ifndef LB_T_VALUE
-#define LB_T_VALUE 256
-#endif
-constexpr int LB_T = LB_T_VALUE;               // (one wave per workgroup -- LB_T_VALUE 64 -- was measured: 11.4 instead of 4.4 ms for the
-                                               //  first pass over the natural corpus)
-// One node per thread: 63 VGPRs = 7 waves per SIMD.  Measured on the natural corpus (K3 in all): 3 nodes per thread, lists of
-// 736 started half full (115 VGPRs, 4 waves) 25.7 ms; 2 per thread 26.7; 1 per thread, 256-node lists started with 128 /
-// 160 / 192 / 224 / 256 nodes: 25.0 / 22.8 / 22.0 / 21.5 / 22.2; 512 threads x 1: 21.9; 128 threads x 1: 28.7.
-#ifndef LB_NPT_VALUE
-#define LB_NPT_VALUE 1
-#endif
-#ifndef LB_CAP_VALUE
-#define LB_CAP_VALUE (LB_T_VALUE * LB_NPT_VALUE)
-#endif
-#ifndef LB_IN_VALUE
-#define LB_IN_VALUE (LB_CAP_VALUE - LB_CAP_VALUE / 8)
-#endif
-constexpr int LB_NPT = LB_NPT_VALUE;
-constexpr uint32_t LB_CAP = LB_CAP_VALUE;      // nodes per LDS list (<= LB_T * LB_NPT)
-constexpr uint32_t LB_IN = LB_IN_VALUE;        // nodes a workgroup starts with
-#ifndef LB_MIN_VALUE
-#define LB_MIN_VALUE (LB_T_VALUE == 64 ? 8 : 48)
-#endif
-constexpr uint32_t LB_MIN = LB_MIN_VALUE;      // fewer nodes than this: handed back (re-chunked with others, or the walkers)
+// Geometry, measured on the natural corpus (K3 in all): ONE node per thread (63 VGPRs = 7 waves per SIMD), 256-node lists
+// started with 128 / 160 / 192 / 224 / 256 nodes: 25.0 / 22.8 / 22.0 / 21.5 / 22.2 ms; three nodes per thread, lists of 736
+// started half full (115 VGPRs, 4 waves): 25.7; two per thread: 26.7; 512 threads x 1: 21.9; 128 threads x 1: 28.7; one wave per
+// workgroup: 11.4 instead of 4.4 ms for the first pass alone.
+constexpr int LB_T = 256;
+constexpr int LB_NPT = 1;                      // nodes per thread and round
+constexpr uint32_t LB_CAP = LB_T * LB_NPT;     // nodes per LDS list
+constexpr uint32_t LB_IN = LB_CAP - LB_CAP / 8;   // nodes a workgroup starts with
+constexpr uint32_t LB_MIN = 48;                // fewer nodes than this: handed back (re-chunked with others, or the walkers; 24: 26.4 ms, 96: 25.0)
 constexpr uint32_t LB_SBLK = 256;              // tagged-symbol slots a workgroup reserves at a time (what is left of a block at the end is holes)
 constexpr uint32_t LB_XCAP = 64;               // nodes on their way to the walkers, buffered in LDS
 
@@ -922,9 +913,6 @@ __global__ __launch_bounds__(LB_T) void k3_local_kernel(DfsArgs a) {
       gm[it] = div96(nd[it].s + nd[it].x0);
       qa[it] = G[ga[it]];
       qb[it] = G[gb[it]];
-#ifdef LB_MID_ALWAYS
-      qm[it] = G[gm[it]];
-#endif
     }
     NodeFlat nf[LB_NPT];
 #pragma unroll
@@ -933,11 +921,9 @@ __global__ __launch_bounds__(LB_T) void k3_local_kernel(DfsArgs a) {
       const Node n3{nd[it].s, nd[it].x0, nd[it].x1};
       node_flat_pre(n3, granule_rank1(qa[it], nd[it].s - ga[it] * 96u),
                     granule_rank1(qb[it], nd[it].s + nd[it].x0 + nd[it].x1 - gb[it] * 96u), nf[it]);
-#ifndef LB_MID_ALWAYS
-      qm[it] = gm[it] == ga[it] ? qa[it] : qb[it];
+      qm[it] = gm[it] == ga[it] ? qa[it] : qb[it];      // (loading it unconditionally with the other two: 4.33 vs 4.44 ms, not worth the registers)
       if (valid[it] && nf[it].need_mid && gm[it] != ga[it] && gm[it] != gb[it])
         qm[it] = (k.gran + (size_t)(nd[it].meta & 7u) * k.ngran)[gm[it]];
-#endif
     }
     uint32_t has0[LB_NPT], has1[LB_NPT], ex0[LB_NPT], ex1[LB_NPT], sym[LB_NPT], kq[LB_NPT], cmeta[LB_NPT];
     Node c0[LB_NPT], c1[LB_NPT];
@@ -1039,13 +1025,9 @@ __global__ __launch_bounds__(LB_T) void k3_local_kernel(DfsArgs a) {
           uint32_t kw, ew;
           pack_symbol(k.cfg[p], p, sym[it], kq[it], nf[it].n0x, nd[it].x1, nd[it].x0 + nd[it].x1, kw, ew);
           const uint64_t r = a.round0 + (uint64_t)(nd[it].meta >> LB_RSH);
-#ifndef LB_NO_SYMSTORE
-          a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = nd[it].s;
+          a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = nd[it].s;      // (five 4-byte stores: without them the pass is as long)
           a.trlo[i] = (uint32_t)r;
           a.trhi[i] = (uint32_t)(r >> 32) | (p << 8);
-#else
-          if (kw == 0xFFFFFFFFu && ew == 0xFFFFFFFFu && r == 12345) a.tkey[i] = kw;
-#endif
           atomicAdd(&s_cntp[p], 1u);
         }
       }

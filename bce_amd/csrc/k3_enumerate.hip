@@ -96,9 +96,7 @@ __device__ __forceinline__ void k3_classify(const K3Args &a, uint32_t p, uint32_
   //  registers cost a wave per SIMD)
   Node nd[K3_NPT];
   k3_load_nodes(a, p, tile_in_plane, c0n, c1n, nd);
-#ifndef K3_NO_SCHEDBAR
   __builtin_amdgcn_sched_barrier(0);            // every node load issued before the first is consumed
-#endif
   const Granule *G = a.gran + (size_t)p * a.ngran;
   const uint32_t zp = a.zeros[p];
   const PlaneCfg &cfg = a.cfg[p];
@@ -116,23 +114,16 @@ __device__ __forceinline__ void k3_classify(const K3Args &a, uint32_t p, uint32_
     gm[it] = div96(nd[it].s + nd[it].x0);
     qa[it] = gran_at(G, ga[it]);
     qb[it] = gran_at(G, gb[it]);
-#ifdef K3_MID_ALWAYS
-    qm[it] = gran_at(G, gm[it]);
-#endif
   }
-#ifndef K3_NO_SCHEDBAR
   __builtin_amdgcn_sched_barrier(0);            // every load above is issued before the first rank below
-#endif
   NodeFlat nf[K3_NPT];
 #pragma unroll
   for (int it = 0; it < K3_NPT; ++it) {
     const uint32_t rs = granule_rank1(qa[it], nd[it].s - ga[it] * 96u);
     const uint32_t re = granule_rank1(qb[it], nd[it].s + nd[it].x0 + nd[it].x1 - gb[it] * 96u);
     node_flat_pre(nd[it], rs, re, nf[it]);
-#ifndef K3_MID_ALWAYS
     qm[it] = gm[it] == ga[it] ? qa[it] : qb[it];
     if (nf[it].need_mid && gm[it] != ga[it] && gm[it] != gb[it]) qm[it] = gran_at(G, gm[it]);
-#endif
   }
 #pragma unroll
   for (int it = 0; it < K3_NPT; ++it) {
