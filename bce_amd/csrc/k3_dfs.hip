@@ -45,7 +45,7 @@ constexpr uint32_t K3_DFS_LANE_PASS = 256;     // ... and one lane-walker (64 of
 
 struct DfsCtl {
   uint32_t nsym;         // tagged symbols emitted
-  uint32_t err;          // 2 symbol capacity, 4 queue capacity
+  uint32_t err;          // 2 symbol capacity, 4 queue capacity, 8 a spine burst did not arrive where it had to (cannot happen)
   uint64_t nodes;        // nodes visited (skipped pass-through nodes included)
   uint64_t maxround;
   uint32_t cntp[8];      // symbols per plane
@@ -57,6 +57,9 @@ struct DfsCtl {
   unsigned long long dbg_slow;   // slowest chain-skip comparison: cycles >> 10 in the high half, x << 20 | min(kk, 2^20 - 1) below
   unsigned long long dbg_maxwave;   // slowest wave: cycles >> 12 of (walk, chain-skip comparisons, staircases), 20 bits each
   uint64_t dbg_cyc[4];   // wave cycles: whole walk, chain-skip comparisons, staircases; [3] = staircase looks
+  uint64_t dbg_gen[4];   // wave-walkers: general-path nodes, their cycles, pass-through-loop nodes, their cycles
+  uint32_t dbg_spine[4]; // spine bursts: tried, done, byte levels, nodes queued
+  uint32_t dbg_why[8];   // why a burst's chain ended: small node, no c-row in A / B / E, full, run ended at once; [6] scans, [7] levels with x1 < 4
 };
 
 struct DNode { uint32_t s, x0, x1, plane; uint64_t round; };
@@ -100,6 +103,7 @@ struct DfsArgs {
   uint32_t lane_budget;  // nodes a LANE-walker classifies per pass (the wave runs as long as its longest walker: keep it short)
   uint32_t lpw;          // lane-walkers per wave (the other lanes only help with the cooperative comparisons)
   uint32_t lb_quiet;     // pass-through levels after which a child arriving at plane 0 is a chain for the walkers
+  uint32_t no_spine;     // debug: no spine bursts
 };
 
 // granule_rank1 with 64-bit masks (fewer scalar instructions)
@@ -547,6 +551,132 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
   return 1;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Spine burst (wave-walkers).  A node of many rows most of which are preceded by the same byte c (the rows inside long
+// runs of zeros of a binary: hundreds of thousands of rows, a few hundred of which leave per byte) is a chain that can
+// neither be skipped nor expanded in closed form, and walking it is 8 dependent nodes per byte, ~1.5 us each, for
+// thousands of bytes.  But the node of the chain one byte further down is known without the eight levels between: the
+// wavelet levels of one byte are a stable LSD sort, so it is rows LF(first c-row) .. LF(last c-row), split at
+// LF(first c-row of the x1 half), and LF(r) = ISA[SA[r] - 1].  While the three boundary rows are themselves preceded
+// by c -- they sit inside runs of c, so for as many bytes as the shortest of the three runs still has -- the next
+// boundary rows are again their images: LEVEL j of the chain is three ISA reads at text positions P - j, all levels at
+// once, one lane each.  Then the 64 lanes walk the eight planes of THEIR level side by side: symbols as usual, the child on
+// c's side is the next plane's chain node, the other child (the rows that leave) is queued for the next pass.
+// Everything is exact: the chain child exists at every plane because it has at least the rows of the byte-level node
+// below it on both sides of the split, which has at least one each; the walked level must end at the next level's node
+// (checked; a mismatch abandons the tail, err 8).
+// ------------------------------------------------------------------------------------------------------
+constexpr uint32_t KD_SPINE_MIN = 64;            // rows from which a wave-walker at plane 0 tries a burst
+constexpr uint32_t KD_SPINE_LEVELS = 64;         // byte levels per burst: one lane each
+struct SpineLds {
+  uint32_t s[KD_SPINE_LEVELS + 1], x0[KD_SPINE_LEVELS + 1], x1[KD_SPINE_LEVELS + 1];   // the chain's node at plane 0, level by level
+  uint32_t c[KD_SPINE_LEVELS];                   // the byte that leads from level i to level i + 1
+  DNode side[8 * KD_SPINE_LEVELS];
+};
+
+// Whole wave, uniform arguments.  Returns the number of byte levels done (0: not a spine, nothing was changed; the node
+// 8 * levels rounds further down is then in `next`), or 0xFFFFFFFF after an error (err is set).
+__device__ __forceinline__ uint32_t spine_burst(const DfsArgs &a, SpineLds *S, uint32_t s, uint32_t x0, uint32_t x1, uint64_t round,
+                                                uint32_t lane, DNode &next) {
+  const K3Args &k = a.k;
+  const uint32_t n = k.n;
+  auto uni = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  auto rdl = [](uint32_t v, int l) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); };
+  const uint64_t lt = (1ull << lane) - 1ull;
+  uint32_t L = 0, cs = s, cx0 = x0, cx1 = x1;
+  if (lane == 0) { S->s[0] = s; S->x0[0] = x0; S->x1[0] = x1; }
+  while (L < KD_SPINE_LEVELS) {
+    const uint32_t x = cx0 + cx1;
+    if (x < KD_SPINE_MIN) { if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_why[0], 1u); break; }
+    if (a.dbg && lane == 0) { atomicAdd(&a.dctl->dbg_why[6], 1u); if (cx1 < 4u) atomicAdd(&a.dctl->dbg_why[7], 1u); }
+    // c: the byte before the middle row of the larger half.  The first c-row of each half and the last c-row of the
+    // node, among 64 rows each.
+    const uint32_t rmid = cx0 >= cx1 ? cs + cx0 / 2u : cs + cx0 + cx1 / 2u;
+    const bool vA = lane < cx0, vB = lane < cx1;
+    const uint32_t pM = a.sa[rmid];
+    const uint32_t pA = vA ? a.sa[cs + lane] : 0u, pB = vB ? a.sa[cs + cx0 + lane] : 0u, pE = vB ? a.sa[cs + x - 1u - lane] : 0u;
+    const uint32_t c = uni(a.text[cyc_back(pM, 1u, n)]);
+    const bool hA = vA && a.text[cyc_back(pA, 1u, n)] == c, hB = vB && a.text[cyc_back(pB, 1u, n)] == c,
+               hE = vB && a.text[cyc_back(pE, 1u, n)] == c;
+    const uint64_t bA = __ballot(hA), bB = __ballot(hB), bE = __ballot(hE);
+    if (!bA || !bB || !bE) { if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_why[!bA ? 1 : !bB ? 2 : 3], 1u); break; }
+    const uint32_t PA = rdl(pA, __ffsll((long long)bA) - 1), PB = rdl(pB, __ffsll((long long)bB) - 1), PE = rdl(pE, __ffsll((long long)bE) - 1);
+    // Step i takes the rows at P - (i-1) to the rows at P - i, the first row, the first row of the second half and the last
+    // row of the node one byte level down, if the three are preceded by the SAME byte T[P - i] (that byte is the level's c;
+    // for i = 1 it is the c of the scan).  Lane j: level L + 1 + j, which needs the bytes of lanes 0..j.
+    const uint32_t room = KD_SPINE_LEVELS - L;
+    const uint32_t qa = cyc_back(PA, lane + 1u, n), qb = cyc_back(PB, lane + 1u, n), qe = cyc_back(PE, lane + 1u, n);
+    const uint32_t ca = a.text[qa];
+    const bool cont = ca == a.text[qb] && ca == a.text[qe];
+    const uint32_t ia = a.isa[qa], ib = a.isa[qb], ie = a.isa[qe] + 1u;
+    const uint64_t stop = __ballot(!cont);                    // lane j set: the rows' images end before level L + 1 + j
+    uint32_t cnt = stop ? (uint32_t)__ffsll((long long)stop) - 1u : 64u;   // (lane 0 always goes on: its byte is the one the scan found)
+    if (cnt == 0) { if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_why[5], 1u); break; }
+    cnt = cnt < room ? cnt : room;
+    if (lane < cnt) { S->c[L + lane] = ca; S->s[L + 1u + lane] = ia; S->x0[L + 1u + lane] = ib - ia; S->x1[L + 1u + lane] = ie - ib; }
+    cs = rdl(ia, (int)cnt - 1); cx0 = rdl(ib, (int)cnt - 1) - cs; cx1 = rdl(ie, (int)cnt - 1) - cs - cx0;
+    L += cnt;
+  }
+  if (L == 0) return 0;
+  __syncthreads();
+  // ---- the eight planes of every level, one lane per level ----
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(&a.dctl->nsym, 8u * L);
+  base = uni(base);
+  if ((uint64_t)base + 8u * L > a.symcap) { a.dctl->err = 2; return 0xFFFFFFFFu; }
+  const bool act = lane < L;
+  Node nd{act ? S->s[lane] : 0u, act ? S->x0[lane] : 1u, act ? S->x1[lane] : 1u};
+  const uint32_t c = act ? S->c[lane] : 0u;
+  uint32_t used = 0, nside = 0;
+#pragma unroll 1
+  for (uint32_t q = 0; q < 8u; ++q) {
+    const Granule *G = k.gran + (size_t)q * k.ngran;
+    const uint32_t ga = div96(nd.s), gb = div96(nd.s + nd.x0 + nd.x1), gm = div96(nd.s + nd.x0);
+    const Granule ua = G[ga], ub = G[gb], um = G[gm];
+    NodeFlat nf;
+    node_flat_pre(nd, granule_rank1(ua, nd.s - ga * 96u), granule_rank1(ub, nd.s + nd.x0 + nd.x1 - gb * 96u), nf);
+    uint32_t has0, has1, sym, kq;
+    Node c0, c1;
+    node_flat_post(nd, k.zeros[q], nf, granule_rank1(um, nd.s + nd.x0 - gm * 96u), has0, c0, has1, c1, sym, kq);
+    const uint64_t rr = round + 8ull * lane + q;
+    const bool emit = act && nf.need_mid;
+    const uint64_t be = __ballot(emit);
+    if (emit) {
+      const uint32_t i = base + used + (uint32_t)__popcll(be & lt);
+      uint32_t kw, ew;
+      pack_symbol(k.cfg[q], q, sym, kq, nf.n0x, nd.x1, nd.x0 + nd.x1, kw, ew);
+      a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = nd.s;
+      a.trlo[i] = (uint32_t)rr;
+      a.trhi[i] = (uint32_t)(rr >> 32) | (q << 8);
+    }
+    if (be && lane == 0) atomicAdd(&a.dctl->cntp[q], (uint32_t)__popcll(be));
+    used += (uint32_t)__popcll(be);
+    const uint32_t bit = (c >> q) & 1u;
+    const bool hside = act && (bit ? has0 : has1);
+    const uint64_t bh = __ballot(hside);
+    if (hside) {
+      const Node sd = bit ? c0 : c1;
+      S->side[nside + (uint32_t)__popcll(bh & lt)] = DNode{sd.s, sd.x0, sd.x1, (q + 1u) & 7u, rr + 1ull};
+    }
+    nside += (uint32_t)__popcll(bh);
+    nd = bit ? c1 : c0;
+  }
+  // the level must have arrived at the next level's node
+  const bool bad = act && (nd.s != S->s[lane + 1u] || nd.x0 != S->x0[lane + 1u] || nd.x1 != S->x1[lane + 1u]);
+  if (__any(bad)) { a.dctl->err = 8; return 0xFFFFFFFFu; }
+  for (uint32_t j = used + lane; j < 8u * L; j += 64u) { a.ts[base + j] = 0; a.trlo[base + j] = 0; a.trhi[base + j] = KD_HOLE; }
+  __syncthreads();
+  if (nside) {
+    uint32_t o = 0;
+    if (lane == 0) o = atomicAdd(&a.dctl->queued, nside);
+    o = uni(o);
+    if (o + nside > a.out_cap) { a.dctl->err = 4; return 0xFFFFFFFFu; }
+    for (uint32_t j = lane; j < nside; j += 64u) a.out[o + j] = S->side[j];
+  }
+  next = DNode{S->s[L], S->x0[L], S->x1[L], 0u, round + 8ull * L};
+  return L;
+}
+
 // One pass of the walkers.  Lane = walker (UNI = false), or WAVE = walker (UNI = true, few walkers left: every value
 // of the walk then depends on blockIdx only, so the compiler keeps it in scalar registers and runs the ~300
 // instructions of a node on the scalar unit instead of issuing them for 64 lanes of which one works; the lanes
@@ -557,6 +687,8 @@ template <bool UNI>
 __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   __shared__ DNode lstack[UNI ? KD_STACK : 1];
   __shared__ StairRegs sregs;
+  __shared__ __attribute__((aligned(8))) uint32_t spine_raw[UNI ? sizeof(SpineLds) / 4 : 1];
+  SpineLds *const spine = reinterpret_cast<SpineLds *>(spine_raw);
   const K3Args &k = a.k;
   const EnumCtl *ctl = k.ctl;
   const uint32_t lane = threadIdx.x & 63u;
@@ -609,6 +741,7 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   uint32_t seen_err = 0;
   uint32_t skip_next = 0, skip_wait = 64u;                    // chain skip: back-off while it does not pay
   uint32_t stair_next = 0, stair_wait = KD_STAIR_RETRY;       // visited count from which I look for a staircase again; back-off
+  uint32_t spine_next = 0, spine_wait = 16u;                  // the same for spine bursts
   auto pop = [&]() {                                          // this subtree is finished: the next pending one
     if (sp) { cur = uni_node(stack[--sp]); quiet = 8; }
     else if (next < a.in_count) { cur = fetch(next); next += W; quiet = 8; }
@@ -617,6 +750,7 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
   // All 64 lanes stay in the loop until every walker of the wave is finished: finished lanes help with the
   // cooperative text comparisons.
   uint64_t cyc_skip = 0, cyc_stair = 0, n_look = 0;
+  uint64_t g_n = 0, g_c = 0, f_n = 0, f_c = 0;
   const uint64_t cyc0 = a.dbg ? clock64() : 0;
   while (__any(alive)) {
     if ((visited & 31u) == 0) seen_err = uni(a.dctl->err);          // a long chain should not wait for this load on every node
@@ -702,6 +836,20 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
       }
       if (c2) cyc_stair += clock64() - c2;
     }
+    // ---- spine burst: a wave-walker at plane 0 on a node of many rows that is neither a skip nor a staircase ----
+    if (UNI && alive && !consumed && a.skip_ok && !a.no_spine && cur.plane == 0 && cur.x0 + cur.x1 >= KD_SPINE_MIN && mykk == 0 && visited >= spine_next) {
+      DNode nx{0u, 1u, 1u, 0u, 0ull};
+      const uint32_t ls = uni(spine_burst(a, spine, cur.s, cur.x0, cur.x1, cur.round, lane, nx));
+      if (a.dbg && writer) { atomicAdd(&a.dctl->dbg_spine[0], 1u); if (ls && ls != 0xFFFFFFFFu) { atomicAdd(&a.dctl->dbg_spine[1], 1u); atomicAdd(&a.dctl->dbg_spine[2], ls); } }
+      if (ls == 0xFFFFFFFFu) alive = false;
+      else if (ls) {
+        cur = uni_node(nx);
+        nodes += 8ull * ls; visited += ls; quiet = 0;
+        maxround = cur.round - 1ull > maxround ? cur.round - 1ull : maxround;
+        spine_wait = 16u;
+        continue;
+      } else { spine_next = visited + spine_wait; spine_wait = spine_wait < 2048u ? spine_wait * 2u : spine_wait; }
+    }
     if (alive && consumed) {
       ++visited;
       if (a.dctl->err) alive = false; else pop();
@@ -720,6 +868,7 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
         // the looks for a skip / a staircase above happen.
         uint32_t s = cur.s, p = cur.plane, steps = 0;
         const uint32_t xx = cur.x0 + cur.x1;
+        const uint64_t tf = a.dbg ? clock64() : 0;
         do {
           // (the rank directory does not change during K3: constant address space + uniform index = scalar loads
           //  through the scalar cache, which a chain that moves a row per byte keeps hitting)
@@ -736,10 +885,12 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
         } while (p != 0);
         cur.s = s; cur.plane = p; cur.round += steps;
         nodes += steps; quiet += steps;
+        if (a.dbg) { f_n += steps; f_c += clock64() - tf; }
         if (steps && p == 0) { visited += steps - 1u; continue; }
         visited += steps;
       }
       const uint32_t p = cur.plane;
+      const uint64_t tg = (UNI && a.dbg) ? clock64() : 0;
       const Granule *G = k.gran + (size_t)p * k.ngran;
       auto ldg = [&](uint32_t g) -> Granule {                 // wave-walker: scalar load (see above)
         if (!UNI) return G[g];
@@ -798,6 +949,7 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
       if (has0) { cur = DNode{c0.s, c0.x0, c0.x1, pn, cur.round + 1}; }
       else if (has1) { cur = DNode{c1.s, c1.x0, c1.x1, pn, cur.round + 1}; }
       else pop();
+      if (UNI && a.dbg) { ++g_n; g_c += clock64() - tg; }
     }
   }
   // the unused slots of my last block are holes: they sort behind every real symbol and are cut off by the host
@@ -809,6 +961,12 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
     atomicAdd((unsigned long long *)&a.dctl->dbg_cyc[1], (unsigned long long)cyc_skip);
     atomicAdd((unsigned long long *)&a.dctl->dbg_cyc[2], (unsigned long long)cyc_stair);
     atomicAdd((unsigned long long *)&a.dctl->dbg_cyc[3], (unsigned long long)n_look);
+    if (UNI) {
+      atomicAdd((unsigned long long *)&a.dctl->dbg_gen[0], (unsigned long long)g_n);
+      atomicAdd((unsigned long long *)&a.dctl->dbg_gen[1], (unsigned long long)g_c);
+      atomicAdd((unsigned long long *)&a.dctl->dbg_gen[2], (unsigned long long)f_n);
+      atomicAdd((unsigned long long *)&a.dctl->dbg_gen[3], (unsigned long long)f_c);
+    }
     const unsigned long long tw = (unsigned long long)(clock64() - cyc0) >> 12, ts = cyc_skip >> 12, tt = cyc_stair >> 12;
     atomicMax(&a.dctl->dbg_maxwave, ((tw & 0xFFFFFull) << 40) | ((ts & 0xFFFFFull) << 20) | (tt & 0xFFFFFull));
   }
@@ -1166,6 +1324,8 @@ retry:
   if (const char *e = getenv("BCE_HIP_DFS_LANE_PASS")) a.lane_budget = (uint32_t)strtoul(e, nullptr, 10);
   if (const char *e = getenv("BCE_HIP_DFS_PASS")) a.budget = (uint32_t)strtoul(e, nullptr, 10);
   a.dbg = getenv("BCE_HIP_DFS_DEBUG") ? 1u : 0u;
+  a.no_spine = getenv("BCE_HIP_NO_SPINE") ? 1u : 0u;
+  static_assert(sizeof(DfsCtl) <= 512, "the carve reserves 512 bytes");
   BCE_HIP_TRY(c, hipMemsetAsync(a.dctl, 0, sizeof(DfsCtl), c->stream));
   DfsCtl h;
   uint32_t count = live, passes = 0, jobs_done = 0;
@@ -1240,6 +1400,11 @@ retry:
       fprintf(stderr, "   slowest wave of this pass: %.2f M cycles, of which chain-skip comparisons %.2f M, staircases %.2f M\n",
               (double)(h.dbg_maxwave >> 40) * 4096e-6, (double)((h.dbg_maxwave >> 20) & 0xFFFFF) * 4096e-6, (double)(h.dbg_maxwave & 0xFFFFF) * 4096e-6);
       BCE_HIP_TRY(c, hipMemsetAsync(&a.dctl->dbg_maxwave, 0, 8, c->stream));
+      if (h.dbg_gen[0] || h.dbg_gen[2])
+        fprintf(stderr, "   wave-walkers so far: %llu general nodes at %.0f cycles each, %llu pass-through-loop nodes at %.0f cycles each\n", (unsigned long long)h.dbg_gen[0],
+                h.dbg_gen[0] ? (double)h.dbg_gen[1] / h.dbg_gen[0] : 0.0, (unsigned long long)h.dbg_gen[2], h.dbg_gen[2] ? (double)h.dbg_gen[3] / h.dbg_gen[2] : 0.0);
+      if (h.dbg_spine[0]) fprintf(stderr, "   spine bursts so far: %u tried, %u done, %u byte levels; ended by: small node %u, no c-row in A %u / B %u / E %u, run over %u; %u scans, %u with x1 < 4\n", h.dbg_spine[0], h.dbg_spine[1], h.dbg_spine[2],
+                                  h.dbg_why[0], h.dbg_why[1], h.dbg_why[2], h.dbg_why[3], h.dbg_why[5], h.dbg_why[6], h.dbg_why[7]);
       fprintf(stderr, "   wave cycles so far: walk %.0f M, chain-skip comparisons %.0f M, staircases %.0f M (%llu looks)\n", h.dbg_cyc[0] * 1e-6,
               h.dbg_cyc[1] * 1e-6, h.dbg_cyc[2] * 1e-6, (unsigned long long)h.dbg_cyc[3]);
       t_pass = now;
