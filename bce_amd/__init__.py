@@ -7,6 +7,6 @@ binding used by tests and bench.py; it mirrors the reference's own interface nam
 There is no CPU fallback: every compute call goes through the HIP library and fails loudly
 when it is missing or when no GPU is present.
 """
-from .api import (BCE, BceError, RankFile, compress, compress_device, decompress, decompress_device,  # noqa: F401
+from .api import (BCE, BceError, ContextPool, RankFile, compress, compress_device, compress_many, decompress, decompress_device,  # noqa: F401
                   library_path, load_library, scan, synth_rand, synth_text, stats)
 from .build import build as build_native  # noqa: F401

@@ -29,7 +29,7 @@ class BceError(RuntimeError):
 
 class Stats(C.Structure):
     _fields_ = [("n", C.c_uint64), ("nodes", C.c_uint64), ("symbols", C.c_uint64), ("rounds", C.c_uint32),
-                ("sort_rounds", C.c_uint32), ("flushes", C.c_uint32), ("reserved", C.c_uint32),
+                ("sort_rounds", C.c_uint32), ("flushes", C.c_uint32), ("spine_levels", C.c_uint32),
                 ("t_load", C.c_double), ("t_bwt", C.c_double), ("t_planes", C.c_double), ("t_enum", C.c_double),
                 ("t_model", C.c_double), ("t_coder", C.c_double), ("t_total", C.c_double),
                 ("k3_ms", C.c_double), ("k3_launches", C.c_double), ("t_coder_busy", C.c_double)]
@@ -47,6 +47,7 @@ SYMBOLS = [
     ("bce_hip_last_error", C.c_char_p, [C.c_void_p]),
     ("bce_hip_set_config", C.c_int, [C.c_void_p, _u8p]),
     ("bce_hip_set_symbol_capacity", C.c_int, [C.c_void_p, C.c_uint64]),
+    ("bce_hip_set_gated", C.c_int, [C.c_void_p, C.c_int]),
     ("bce_hip_set_progress", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bce_hip_debug_set", C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     ("bce_hip_load_host", C.c_int, [C.c_void_p, _u8p, C.c_uint32]),
@@ -294,6 +295,74 @@ def compress_device(device_ptr, n, config=None, device=0, ctx=None):
     finally:
         if own:
             c.close()
+
+
+class ContextPool:
+    """`contexts` gated contexts on one device (bce_hip_set_gated), driven by one host thread each: their GPU phases take
+    turns while the eight coder threads of the context that has just left the GPU finish its last batches, so the step
+    time of a stream of inputs is the GPU phase instead of GPU phase + coding tail.  Buffers are kept between calls."""
+
+    def __init__(self, contexts=2, device=0):
+        self.ctxs = [_Ctx(device) for _ in range(max(1, int(contexts)))]
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+        self.ctxs = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def compress_many(self, inputs, config=None, on_device=False, with_stats=False, symbol_capacity=0):
+        """Independent inputs (files, or the blocks of `bce -cN`) -> their archives, in order; each is the archive
+        `compress` gives for the same input.  `inputs`: buffers, or (device_ptr, n) pairs with on_device=True."""
+        import threading
+        inputs = list(inputs)
+        results = [None] * len(inputs)
+        errors = []
+        ctxs = self.ctxs[:max(1, min(len(self.ctxs), len(inputs)))]
+        lock = threading.Lock()
+        nxt = [0]
+
+        def worker(c):
+            try:
+                c.check(c.lib.bce_hip_set_gated(c.h, 1 if len(ctxs) > 1 else 0), "bce_hip_set_gated")
+                while True:
+                    with lock:
+                        if errors or nxt[0] >= len(inputs):
+                            return
+                        i = nxt[0]
+                        nxt[0] += 1
+                    if on_device:
+                        ptr, n = inputs[i]
+                        rf = RankFile(n=n, device_ptr=ptr, ctx=c)
+                    else:
+                        rf = RankFile(inputs[i], ctx=c)
+                    arch = BCE(config, symbol_capacity).encode(rf)
+                    results[i] = (arch, stats(rf)) if with_stats else arch
+            except Exception as e:  # the other workers stop at their next input
+                with lock:
+                    errors.append(e)
+            finally:
+                c.lib.bce_hip_set_gated(c.h, 0)      # (gives the gate back if this context still holds it)
+
+        threads = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return results
+
+
+def compress_many(inputs, config=None, device=0, contexts=2, on_device=False, with_stats=False, symbol_capacity=0):
+    """ContextPool.compress_many with a pool of its own."""
+    with ContextPool(contexts, device) as pool:
+        return pool.compress_many(inputs, config=config, on_device=on_device, with_stats=with_stats, symbol_capacity=symbol_capacity)
 
 
 def scan(data, device=0):

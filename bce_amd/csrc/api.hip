@@ -1,5 +1,7 @@
 // api.hip -- the C ABI of libbcehip.so (include/bce_hip.h): context lifetime, stage entry points and
 // the host-side driver of BCE::encode (bce.cpp:1117-1167).
+#include <condition_variable>
+#include <mutex>
 #include <new>
 #include <utility>
 
@@ -45,8 +47,44 @@ int check_stage(bce_hip_ctx *c, int need) {
   return BCE_HIP_OK;
 }
 
+// The device gate (bce_hip_set_gated).  A compression is a GPU phase (K1..K4) followed by a host phase in which the
+// coder threads finish the last batches; a second context can use the GPU meanwhile.  Gated contexts of one device
+// hold the gate from load to the end of their GPU phase and hand it over whenever they would wait for their own coder
+// threads, so at any moment ONE of them has kernels of K3 in flight: its single-launch rounds spin on predecessor
+// tiles and count on a grid that is resident as a whole (k3_enumerate.hip), which two contexts side by side would break.
+struct DeviceGate { std::mutex mu; std::condition_variable cv; bool busy = false; };
+DeviceGate &device_gate(int device) {
+  static DeviceGate gates[64];
+  return gates[device >= 0 && device < 64 ? device : 0];
+}
+void gate_acquire(bce_hip_ctx *c) {
+  if (!c->gated || c->gate_held) return;
+  DeviceGate &g = device_gate(c->device);
+  std::unique_lock<std::mutex> lk(g.mu);
+  g.cv.wait(lk, [&] { return !g.busy; });
+  g.busy = true;
+  c->gate_held = true;
+}
+void gate_release(bce_hip_ctx *c) {
+  if (!c->gate_held) return;
+  DeviceGate &g = device_gate(c->device);
+  { std::lock_guard<std::mutex> lk(g.mu); g.busy = false; }
+  c->gate_held = false;
+  g.cv.notify_one();
+}
+// a stage that failed gives the gate back: the caller will not get to the point where encode does
+int gate_on_error(bce_hip_ctx *c, int status) {
+  if (c && status != BCE_HIP_OK) gate_release(c);
+  return status;
+}
+
+int set_input_body(bce_hip_ctx *c, const void *src, uint32_t n, hipMemcpyKind kind);
 int set_input(bce_hip_ctx *c, const void *src, uint32_t n, hipMemcpyKind kind) {
   if (!c || !src || n == 0 || n >= 0x80000000u) return BCE_HIP_E_ARG;   // n < 2^31 (saidx_t, getv: SURVEY section 5)
+  gate_acquire(c);
+  return gate_on_error(c, set_input_body(c, src, n, kind));
+}
+int set_input_body(bce_hip_ctx *c, const void *src, uint32_t n, hipMemcpyKind kind) {
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   const double t0 = now_s();
   BCE_TRY(ensure(c, c->text, n));
@@ -77,7 +115,12 @@ int flush_symbols(bce_hip_ctx *c, uint64_t nsym) {
     FlushSlot &slot = c->slot[c->slot_next];
     c->slot_next = (c->slot_next + 1) % 3;
     double t0 = now_s();
-    c->coder->wait(&slot.batch);                 // the slot's previous batch must be fully coded (so its copy is done)
+    // the slot's previous batch must be fully coded (so its copy is done); a gated context gives the GPU away while it
+    // waits (no round of its own is in flight here: every batch of rounds ends with a sync on the control block)
+    const bool handover = c->gate_held && slot.batch.pending.load() != 0;
+    if (handover) gate_release(c);
+    c->coder->wait(&slot.batch);
+    if (handover) { gate_acquire(c); BCE_HIP_TRY(c, hipSetDevice(c->device)); }
     c->stats.t_coder += now_s() - t0;
     account_slot(c, slot);
     const uint32_t seq0 = c->flush_seq;
@@ -162,6 +205,7 @@ static int create_body(bce_hip_ctx **out, int device) {
 
 void bce_hip_destroy(bce_hip_ctx *c) {
   if (!c) return;
+  gate_release(c);
   (void)hipSetDevice(c->device);
   if (c->coder) c->coder->drain();
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -250,6 +294,13 @@ int bce_hip_set_progress(bce_hip_ctx *c, bce_hip_progress_fn fn, void *user) {
   return BCE_HIP_OK;
 }
 
+int bce_hip_set_gated(bce_hip_ctx *c, int on) {
+  if (!c) return BCE_HIP_E_ARG;
+  if (!on) gate_release(c);
+  c->gated = on != 0;
+  return BCE_HIP_OK;
+}
+
 int bce_hip_set_symbol_capacity(bce_hip_ctx *c, uint64_t records) {
   if (!c || records >= (1ull << 31)) return BCE_HIP_E_ARG;
   c->sym_cap_user = records;
@@ -259,7 +310,9 @@ int bce_hip_set_symbol_capacity(bce_hip_ctx *c, uint64_t records) {
 int bce_hip_load_host(bce_hip_ctx *c, const uint8_t *in, uint32_t n) { return set_input(c, in, n, hipMemcpyHostToDevice); }
 int bce_hip_load_device(bce_hip_ctx *c, const void *d_in, uint32_t n) { return set_input(c, d_in, n, hipMemcpyDeviceToDevice); }
 
-int bce_hip_bwt(bce_hip_ctx *c, uint32_t *offset) {
+static int bwt_body(bce_hip_ctx *c, uint32_t *offset);
+int bce_hip_bwt(bce_hip_ctx *c, uint32_t *offset) { return gate_on_error(c, bwt_body(c, offset)); }
+static int bwt_body(bce_hip_ctx *c, uint32_t *offset) {
   BCE_TRY(check_stage(c, 1));
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   const double t0 = now_s();
@@ -309,7 +362,9 @@ int bce_hip_inverse_bwt(bce_hip_ctx *c, const uint8_t *in, uint8_t *out, uint32_
   });
 }
 
-int bce_hip_build_planes(bce_hip_ctx *c, uint32_t zeros[8]) {
+static int planes_body(bce_hip_ctx *c, uint32_t zeros[8]);
+int bce_hip_build_planes(bce_hip_ctx *c, uint32_t zeros[8]) { return gate_on_error(c, planes_body(c, zeros)); }
+static int planes_body(bce_hip_ctx *c, uint32_t zeros[8]) {
   BCE_TRY(check_stage(c, 2));
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   const double t0 = now_s();
@@ -405,7 +460,7 @@ int bce_hip_enum_model(bce_hip_ctx *c, uint32_t *out, uint64_t cap_records, uint
 
 // ---- BCE::encode ------------------------------------------------------------------------------------
 static int encode_body(bce_hip_ctx *c);
-int bce_hip_encode(bce_hip_ctx *c) { return bce_guarded(c, [&] { return encode_body(c); }); }
+int bce_hip_encode(bce_hip_ctx *c) { return gate_on_error(c, bce_guarded(c, [&] { return encode_body(c); })); }
 static int encode_body(bce_hip_ctx *c) {
   BCE_TRY(check_stage(c, 3));
   BCE_HIP_TRY(c, hipSetDevice(c->device));
@@ -537,6 +592,7 @@ static int encode_body(bce_hip_ctx *c) {
       ctl.sym_total = 0;                         // the host copy is consulted again at the top of the loop
     }
   }
+  gate_release(c);                               // the GPU phase is over (the last flush and its copy are queued): next context
   {
     const double tw = now_s();
     c->coder->drain();                           // coding of the last batches (the exposed part)
@@ -559,7 +615,9 @@ static int encode_body(bce_hip_ctx *c) {
 // the host in stream order, then pick the context bits.
 static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes);
 int bce_hip_scan(bce_hip_ctx *c, uint8_t config288[BCE_HIP_CONFIG_BYTES], double result_bytes[9]) {
-  return bce_guarded(c, [&] { return scan_body(c, config288, result_bytes); });
+  const int r = bce_guarded(c, [&] { return scan_body(c, config288, result_bytes); });
+  if (c) gate_release(c);                        // (-s keeps the gate to its end: its host part is short)
+  return r;
 }
 static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes) {
   BCE_TRY(check_stage(c, 3));

@@ -74,6 +74,8 @@ struct bce_hip_ctx {
   hipEvent_t ev_k3_batch = nullptr;              // the rounds whose symbols a flush takes are done (main stream)
   hipEvent_t ev_k4_done[2] = {nullptr, nullptr}; // flush f's kernels have read their symbol buffers (k4 stream), f & 1
   bool overlap = false;
+  bool gated = false;                            // bce_hip_set_gated: GPU stages of gated contexts of one device take turns
+  bool gate_held = false;
   uint32_t flush_seq = 0;                        // flushes issued by this context (parity selects ev_k4_done)
   hipEvent_t copy_busy = nullptr;                // last copy out of `sout` (the next K4 must not overwrite it earlier)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_k4 = nullptr;

@@ -51,7 +51,8 @@ struct DfsCtl {
   uint32_t cntp[8];      // symbols per plane
   uint32_t queued;       // nodes handed to the next pass
   uint32_t spilled;      // k3_local_kernel: children that did not fit a workgroup's LDS list (worked off by another local pass)
-  uint32_t njobs, pad2;  // staircase jobs queued so far
+  uint32_t njobs;        // staircase jobs queued so far
+  uint32_t spine_levels; // byte levels done by spine bursts
   uint32_t dbg_hist[32]; uint32_t dbg_maxvis; uint32_t dbg_skips; uint64_t dbg_skipbytes;
   uint32_t dbg_stairs, dbg_stairsyms;
   unsigned long long dbg_slow;   // slowest chain-skip comparison: cycles >> 10 in the high half, x << 20 | min(kk, 2^20 - 1) below
@@ -673,6 +674,7 @@ __device__ __forceinline__ uint32_t spine_burst(const DfsArgs &a, SpineLds *S, u
     if (o + nside > a.out_cap) { a.dctl->err = 4; return 0xFFFFFFFFu; }
     for (uint32_t j = lane; j < nside; j += 64u) a.out[o + j] = S->side[j];
   }
+  if (lane == 0) atomicAdd(&a.dctl->spine_levels, L);
   next = DNode{S->s[L], S->x0[L], S->x1[L], 0u, round + 8ull * L};
   return L;
 }
@@ -1454,6 +1456,7 @@ retry:
   BCE_HIP_TRY(c, hipMemcpyAsync(&d->nodes_total, &nodes, 8, hipMemcpyHostToDevice, c->stream));
   BCE_HIP_TRY(c, hipMemcpyAsync(&d->done_round, &done_round, 4, hipMemcpyHostToDevice, c->stream));
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stats.spine_levels = h.spine_levels;
   for (int p = 0; p < 8; ++p) c->run_log[p].clear();
   uint64_t start = 0;
   for (int p = 0; p < 8; ++p) {

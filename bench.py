@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--file", default=os.environ.get("BCE_BENCH_FILE"))
     ap.add_argument("--cpu-sample", type=int, default=48 << 20, help="bytes of the workload the CPU baseline compresses")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-stream", action="store_true", help="skip the two-context stream leg (N=1 only)")
+    ap.add_argument("--stream-contexts", type=int, default=2, help="contexts of the stream leg")
+    ap.add_argument("--stream-steps", type=int, default=0, help="inputs of the stream leg (default: max(4, --steps))")
     ap.add_argument("--no-decode", action="store_true", help="skip the untimed decode-and-compare leg (N=1 only)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (H2D inside) leg")
     ap.add_argument("--no-workloads", action="store_true", help="skip the extra workloads (natural / binary corpus, synth-rand)")
@@ -295,6 +298,23 @@ def main():
             out["value_end_to_end"] = {"value": round(n / te / 1e6, 3), "unit": "MB/s", "ms_per_step": round(te * 1e3, 2),
                                        "identical_to_headline": bool(bytes(a2) == bytes(arch)),
                                        "note": "host buffer -> archive bytes on the host: the H2D copy of the input is inside the timed region (PCIe); not `value`"}
+        if n_gpus == 1 and not args.no_stream:
+            # A STREAM of such inputs (files, the blocks of `bce -cN`): two gated contexts take turns on the GPU, the coding
+            # tail of one overlaps the kernels of the other (bce_amd.compress_many).  Same input, same archive, every step.
+            ks = args.stream_steps or max(4, args.steps)
+            nctx = max(1, args.stream_contexts)
+            with bce_amd.ContextPool(nctx, 0) as pool:
+                pool.compress_many([(t_in.data_ptr(), n)] * nctx, config=config, on_device=True)     # warm-up: one input per context
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = pool.compress_many([(t_in.data_ptr(), n)] * ks, config=config, on_device=True, with_stats=True)
+                ts = time.perf_counter() - t0
+            out["value_stream"] = {"value": round(n * ks / ts / 1e6, 3), "unit": "MB/s", "steps": ks, "ms_per_step": round(ts / ks * 1e3, 2), "contexts": nctx,
+                                   "identical_to_headline": bool(all(bytes(a) == bytes(arch) for a, _ in res)),
+                                   "k3_ms_per_step": round(sum(s_["t_enum"] for _, s_ in res) / ks * 1e3, 3),
+                                   "coder_busy_ms": round(max(s_["t_coder_busy"] for _, s_ in res) * 1e3, 1),
+                                   "note": "throughput of a stream of inputs on one GPU: gated contexts take turns, the coding tail of one overlaps the "
+                                           "kernels of the other; `value` stays the one-input-at-a-time figure"}
         if n_gpus == 1 and not args.no_decode and n <= 1_000_000_000:
             # untimed: the archive of the last step through the GPU-assisted decoder (`bce -d`), compared with the input
             t0 = time.perf_counter()

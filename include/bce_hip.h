@@ -43,6 +43,15 @@ const char *bce_hip_last_error(const bce_hip_ctx *ctx);
 /* AdaptiveCoder<31>::load_config (bce.cpp:626-641): 9 rows x 32 context-bit counts.  NULL restores
  * the built-in defaults (bce.cpp:713-724). */
 int bce_hip_set_config(bce_hip_ctx *ctx, const uint8_t *config288);
+/* Several contexts on ONE device (a stream of files or blocks, `bce -cN` with more blocks than GPUs): a compression is a
+ * GPU phase (load .. the last model flush) followed by a host phase in which the eight coder threads finish the last
+ * batches, so two contexts driven by two host threads overlap one's coding with the other's kernels.  Gated contexts
+ * (on != 0) of a device take turns on the GPU: the gate is taken in bce_hip_load_* and given back by bce_hip_encode
+ * when its last flush is queued, by any stage that fails, by bce_hip_scan and by bce_hip_destroy; while a gated
+ * context waits for its own coder threads it lends the gate to the next one.  A gated context that is loaded must
+ * therefore be taken through bce_hip_encode (or destroyed, or un-gated with on = 0) before another gated context of the same
+ * device can load.  Ungated contexts (default) ignore the gate; do not run them beside gated ones on the same device. */
+int bce_hip_set_gated(bce_hip_ctx *ctx, int on);
 /* capacity (in symbol records) of the device symbol buffer between model flushes; 0 = automatic */
 int bce_hip_set_symbol_capacity(bce_hip_ctx *ctx, uint64_t records);
 
@@ -151,7 +160,7 @@ typedef struct bce_hip_stats {
   uint32_t rounds;       /* rounds of BCE::code */
   uint32_t sort_rounds;  /* prefix-doubling rounds of K1 */
   uint32_t flushes;      /* K4 model flushes */
-  uint32_t reserved;
+  uint32_t spine_levels; /* byte levels of the enumeration's tail done by spine bursts (k3_dfs.hip) */
   /* t_load, t_bwt, t_planes, t_total: host wall seconds.  t_enum, t_model: GPU seconds (HIP events) of K3 and of
    * K4 + device-to-host copies.  t_coder: host seconds spent waiting for the coder threads (the part of the range
    * coding that nothing hides).  The last three overlap, so they do not add up to t_total. */

@@ -1,0 +1,80 @@
+"""GPU: a stream of inputs through several gated contexts on one device (bce_hip_set_gated, bce_amd.compress_many).
+Every archive must be the oracle's for its input, whatever the interleaving; a context that fails must not leave the
+others waiting for the gate."""
+import numpy as np
+import pytest
+
+import bce_amd
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs():
+    rng = np.random.RandomState(11)
+    zeros = b"".join(rng.bytes(int(rng.randint(1, 30))) + bytes(int(rng.randint(1, 2000))) for _ in range(400))
+    return [oracle.synth_text(3, 300001), oracle.synth_rand(4, 70000), zeros, b"a", oracle.synth_text(9, 1 << 20),
+            bytes(5000) + b"\x01", oracle.synth_text(3, 300001), b"abcabcabcabd" * 3000]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("contexts", [1, 2, 3])
+def test_compress_many_gives_the_oracles_archives(contexts):
+    ins = _inputs()
+    got = bce_amd.compress_many(ins, contexts=contexts)
+    assert len(got) == len(ins)
+    for data, arch in zip(ins, got):
+        assert bytes(arch) == oracle.compress(data)
+
+
+@pytest.mark.timeout(600)
+def test_gated_contexts_hand_the_gpu_over_while_they_wait_for_their_coders():
+    # a tiny symbol buffer: dozens of flushes per input over three slots, so every context waits for its coder threads
+    # in the middle of its GPU phase (flush_symbols lends the gate to the other context there)
+    ins = [oracle.synth_text(20 + i, 400000 + 1000 * i) for i in range(6)]
+    got = bce_amd.compress_many(ins, contexts=2, symbol_capacity=20000)
+    for data, arch in zip(ins, got):
+        assert bytes(arch) == oracle.compress(data)
+
+
+@pytest.mark.timeout(300)
+def test_a_failing_context_gives_the_gate_back():
+    bad = bytes([9]) * bce_amd.api.CONFIG_BYTES                   # context bits > 5: bce_hip_set_config refuses, after load + K1 + K2
+    ins = [oracle.synth_text(1, 200000)] * 4
+    with pytest.raises(bce_amd.BceError):
+        bce_amd.compress_many(ins, config=bad, contexts=2)
+    # the device's gate is free again: a fresh stream runs
+    got = bce_amd.compress_many(ins[:2], contexts=2)
+    assert bytes(got[0]) == oracle.compress(ins[0]) and bytes(got[1]) == bytes(got[0])
+
+
+@pytest.mark.timeout(300)
+def test_gate_by_hand_two_contexts_one_thread_each():
+    """The C ABI itself: load takes the gate, encode gives it back."""
+    import ctypes as C
+    import threading
+    lib = bce_amd.load_library()
+    data = [np.frombuffer(oracle.synth_text(40 + i, 250000), dtype=np.uint8) for i in range(2)]
+    out = [None, None]
+
+    def run(i):
+        h = C.c_void_p()
+        assert lib.bce_hip_create(C.byref(h), 0) == 0
+        try:
+            assert lib.bce_hip_set_gated(h, 1) == 0
+            for _ in range(3):
+                cap = len(data[i]) + 4096
+                buf = (C.c_uint8 * cap)()
+                ln = C.c_size_t()
+                assert lib.bce_hip_compress(h, data[i].ctypes.data, len(data[i]), buf, cap, C.byref(ln)) == 0
+                out[i] = bytes(buf[:ln.value])
+        finally:
+            lib.bce_hip_destroy(h)
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(2):
+        assert out[i] == oracle.compress(data[i].tobytes())

@@ -268,3 +268,54 @@ def test_model_flushes_beside_the_rounds_with_many_small_flushes():
             assert bce_amd.stats(rf)["flushes"] >= 3
     finally:
         ctx.close()
+
+
+# ---- spine bursts (k3_dfs.hip): chains of many rows that lose a few rows per byte ---------------------------------------
+def _spine_input(kind, seed=5):
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    text = oracle.synth_text(70 + seed, 120000)
+    if kind == "zero-runs":            # runs of zeros of hundreds of different lengths between random bytes: the all-zero context keeps
+        parts = []                     # thousands of rows for thousands of bytes, a few runs end at every length
+        for _ in range(1500):
+            parts.append(rng.bytes(int(rng.randint(1, 24))))
+            parts.append(bytes(int(rng.randint(1, 3000))))
+        return text[:60000] + b"".join(parts) + text[60000:]
+    if kind == "equal-runs":           # hundreds of runs of the SAME length: the first rows of the chain all leave at once
+        return text[:50000] + b"".join(rng.bytes(3) + bytes(2048) for _ in range(300)) + text[50000:] + b"".join(
+            rng.bytes(5) + bytes(int(rng.randint(1500, 2500))) for _ in range(200))
+    if kind == "u16-ramps":            # little-endian 16-bit arrays with small values: the context alternates between two bytes
+        arrs = [np.minimum(rng.geometric(0.2, int(rng.randint(200, 4000))), 200).astype("<u2").tobytes() for _ in range(300)]
+        return text[:30000] + b"".join(a + rng.bytes(2) for a in arrs) + text[30000:]
+    if kind == "records":              # records of 12 bytes whose last 9 are constant, in tables of many lengths
+        recs = [b"".join(rng.bytes(3) + b"\x00\x00\x00\x01\x00\x00\x00\xff\x10" for _ in range(int(rng.randint(50, 1500)))) for _ in range(200)]
+        return text[:40000] + b"".join(r + rng.bytes(int(rng.randint(1, 9))) for r in recs) + text[40000:]
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["zero-runs", "equal-runs", "u16-ramps", "records"])
+def test_spine_bursts_match_oracle(kind, monkeypatch):
+    data = _spine_input(kind)
+    ref = oracle.compress(data)
+    arch, st = _encode_with_knobs(data, {})
+    assert arch == ref
+    monkeypatch.setenv("BCE_HIP_NO_SPINE", "1")
+    arch2, st2 = _encode_with_knobs(data, {})
+    assert arch2 == ref and st2["spine_levels"] == 0
+    assert st["nodes"] == st2["nodes"] and st["rounds"] == st2["rounds"] and st["symbols"] == st2["symbols"]
+
+
+def test_spine_bursts_are_taken():
+    """The bursts must actually run on the input they were made for (the walkers alone give the same archive, slowly)."""
+    data = _spine_input("zero-runs", seed=8)
+    arch, st = _encode_with_knobs(data, {})
+    assert arch == oracle.compress(data)
+    assert st["spine_levels"] >= 500, st
+
+
+@pytest.mark.parametrize("budget", [3, 50])
+def test_spine_bursts_with_tiny_walker_budgets(budget):
+    """Knob 0: walkers hand their work on every few nodes, so bursts start and end at arbitrary levels and passes."""
+    data = _spine_input("zero-runs", seed=9)[:900000]
+    arch, st = _encode_with_knobs(data, {0: budget})
+    assert arch == oracle.compress(data)

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out
 [ -f /tmp/bin.bin ] || python3 $ROOT/tools/make_binary_corpus.py --out /tmp/bin.bin --size 100000000 2>/dev/null
 for w in nat bin text; do
   if [ $w = text ]; then F=""; else F="--file /tmp/$w.bin"; fi
-  BCE_HIP_DFS_DEBUG=1 timeout -k 10 200 python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-decode --no-workloads --no-e2e $F "$@" > $OUT/b_${TAG}_$w.log 2>&1
+  BCE_HIP_DFS_DEBUG=1 timeout -k 10 200 python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-decode --no-workloads --no-e2e --no-stream $F "$@" > $OUT/b_${TAG}_$w.log 2>&1
   echo "== $w"; grep -E "^local pass|^dfs pass|^dfs:" $OUT/b_${TAG}_$w.log | tail -14 | cut -c1-230
   grep '^{' $OUT/b_${TAG}_$w.log | python3 -c "
 import json,sys

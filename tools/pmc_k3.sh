@@ -12,7 +12,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o run -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-decode --no-workloads --no-e2e "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o run -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu --no-decode --no-workloads --no-e2e --no-stream "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 - $OUT <<'P'
 import csv,glob,sys,re,collections,json
