@@ -311,8 +311,7 @@ static int k1_sort_rotations(bce_hip_ctx *c, const uint8_t *T, uint32_t n, bool 
                        blockmax, scalars);
     hipLaunchKernelGGL(k1_apply_kernel, dim3(pl.nb), dim3(K1_T), 0, c->stream, nrk, blockmax, n, pl.per_block, sa,
                        rank);
-    BCE_HIP_TRY(c, hipMemcpyAsync(&groups, scalars, 4, hipMemcpyDeviceToHost, c->stream));
-    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    BCE_TRY(read_back(c, &groups, scalars, 4));
     return BCE_HIP_OK;
   };
   BCE_TRY(rerank(key[res], nullptr, val[res]));
@@ -329,11 +328,13 @@ static int k1_sort_rotations(bce_hip_ctx *c, const uint8_t *T, uint32_t n, bool 
                        blockmax, out, scalars + 2);
     hipLaunchKernelGGL(k1_active_kernel<1>, dim3(ap.nb), dim3(K1_T), 0, c->stream, nrk_in, src, cnt, ap.per_block, ap.nb,
                        blockmax, out, scalars + 2);
-    BCE_HIP_TRY(c, hipMemcpyAsync(&m, scalars + 2, 4, hipMemcpyDeviceToHost, c->stream));
-    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    BCE_TRY(read_back(c, &m, scalars + 2, 4));
     return BCE_HIP_OK;
   };
+  const bool trace = getenv("BCE_K1_TRACE") != nullptr;
+  if (trace) fprintf(stderr, "k1 %p: start n %u groups %u\n", (void *)c, n, groups);
   while (groups < n && h < n) {
+    if (trace) fprintf(stderr, "k1 %p: h %llu groups %u m %u list %d\n", (void *)c, (unsigned long long)h, groups, m, (int)have_list);
     if (!have_list && (uint64_t)(n - groups) * 10 < (uint64_t)n * K1_ACT_TENTHS + 10) {
       // few elements can still be in non-singleton groups (at most 2 per missing group... bound: n - groups < 0.4 n
       // means at most 0.8 n active): build the explicit list and check its real size
@@ -414,8 +415,7 @@ int k1_bwt(bce_hip_ctx *c) {
   hipLaunchKernelGGL(k1_bwt_kernel, dim3(g), dim3(K1_T), 0, c->stream, T, sa, n, bwt);
   hipLaunchKernelGGL(k1_offset_kernel, dim3(g), dim3(K1_T), 0, c->stream, c->rank.as<uint32_t>(), n, scalars + 1);
   uint32_t off = 0;
-  BCE_HIP_TRY(c, hipMemcpyAsync(&off, scalars + 1, 4, hipMemcpyDeviceToHost, c->stream));
-  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  BCE_TRY(read_back(c, &off, scalars + 1, 4));
   BCE_HIP_TRY(c, hipGetLastError());
   if (off >= n) { snprintf(c->err, sizeof c->err, "k1: no rank-0 rotation found"); return BCE_HIP_E_INTERNAL; }
   c->offset = off;
@@ -446,8 +446,7 @@ int k1_divbwt(bce_hip_ctx *c, const uint8_t *T_host, uint8_t *U_host, uint32_t n
   c->stats.sort_rounds = 0;
   BCE_TRY(k1_sort_rotations(c, T, m, true));
   uint32_t pidx = 0;
-  BCE_HIP_TRY(c, hipMemcpyAsync(&pidx, c->rank.as<uint32_t>(), 4, hipMemcpyDeviceToHost, c->stream));   // row of suffix 0
-  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  BCE_TRY(read_back(c, &pidx, c->rank.as<uint32_t>(), 4));   // row of suffix 0
   if (pidx == 0 || pidx > n) { snprintf(c->err, sizeof c->err, "divbwt: primary index %u out of range", pidx); return BCE_HIP_E_INTERNAL; }
   hipLaunchKernelGGL(k1_divbwt_gather_kernel, dim3(grid_for(m)), dim3(K1_T), 0, c->stream, T, c->sa[c->sa_res].as<uint32_t>(), m,
                      pidx, c->bwt.as<uint8_t>());

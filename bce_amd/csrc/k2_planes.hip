@@ -156,8 +156,7 @@ int k2_build_planes(bce_hip_ctx *c) {
                        pl.nb, j, zc, G, zout);
     cur = nxt;
   }
-  BCE_HIP_TRY(c, hipMemcpyAsync(c->zeros, zout, 32, hipMemcpyDeviceToHost, c->stream));
-  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  BCE_TRY(read_back(c, c->zeros, zout, 32));
   BCE_HIP_TRY(c, hipGetLastError());
   return BCE_HIP_OK;
 }

@@ -1344,8 +1344,7 @@ retry:
     for (;;) {
       a.in = lin; a.in_count = lcount; a.out = queue[0]; a.spill = spillq[lpass & 1];
       hipLaunchKernelGGL(k3_local_kernel, dim3((lcount + LB_IN - 1) / LB_IN), dim3(LB_T), 0, c->stream, a);
-      BCE_HIP_TRY(c, hipMemcpyAsync(&h, a.dctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
-      BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+      BCE_TRY(read_back(c, &h, a.dctl, sizeof h));
       BCE_HIP_TRY(c, hipGetLastError());
       c->stats.k3_launches += 1.0;
       if (a.dbg) {
@@ -1389,8 +1388,7 @@ retry:
     }
     // the long staircase stretches the walkers queued in this pass: their events, over the whole grid
     hipLaunchKernelGGL(kd_jobs_kernel, dim3(1024), dim3(256), 0, c->stream, a, jobs_done);
-    BCE_HIP_TRY(c, hipMemcpyAsync(&h, a.dctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    BCE_TRY(read_back(c, &h, a.dctl, sizeof h));
     BCE_HIP_TRY(c, hipGetLastError());
     jobs_done = h.njobs < KD_JOBS ? h.njobs : KD_JOBS;
     if (a.dbg) {

@@ -47,6 +47,7 @@ struct DecCtl {
   uint32_t next_nodes, pad;
   uint64_t nodes_total;
 };
+static_assert(sizeof(DecCtl) <= 4096, "read_back() moves it through 4 KB of pinned memory");
 
 struct DecInfo {             // what the host needs after the query pass (pinned host memory)
   uint32_t qbase[8], qtot[8];
@@ -1354,9 +1355,8 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
             __builtin_ia32_pause();
           }
         }
-        BCE_HIP_TRY(c, hipMemcpyAsync(done, d_rounds, 20, hipMemcpyDeviceToHost, c->stream));
-        BCE_HIP_TRY(c, hipMemcpyAsync(&ctl, c->ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
-        BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        BCE_TRY(read_back(c, done, d_rounds, 20));
+        BCE_TRY(read_back(c, &ctl, c->ctl.p, sizeof ctl));
         BCE_HIP_TRY(c, hipGetLastError());
         if (getenv("BCE_DEC_TRACE")) fprintf(stderr, "tail: round %u wave %d resume %d -> done %u why %u next %u\n", round, (int)wave, (int)resume, done[0], done[1], ctl.next_nodes);
         round += done[0]; tail_rounds += done[0];
@@ -1444,8 +1444,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
     hipLaunchKernelGGL((dec_scan_kernel<false>), dim3(8), dim3(1024), 0, c->stream, a);
     hipLaunchKernelGGL((dec_tiles_kernel<3>), dim3(grid), dim3(K3_T), 0, c->stream, a);
     // the next round's size: read the control block (the query pass of the next round would tell, but its grid needs it)
-    BCE_HIP_TRY(c, hipMemcpyAsync(&ctl, c->ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
-    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    BCE_TRY(read_back(c, &ctl, c->ctl.p, sizeof ctl));
     BCE_HIP_TRY(c, hipGetLastError());
     if (ctl.err) {
       snprintf(c->err, sizeof c->err, ctl.err == 2 ? "decode: node list overflow (capP=%u)" : "decode: inconsistent archive (round %u)",
@@ -1492,8 +1491,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
     hipLaunchKernelGGL(gran_from_words_kernel, dim3(gb < 4096 ? gb : 4096, 8), dim3(256), 0, c->stream, f, c->gran.as<Granule>(), ngran);
   }
   uint32_t ferr = 0;
-  BCE_HIP_TRY(c, hipMemcpyAsync(&ferr, f.err, 4, hipMemcpyDeviceToHost, c->stream));
-  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  BCE_TRY(read_back(c, &ferr, f.err, 4));
   BCE_HIP_TRY(c, hipGetLastError());
   if (ferr) { snprintf(c->err, sizeof c->err, "decode: a mixed gap was never split"); return BCE_HIP_E_INTERNAL; }
   BCE_TRY(ensure(c, c->bwt, n));

@@ -11,6 +11,8 @@
 #include <chrono>
 #include <fstream>
 #include <string>
+#include <algorithm>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -38,35 +40,54 @@ static void put_u32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4
 static void put_u64(std::vector<uint8_t> &v, uint64_t x) { for (int i = 0; i < 8; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
 static uint64_t get_le(const uint8_t *p, int bytes) { uint64_t x = 0; for (int i = 0; i < bytes; ++i) x |= (uint64_t)p[i] << (8 * i); return x; }
 
-// `bce -cN`: N contiguous blocks, block b on device b mod (number of GPUs), one host thread per device.
+// `bce -cN`: N contiguous blocks over the GPUs of the node.  With more blocks than GPUs every device gets up to three
+// gated contexts (bce_hip_set_gated), one host thread each: their GPU phases take turns while the coder threads of the
+// context that has just left the GPU finish its block.  Blocks are handed out in order to whichever context is free.
 static int compress_blocks(const std::vector<uint8_t> &data, uint32_t nblocks, const uint8_t *config, std::vector<uint8_t> &out) {
   std::vector<bce_hip_ctx *> ctx;
-  for (int dev = 0; dev < 64 && ctx.size() < nblocks; ++dev) {
+  int ndev = 0;
+  for (int dev = 0; dev < 64; ++dev) {
     bce_hip_ctx *c = nullptr;
     if (bce_hip_create(&c, dev) != 0) break;
-    if (config && bce_hip_set_config(c, config) != 0) {        // (validated by the caller already: cannot happen)
-      printf("Config rejected on device %d: %s\n", dev, bce_hip_last_error(c));
-      bce_hip_destroy(c);
+    ctx.push_back(c);
+    ndev = dev + 1;
+    if (ctx.size() >= nblocks) break;
+  }
+  if (ctx.empty()) return -3;
+  const size_t per_dev = std::min<size_t>(3, (nblocks + (size_t)ndev - 1) / (size_t)ndev);
+  for (size_t extra = 1; extra < per_dev; ++extra)
+    for (int dev = 0; dev < ndev && ctx.size() < nblocks; ++dev) {
+      bce_hip_ctx *c = nullptr;
+      if (bce_hip_create(&c, dev) != 0) break;
+      ctx.push_back(c);
+    }
+  for (size_t i = 0; i < ctx.size(); ++i) {
+    if (config && bce_hip_set_config(ctx[i], config) != 0) {        // (validated by the caller already: cannot happen)
+      printf("Config rejected: %s\n", bce_hip_last_error(ctx[i]));
       for (bce_hip_ctx *o : ctx) bce_hip_destroy(o);
       return -1;
     }
-    ctx.push_back(c);
+    (void)bce_hip_set_gated(ctx[i], ctx.size() > (size_t)ndev ? 1 : 0);
   }
-  if (ctx.empty()) return -3;
   const size_t n = data.size(), base = n / nblocks, rem = n % nblocks;
   std::vector<std::vector<uint8_t>> arch(nblocks);
   std::vector<size_t> lo(nblocks + 1);
   for (uint32_t b = 0; b <= nblocks; ++b) lo[b] = b * base + (b < rem ? b : rem);
   std::vector<int> rcs(ctx.size(), 0);
+  std::atomic<uint32_t> next_block{0};
+  std::atomic<bool> failed{false};
   std::vector<std::thread> th;
   for (size_t d = 0; d < ctx.size(); ++d)
     th.emplace_back([&, d] {
-      for (uint32_t b = (uint32_t)d; b < nblocks && rcs[d] == 0; b += (uint32_t)ctx.size()) {
+      while (!failed.load()) {
+        const uint32_t b = next_block.fetch_add(1);
+        if (b >= nblocks) break;
         size_t alen = 0;
         int rc = bce_hip_compress(ctx[d], data.data() + lo[b], (uint32_t)(lo[b + 1] - lo[b]), nullptr, 0, &alen);
         if (rc == 0) { arch[b].resize(alen); rc = bce_hip_archive_copy(ctx[d], arch[b].data(), alen); }
-        rcs[d] = rc;
+        if (rc) { rcs[d] = rc; failed.store(true); break; }
       }
+      (void)bce_hip_set_gated(ctx[d], 0);                           // (gives the gate back if a failed stage left it held)
     });
   for (auto &t : th) t.join();
   int rc = 0;

@@ -44,13 +44,12 @@ const char *bce_hip_last_error(const bce_hip_ctx *ctx);
  * the built-in defaults (bce.cpp:713-724). */
 int bce_hip_set_config(bce_hip_ctx *ctx, const uint8_t *config288);
 /* Several contexts on ONE device (a stream of files or blocks, `bce -cN` with more blocks than GPUs): a compression is a
- * GPU phase (load .. the last model flush) followed by a host phase in which the eight coder threads finish the last
- * batches, so two contexts driven by two host threads overlap one's coding with the other's kernels.  Gated contexts
- * (on != 0) of a device take turns on the GPU: the gate is taken in bce_hip_load_* and given back by bce_hip_encode
- * when its last flush is queued, by any stage that fails, by bce_hip_scan and by bce_hip_destroy; while a gated
- * context waits for its own coder threads it lends the gate to the next one.  A gated context that is loaded must
- * therefore be taken through bce_hip_encode (or destroyed, or un-gated with on = 0) before another gated context of the same
- * device can load.  Ungated contexts (default) ignore the gate; do not run them beside gated ones on the same device. */
+ * GPU phase followed by a host phase in which the eight coder threads finish the last batches, so contexts driven by
+ * one host thread each overlap one's coding -- and one's rotation sort -- with the other's enumeration.  Gated contexts
+ * (on != 0) of a device take turns for the ENUMERATION (its single-launch rounds must not run beside another context's):
+ * bce_hip_encode / bce_hip_scan take the device's gate, give it back when the last model flush is queued or when they
+ * fail, and lend it to the next context while they wait for their own coder threads; bce_hip_destroy and on = 0 give it
+ * back too.  Ungated contexts (default) ignore the gate: do not encode with them beside gated ones on the same device. */
 int bce_hip_set_gated(bce_hip_ctx *ctx, int on);
 /* capacity (in symbol records) of the device symbol buffer between model flushes; 0 = automatic */
 int bce_hip_set_symbol_capacity(bce_hip_ctx *ctx, uint64_t records);

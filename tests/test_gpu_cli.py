@@ -78,3 +78,19 @@ def test_cli_block_container(tmp_path):
     for flag in ("-d", "-ds"):
         r = subprocess.run([EXE, flag, str(out), str(arc)], capture_output=True, text=True)
         assert r.returncode == 0 and out.read_bytes() == data
+
+
+def test_cli_many_blocks_on_few_gpus(tmp_path):
+    """`bce -c11` on a box with fewer GPUs than blocks: up to three gated contexts per device take the blocks in turn
+    (main.cpp compress_blocks); every block is still exactly `bce -c` of its bytes, whichever context coded it."""
+    from bce_amd import container, sharding
+    data = oracle.synth_text(16, 1300003)
+    src, arc = tmp_path / "in.txt", tmp_path / "a.bcem"
+    src.write_bytes(data)
+    r = subprocess.run([EXE, "-c11", str(arc), str(src)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    archives, sizes = container.unpack_blocks(arc.read_bytes())
+    assert len(archives) == 11 and sum(sizes) == len(data)
+    for b in range(11):
+        lo, hi = sharding.block_range(len(data), 11, b)
+        assert sizes[b] == hi - lo and archives[b] == oracle.compress(data[lo:hi])
