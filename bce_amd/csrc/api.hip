@@ -76,64 +76,15 @@ void gate_release(bce_hip_ctx *c) {
   c->gate_held = false;
   g.cv.notify_one();
 }
-// First use.  A gated context whose buffers still have to be allocated (its first compression, or a larger input than it
-// has seen) runs that whole compression ALONE among the gated contexts of the process: measured on MI355X / ROCm 7.2,
-// three contexts that start cold side by side -- dozens of 400 MB hipMallocs from three host threads while the others'
-// kernels run -- end with one of them sorting wrong (K1 leaves a few hundred rotations unseparated and reports "no rank-0
-// rotation"; tools/stream_check.py FILE 3 6 keep), although no two buffers overlap, nothing is freed, and the same
-// contexts started one after the other never fail.  Whatever the cause below the HIP API, allocation phases are kept
-// out of the concurrent regime: warm contexts hold the stage lock as readers for the duration of a stage, a cold one as
-// the writer from load to the end of encode.
-struct StageLock { std::mutex mu; std::condition_variable cv; int readers = 0, writers_waiting = 0; bool writer = false; };
-StageLock &stage_lock() { static StageLock l; return l; }
-void stage_enter(bce_hip_ctx *c, bool exclusive) {
-  if (!c->gated || c->cold_excl || c->stage_shared) return;
-  StageLock &l = stage_lock();
-  std::unique_lock<std::mutex> lk(l.mu);
-  if (exclusive) {
-    ++l.writers_waiting;
-    l.cv.wait(lk, [&] { return !l.writer && l.readers == 0; });
-    --l.writers_waiting;
-    l.writer = true;
-    c->cold_excl = true;
-  } else {
-    l.cv.wait(lk, [&] { return !l.writer && l.writers_waiting == 0; });
-    ++l.readers;
-    c->stage_shared = true;
-  }
-}
-void stage_exit_shared(bce_hip_ctx *c) {
-  if (!c->stage_shared) return;
-  StageLock &l = stage_lock();
-  { std::lock_guard<std::mutex> lk(l.mu); --l.readers; }
-  c->stage_shared = false;
-  l.cv.notify_all();
-}
-void stage_exit_exclusive(bce_hip_ctx *c) {
-  if (!c->cold_excl) return;
-  StageLock &l = stage_lock();
-  { std::lock_guard<std::mutex> lk(l.mu); l.writer = false; }
-  c->cold_excl = false;
-  l.cv.notify_all();
-}
-// one API stage of a gated context: reader for its duration unless the context is the writer already
-struct StageScope {
-  bce_hip_ctx *c;
-  explicit StageScope(bce_hip_ctx *ctx) : c(ctx) { if (c) stage_enter(c, false); }
-  ~StageScope() { if (c) stage_exit_shared(c); }
-};
-
 // a stage that failed gives the gate back: the caller will not get to the point where encode does
 int gate_on_error(bce_hip_ctx *c, int status) {
-  if (c && status != BCE_HIP_OK) { gate_release(c); stage_exit_exclusive(c); }
+  if (c && status != BCE_HIP_OK) gate_release(c);
   return status;
 }
 
 int set_input_body(bce_hip_ctx *c, const void *src, uint32_t n, hipMemcpyKind kind);
 int set_input(bce_hip_ctx *c, const void *src, uint32_t n, hipMemcpyKind kind) {
   if (!c || !src || n == 0 || n >= 0x80000000u) return BCE_HIP_E_ARG;   // n < 2^31 (saidx_t, getv: SURVEY section 5)
-  if (c->gated && n > c->warm_n) stage_enter(c, true);      // cold: alone from here to the end of encode
-  StageScope scope(c);
   if (getenv("BCE_HIP_GATE_ALL")) gate_acquire(c);      // (experiment: the whole GPU phase exclusive, not only the enumeration)
   return gate_on_error(c, set_input_body(c, src, n, kind));
 }
@@ -259,8 +210,6 @@ static int create_body(bce_hip_ctx **out, int device) {
 void bce_hip_destroy(bce_hip_ctx *c) {
   if (!c) return;
   gate_release(c);
-  stage_exit_shared(c);
-  stage_exit_exclusive(c);
   (void)hipSetDevice(c->device);
   if (c->coder) c->coder->drain();
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -352,7 +301,7 @@ int bce_hip_set_progress(bce_hip_ctx *c, bce_hip_progress_fn fn, void *user) {
 
 int bce_hip_set_gated(bce_hip_ctx *c, int on) {
   if (!c) return BCE_HIP_E_ARG;
-  if (!on) { gate_release(c); stage_exit_shared(c); stage_exit_exclusive(c); }
+  if (!on) gate_release(c);
   c->gated = on != 0;
   return BCE_HIP_OK;
 }
@@ -367,7 +316,7 @@ int bce_hip_load_host(bce_hip_ctx *c, const uint8_t *in, uint32_t n) { return se
 int bce_hip_load_device(bce_hip_ctx *c, const void *d_in, uint32_t n) { return set_input(c, d_in, n, hipMemcpyDeviceToDevice); }
 
 static int bwt_body(bce_hip_ctx *c, uint32_t *offset);
-int bce_hip_bwt(bce_hip_ctx *c, uint32_t *offset) { StageScope scope(c); return gate_on_error(c, bwt_body(c, offset)); }
+int bce_hip_bwt(bce_hip_ctx *c, uint32_t *offset) { return gate_on_error(c, bwt_body(c, offset)); }
 static int bwt_body(bce_hip_ctx *c, uint32_t *offset) {
   BCE_TRY(check_stage(c, 1));
   BCE_HIP_TRY(c, hipSetDevice(c->device));
@@ -419,7 +368,7 @@ int bce_hip_inverse_bwt(bce_hip_ctx *c, const uint8_t *in, uint8_t *out, uint32_
 }
 
 static int planes_body(bce_hip_ctx *c, uint32_t zeros[8]);
-int bce_hip_build_planes(bce_hip_ctx *c, uint32_t zeros[8]) { StageScope scope(c); return gate_on_error(c, planes_body(c, zeros)); }
+int bce_hip_build_planes(bce_hip_ctx *c, uint32_t zeros[8]) { return gate_on_error(c, planes_body(c, zeros)); }
 static int planes_body(bce_hip_ctx *c, uint32_t zeros[8]) {
   BCE_TRY(check_stage(c, 2));
   BCE_HIP_TRY(c, hipSetDevice(c->device));
@@ -516,12 +465,7 @@ int bce_hip_enum_model(bce_hip_ctx *c, uint32_t *out, uint64_t cap_records, uint
 
 // ---- BCE::encode ------------------------------------------------------------------------------------
 static int encode_body(bce_hip_ctx *c);
-int bce_hip_encode(bce_hip_ctx *c) {
-  StageScope scope(c);
-  const int r = gate_on_error(c, bce_guarded(c, [&] { return encode_body(c); }));
-  if (c && r == BCE_HIP_OK && c->cold_excl) { c->warm_n = c->n > c->warm_n ? c->n : c->warm_n; stage_exit_exclusive(c); }
-  return r;
-}
+int bce_hip_encode(bce_hip_ctx *c) { return gate_on_error(c, bce_guarded(c, [&] { return encode_body(c); })); }
 static int encode_body(bce_hip_ctx *c) {
   BCE_TRY(check_stage(c, 3));
   gate_acquire(c);
@@ -677,9 +621,8 @@ static int encode_body(bce_hip_ctx *c) {
 // the host in stream order, then pick the context bits.
 static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes);
 int bce_hip_scan(bce_hip_ctx *c, uint8_t config288[BCE_HIP_CONFIG_BYTES], double result_bytes[9]) {
-  StageScope scope(c);
   const int r = bce_guarded(c, [&] { return scan_body(c, config288, result_bytes); });
-  if (c) { gate_release(c); stage_exit_exclusive(c); }   // (-s keeps the gate to its end: its host part is short)
+  if (c) gate_release(c);                        // (-s keeps the gate to its end: its host part is short)
   return r;
 }
 static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes) {

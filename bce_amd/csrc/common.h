@@ -76,9 +76,6 @@ struct bce_hip_ctx {
   bool overlap = false;
   bool gated = false;                            // bce_hip_set_gated: GPU stages of gated contexts of one device take turns
   bool gate_held = false;
-  bool cold_excl = false;                        // this (gated) context runs its first compression of this size alone
-  bool stage_shared = false;                     // ... or holds the process-wide stage lock as one of many
-  uint32_t warm_n = 0;                           // largest input a gated compression has been completed for
   uint32_t flush_seq = 0;                        // flushes issued by this context (parity selects ev_k4_done)
   hipEvent_t copy_busy = nullptr;                // last copy out of `sout` (the next K4 must not overwrite it earlier)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_k4 = nullptr;
@@ -163,10 +160,8 @@ inline int ensure(bce_hip_ctx *c, DevBuf &b, size_t bytes) {
   if (bytes <= b.cap) return BCE_HIP_OK;
   if (b.p) {
     // The old buffer may still be read or written by work this context has queued (a model flush and its copy run
-    // behind the host): nothing of it may be in flight when the memory goes back to the allocator, because ANOTHER
-    // context's hipMalloc -- another host thread -- can be handed it at once.  (hipFree's own synchronisation did not
-    // cover that: with three contexts starting cold side by side, one context's flush buffers, freed while they grew
-    // from flush to flush, turned up as another's K1 arrays and were written to; tools/stream_check.py.)
+    // behind the host): nothing of it may be in flight when the memory goes back to the allocator, because another
+    // context's hipMalloc -- another host thread -- can be handed it at once.
     for (hipStream_t st : {c->stream, c->k4_stream, c->copy_stream}) if (st) BCE_HIP_TRY(c, hipStreamSynchronize(st));
     (void)hipFree(b.p);
     b.p = nullptr; b.cap = 0;
@@ -180,10 +175,8 @@ inline void release(DevBuf &b) {
   b.p = nullptr; b.cap = 0;
 }
 
-// A few bytes from the device, now: through pinned memory of the context's own.  (A device-to-host copy into PAGEABLE
-// memory -- a stack variable -- goes through the runtime's staging path; with several contexts at work from several
-// host threads such copies were seen to deliver the bytes from BEFORE the kernel queued in front of them on the same
-// stream: K1 then read its group count or the offset too early.  tools/k1_concurrent.py shows it.)
+// A few bytes from the device, now: through pinned memory of the context's own (a copy into pageable memory -- a stack
+// variable -- goes through the runtime's staging buffers, which all host threads and contexts share).
 inline int read_back(bce_hip_ctx *c, void *dst, const void *dev_src, size_t bytes) {
   if (bytes > 4096) return BCE_HIP_E_ARG;
   if (!c->h_small) BCE_HIP_TRY(c, hipHostMalloc(&c->h_small, 4096, hipHostMallocDefault));

@@ -30,12 +30,18 @@ namespace bce {
 
 constexpr int K1_T = 256;
 
+// Blocks of the per-block passes (heads / apply / active list): at most K1_MAXB, each a whole number of 2048-element chunks.
+// (nb is NOT monotonic in n -- 10^8 elements give 1018 blocks, 4*10^7 give 1022 -- so everything laid out behind the
+//  per-block array sits at K1_MAXB, not at the first plan's nb: with the scalars at nb(n) the active rounds' block 1020
+//  shared its count with the list length that block 0 writes at the end of the same kernel, which showed as soon as
+//  other contexts delayed the last blocks of a launch.)
+constexpr uint32_t K1_MAXB = 1024;
 struct K1Plan { uint32_t nb, per_block; };
 static K1Plan k1_plan(uint32_t n) {
   const uint32_t chunk = 2048;
   uint32_t chunks = (uint32_t)(((uint64_t)n + chunk - 1) / chunk);
   if (!chunks) chunks = 1;
-  uint32_t nb = chunks < 1024u ? chunks : 1024u;
+  uint32_t nb = chunks < K1_MAXB ? chunks : K1_MAXB;
   uint32_t cpb = (chunks + nb - 1) / nb;
   nb = (chunks + cpb - 1) / cpb;
   return {nb, cpb * chunk};
@@ -288,9 +294,9 @@ static int k1_sort_rotations(bce_hip_ctx *c, const uint8_t *T, uint32_t n, bool 
   BCE_TRY(ensure(c, c->nrk, b4));
   for (int i = 0; i < 2; ++i) BCE_TRY(ensure(c, c->act[i], b4));
   const K1Plan pl = k1_plan(n);
-  BCE_TRY(ensure(c, c->blk, (size_t)(pl.nb + 16) * 4));
+  BCE_TRY(ensure(c, c->blk, (size_t)(K1_MAXB + 16) * 4));
   uint32_t *blockmax = c->blk.as<uint32_t>();
-  uint32_t *scalars = blockmax + pl.nb;  // [0] groups, [1] offset
+  uint32_t *scalars = blockmax + K1_MAXB;  // [0] groups, [1] offset, [2] active elements
   uint32_t *rank = c->rank.as<uint32_t>(), *k2 = c->k2.as<uint32_t>(), *nrk = c->nrk.as<uint32_t>();
   const uint32_t g = grid_for(n);
 
@@ -409,7 +415,7 @@ int k1_bwt(bce_hip_ctx *c) {
   }
   BCE_TRY(k1_sort_rotations(c, T, n, false));
   const uint32_t g = grid_for(n);
-  uint32_t *scalars = c->blk.as<uint32_t>() + k1_plan(n).nb;   // [0] groups, [1] offset
+  uint32_t *scalars = c->blk.as<uint32_t>() + K1_MAXB;   // [0] groups, [1] offset
   const uint32_t *sa = c->sa[c->sa_res].as<uint32_t>();
   BCE_HIP_TRY(c, hipMemsetAsync(scalars + 1, 0xFF, 4, c->stream));
   hipLaunchKernelGGL(k1_bwt_kernel, dim3(g), dim3(K1_T), 0, c->stream, T, sa, n, bwt);

@@ -824,8 +824,8 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
         uint32_t res = 0;
         DNode nx{0u, 1u, 1u, 0u, 0ull};
         const uint64_t tq = UNI ? 0 : clock64();
-        if ((singles >> L) & 1ull) ok = stair_run(a, sL, x0L, x1L, rL, lane, nn, mr);
-        if (!ok) res = stairs_run(a, &sregs, sL, x0L, x1L, rL, lane, nx, nn);
+        if ((singles >> L) & 1ull) ok = uni(stair_run(a, sL, x0L, x1L, rL, lane, nn, mr) ? 1u : 0u) != 0u;
+        if (!ok) res = uni(stairs_run(a, &sregs, sL, x0L, x1L, rL, lane, nx, nn));
         if (UNI || (int)lane == L) {
           if (!UNI) visited += (uint32_t)((clock64() - tq) >> 12);
           if (ok) { consumed = true; nodes += nn; maxround = mr > maxround ? mr : maxround; }
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
     }
     if (alive && consumed) {
       ++visited;
-      if (a.dctl->err) alive = false; else pop();
+      if (uni(a.dctl->err)) alive = false; else pop();
     } else if (alive) {
       ++visited;
       if (mykk) {                                    // mykk whole bytes of pass-through: 8*mykk rounds, no symbols
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
           //  through the scalar cache, which a chain that moves a row per byte keeps hitting)
           const ConstGranule *G = (const ConstGranule *)(k.gran + (size_t)p * k.ngran);
           const uint32_t ga = div96(s), gb = div96(s + xx);
-          const uint32_t zp = k.zeros[p];                    // all three loads in flight together
+          const uint32_t zp = uni(k.zeros[p]);               // all three loads in flight together
           const Granule qa{G[ga].cum, G[ga].w0, G[ga].w1, G[ga].w2}, qb{G[gb].cum, G[gb].w0, G[gb].w1, G[gb].w2};
           const uint32_t rs = rank1_64(qa, s - ga * 96u), n1x = rank1_64(qb, s + xx - gb * 96u) - rs;
           if (n1x == 0) s -= rs;
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
       }
       uint32_t has0, has1, sym, kq;
       Node c0, c1;
-      node_flat_post(nd, k.zeros[p], nf, granule_rank1(qm, nd.s + nd.x0 - gm * 96u), has0, c0, has1, c1, sym, kq);
+      node_flat_post(nd, uni(k.zeros[p]), nf, granule_rank1(qm, nd.s + nd.x0 - gm * 96u), has0, c0, has1, c1, sym, kq);
       ++nodes;
       if (a.dbg && writer) atomicAdd(&a.dctl->dbg_hist[31 - __clz((int)(nd.x0 + nd.x1))], 1u);
       maxround = cur.round > maxround ? cur.round : maxround;

@@ -51,3 +51,25 @@ def test_above_2_27_bytes_context_wrap_matches_the_oracle():
     assert len(arch) == v["archive_bytes"] and hashlib.sha256(arch).hexdigest() == v["archive_sha256"]
     back = bce_amd.decompress_device(arch)
     assert len(back) == v["n"] and hashlib.sha256(back).hexdigest() == v["input_sha256"]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("name", ["natural-1e8", "synth-text-1e8"])
+def test_stream_through_three_contexts_equals_the_oracles(name):
+    """A stream of full-size inputs through three gated contexts (bce_amd.ContextPool): K1 of one input runs beside the
+    enumeration and the model flushes of the others, so blocks of a launch start late and out of step -- which is what
+    exposed K1's active-list kernel sharing a word between its per-block counts and its result (k1_plan's block count is
+    not monotonic in the element count; 10^8 bytes of source code hit it, text did not).  Every archive of the stream
+    must be the oracle's."""
+    v = GOLD[name]
+    data = fullsize_input(v)
+    if data is None:
+        pytest.skip("this box cannot rebuild the %s corpus bit for bit (files of another image)" % v["kind"])
+    t = torch.from_numpy(data).to("cuda:0")
+    torch.cuda.synchronize()
+    with bce_amd.ContextPool(3, 0) as pool:
+        for _ in range(2):                       # cold contexts first, then warm ones
+            res = pool.compress_many([(t.data_ptr(), len(data))] * 6, on_device=True)
+            assert [hashlib.sha256(a).hexdigest() for a in res] == [v["archive_sha256"]] * 6
+    del t
+    torch.cuda.empty_cache()

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Stream of identical inputs through N gated contexts; checks every archive and that the input tensor is intact.
-   tools/stream_check.py FILE contexts steps"""
+   tools/stream_check.py FILE contexts steps [keep] [pre] [pin] [stats] [seqload] [seqwarm]
+   keep: a used context stays alive beside the pool; pre: the pool is warmed on synth-text first; seqload / seqwarm: every
+   context runs K1 + K2 / a whole compression alone before the stream starts.  (This is the tool that cornered the K1
+   active-list bug: run with GPU_MAX_HW_QUEUES=8 it failed on 10^8 bytes of source code until k1_plan's scalars moved.)"""
 import hashlib
 import sys
 
@@ -23,6 +26,10 @@ ref, _ = bce_amd.compress_device(t_in.data_ptr(), n, ctx=keep)
 ref = hashlib.sha256(ref).hexdigest()
 print("alone:", ref[:16])
 with bce_amd.ContextPool(nctx, 0) as pool:
+    if "pre" in opts:       # warm the pool on another input of the same size first
+        other = torch.from_numpy(bce_amd.synth_text(1, n)).to("cuda:0")
+        pool.compress_many([(other.data_ptr(), n)] * (2 * nctx), on_device=True)
+        print("pool warmed on synth-text")
     if "seqload" in opts:
         for c in pool.ctxs:
             rf = bce_amd.RankFile(n=n, device_ptr=t_in.data_ptr(), ctx=c)
