@@ -15,7 +15,7 @@ import oracle    # noqa: E402
 
 
 def gen(rs, n):
-    kind = rs.randint(0, 10)
+    kind = rs.randint(0, 12)
     if kind in (2, 3, 8) and n > 60000:      # long exact repeats: the CPU oracle walks them bit by bit (minutes at MBs)
         n = 20000 + n % 40000
     if kind == 0:
@@ -44,6 +44,19 @@ def gen(rs, n):
         return rs.randint(0, 256, n).astype(np.uint8)
     if kind == 7:
         return (rs.randint(0, 1 << rs.randint(1, 5), n).astype(np.uint8) << rs.randint(0, 5)).astype(np.uint8)
+    if kind in (10, 11):   # spines (k3_dfs.hip spine_burst): a context that keeps thousands of rows and loses a few per byte
+        parts, size = [], 0
+        while size < n:
+            if kind == 10:     # runs of one byte of many lengths between random bytes
+                p = rs.bytes(int(rs.randint(1, 24))) + bytes([int(rs.choice([0, 0, 255, 32]))]) * int(rs.randint(1, 2500))
+            else:              # little-endian 16-bit tables with small values, records with constant fields
+                if rs.randint(0, 2):
+                    p = np.minimum(rs.geometric(0.2, int(rs.randint(50, 3000))), 200).astype("<u2").tobytes() + rs.bytes(2)
+                else:
+                    p = b"".join(rs.bytes(3) + b"\x00\x00\x00\x01\x00\x00\x00\xff\x10" for _ in range(int(rs.randint(20, 800)))) + rs.bytes(int(rs.randint(1, 9)))
+            parts.append(p)
+            size += len(p)
+        return np.frombuffer(b"".join(parts), dtype=np.uint8)[:n].copy()
     if kind == 9:          # long runs of one byte inside other data (executables): chains that cannot be skipped
         base = rs.randint(0, 256, n).astype(np.uint8) if rs.randint(0, 2) else np.frombuffer(oracle.synth_text(int(rs.randint(1, 10 ** 6)), n), dtype=np.uint8).copy()
         unit0 = rs.randint(0, 4, rs.randint(1, 9)).astype(np.uint8) * rs.choice([1, 1, 85])    # the same pattern in several places
