@@ -30,9 +30,33 @@ static RsPlan rs_plan(uint32_t n) {
   return {nb, cpb * (uint32_t)RS_CHUNK};
 }
 
-// lanes holding the same digit as this lane (valid lanes only)
+// lanes holding the same digit as this lane (valid lanes only).  NBITS > 0: digit width known at compile time (the
+// scatter kernel is bound by exactly these instructions -- rocprofv3: 108 VALU per key with the runtime loop, SIMDs
+// ~60 % busy issuing -- so the loop is unrolled and written as "lanes that DIFFER in some bit": per bit one bitfield
+// extract that gives 0 / ~0, one compare for the ballot, two xors, and one three-way or per two bits and half).
+template <int NBITS>
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, int nbits, bool valid) {
-  uint64_t peers = __ballot(valid);
+  const uint64_t vm = __ballot(valid);
+  if (NBITS > 0) {
+    uint32_t dl = 0, dh = 0;                     // lanes whose digit differs from mine in some bit
+#pragma unroll
+    for (int b = 0; b + 1 < NBITS; b += 2) {
+      const uint32_t n0 = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1), n1 = (uint32_t)__builtin_amdgcn_sbfe((int)d, b + 1, 1);   // 0 or ~0
+      const uint64_t m0 = __ballot(n0 != 0u), m1 = __ballot(n1 != 0u);
+      dl |= ((uint32_t)m0 ^ n0) | ((uint32_t)m1 ^ n1);          // bit set: my bit is 1 and theirs 0, or the other way round
+      dh |= ((uint32_t)(m0 >> 32) ^ n0) | ((uint32_t)(m1 >> 32) ^ n1);
+    }
+    if (NBITS & 1) {
+      const uint32_t n0 = (uint32_t)__builtin_amdgcn_sbfe((int)d, NBITS - 1, 1);
+      const uint64_t m0 = __ballot(n0 != 0u);
+      dl |= (uint32_t)m0 ^ n0;
+      dh |= (uint32_t)(m0 >> 32) ^ n0;
+    }
+    // (my bit 1: m ^ ~0 = lanes with 0 = the lanes that differ; my bit 0: m ^ 0 = lanes with 1 = the lanes that differ)
+    const uint64_t differ = ((uint64_t)dh << 32) | dl;
+    return valid ? (vm & ~differ) : 0ull;
+  }
+  uint64_t peers = vm;
   for (int b = 0; b < nbits; ++b) {
     const bool bit = (d >> b) & 1u;
     const uint64_t m = __ballot(bit);
@@ -95,6 +119,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t *__restric
   if (threadIdx.x == 0) rowtotal[blockIdx.x] = carry;
 }
 
+template <int NBITS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *__restrict__ keys_in,
                                                                 const uint32_t *__restrict__ vals_in,
                                                                 uint32_t *__restrict__ keys_out,
@@ -149,7 +174,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
       const uint32_t q = w * (RS_CHUNK / 4) + (uint32_t)it * 64u + lane;
       const bool valid = q < cnt;
       const uint32_t d = (key[it] >> shift) & mask;
-      const uint64_t peers = match_digit(d, nbits, valid);
+      const uint64_t peers = match_digit<NBITS>(d, nbits, valid);
       const uint32_t leader = valid ? (uint32_t)(__ffsll((long long)peers) - 1) : lane;
       uint32_t pre = 0;
       if (valid && lane == leader) pre = atomicAdd(&wcnt[w][d], (uint32_t)__popcll(peers));
@@ -236,8 +261,17 @@ int radix_sort_pairs_on(bce_hip_ctx *c, hipStream_t stream, DevBuf &hbuf, uint32
     hipLaunchKernelGGL(rs_hist_kernel, dim3(pl.nb), dim3(RS_THREADS), 0, stream, key[cur], n, pl.per_block, pl.nb,
                        (int)shift, nbits, hist);
     hipLaunchKernelGGL(rs_scan_kernel, dim3(nbins), dim3(RS_THREADS), 0, stream, hist, pl.nb, rowtotal);
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(pl.nb), dim3(RS_THREADS), 0, stream, key[cur], val[cur],
-                       key[cur ^ 1], val[cur ^ 1], n, pl.per_block, pl.nb, (int)shift, nbits, hist, rowtotal);
+#define RS_SCATTER(NB)                                                                                              \
+  hipLaunchKernelGGL(rs_scatter_kernel<NB>, dim3(pl.nb), dim3(RS_THREADS), 0, stream, key[cur], val[cur], key[cur ^ 1], \
+                     val[cur ^ 1], n, pl.per_block, pl.nb, (int)shift, nbits, hist, rowtotal)
+    switch (nbits) {
+      case 9: RS_SCATTER(9); break;
+      case 8: RS_SCATTER(8); break;
+      case 7: RS_SCATTER(7); break;
+      case 6: RS_SCATTER(6); break;
+      default: RS_SCATTER(0); break;
+    }
+#undef RS_SCATTER
     cur ^= 1;
     done += (uint32_t)nbits;
   }
