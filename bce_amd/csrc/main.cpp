@@ -226,31 +226,74 @@ int main(int argc, char **argv) {
     }
     int rc = 0;
     std::vector<uint8_t> out;
-    uint64_t prog = 0;
-    bce_hip_ctx *ctx = nullptr;
-    if (argv[1][2] != 's') {
-      rc = bce_hip_create(&ctx, 0);
-      if (rc != 0) {
-        printf("No usable HIP device: %s (bce -ds decodes on the host)\n", bce_hip_strerror(rc));
-        return -3;
+    const bool use_gpu = argv[1][2] != 's';
+    if (blocks.size() == 1) {
+      uint64_t prog = 0;
+      bce_hip_ctx *ctx = nullptr;
+      if (use_gpu) {
+        rc = bce_hip_create(&ctx, 0);
+        if (rc != 0) {
+          printf("No usable HIP device: %s (bce -ds decodes on the host)\n", bce_hip_strerror(rc));
+          return -3;
+        }
+        bce_hip_set_progress(ctx, progress, &prog);
       }
-      bce_hip_set_progress(ctx, progress, &prog);
-    }
-    for (const auto &blk : blocks) {
-      const uint8_t *ap = adata.data() + blk.first;
+      const uint8_t *ap = adata.data() + blocks[0].first;
       size_t n = 0;
-      rc = ctx ? bce_hip_decompress_device(ctx, ap, blk.second, nullptr, 0, &n) : bce_hip_decompress(ap, blk.second, nullptr, 0, &n);
-      if (rc != 0) break;
-      const size_t at = out.size();
-      out.resize(at + n);
-      prog = 0;
-      rc = ctx ? bce_hip_decompress_device(ctx, ap, blk.second, out.data() + at, n, &n) : bce_hip_decompress(ap, blk.second, out.data() + at, n, &n);
-      if (rc != 0) break;
-    }
-    if (ctx) {
-      progress_end();
-      if (rc != 0) printf("%s\n", bce_hip_last_error(ctx));
-      bce_hip_destroy(ctx);
+      rc = ctx ? bce_hip_decompress_device(ctx, ap, blocks[0].second, nullptr, 0, &n) : bce_hip_decompress(ap, blocks[0].second, nullptr, 0, &n);
+      if (rc == 0) {
+        out.resize(n);
+        rc = ctx ? bce_hip_decompress_device(ctx, ap, blocks[0].second, out.data(), n, &n) : bce_hip_decompress(ap, blocks[0].second, out.data(), n, &n);
+      }
+      if (ctx) {
+        progress_end();
+        if (rc != 0) printf("%s\n", bce_hip_last_error(ctx));
+        bce_hip_destroy(ctx);
+      }
+    } else {
+      // a container: the blocks are independent, their sizes are in the table -- decoded side by side, two contexts per GPU
+      // (a block's decoding is mostly its eight sequential range decoders on the host) or, for -ds, up to 8 host threads
+      std::vector<size_t> at(blocks.size() + 1, 0);
+      for (size_t b = 0; b < blocks.size(); ++b) at[b + 1] = at[b] + (size_t)get_le(adata.data() + 12 + b * 16, 8);
+      out.resize(at.back());
+      std::vector<bce_hip_ctx *> ctxs;
+      if (use_gpu) {
+        int ndev = 0;
+        for (int dev = 0; dev < 64 && ctxs.size() < blocks.size(); ++dev) {
+          bce_hip_ctx *c = nullptr;
+          if (bce_hip_create(&c, dev) != 0) break;
+          ctxs.push_back(c);
+          ndev = dev + 1;
+        }
+        if (ctxs.empty()) { printf("No usable HIP device (bce -ds decodes on the host)\n"); return -3; }
+        for (int dev = 0; dev < ndev && ctxs.size() < blocks.size(); ++dev) {
+          bce_hip_ctx *c = nullptr;
+          if (bce_hip_create(&c, dev) != 0) break;
+          ctxs.push_back(c);
+        }
+      }
+      const size_t workers = use_gpu ? ctxs.size() : std::min<size_t>(blocks.size(), 8);
+      std::atomic<size_t> next_block{0};
+      std::atomic<int> first_rc{0};
+      std::vector<std::thread> th;
+      for (size_t w = 0; w < workers; ++w)
+        th.emplace_back([&, w] {
+          bce_hip_ctx *c = use_gpu ? ctxs[w] : nullptr;
+          while (first_rc.load() == 0) {
+            const size_t b = next_block.fetch_add(1);
+            if (b >= blocks.size()) break;
+            const uint8_t *ap = adata.data() + blocks[b].first;
+            size_t n = 0;
+            const size_t want = at[b + 1] - at[b];
+            int r = c ? bce_hip_decompress_device(c, ap, blocks[b].second, out.data() + at[b], want, &n)
+                      : bce_hip_decompress(ap, blocks[b].second, out.data() + at[b], want, &n);
+            if (r == 0 && n != want) r = BCE_HIP_E_INTERNAL;       // the table and the block's own header disagree
+            if (r != 0) { int z = 0; first_rc.compare_exchange_strong(z, r); }
+          }
+        });
+      for (auto &t : th) t.join();
+      rc = first_rc.load();
+      for (bce_hip_ctx *c : ctxs) { if (rc != 0 && bce_hip_last_error(c)[0]) printf("%s\n", bce_hip_last_error(c)); bce_hip_destroy(c); }
     }
     if (rc != 0) { printf("Decompression failed: %s\n", bce_hip_strerror(rc)); return -4; }
     auto end = std::chrono::high_resolution_clock::now();

@@ -94,3 +94,16 @@ def test_cli_many_blocks_on_few_gpus(tmp_path):
     for b in range(11):
         lo, hi = sharding.block_range(len(data), 11, b)
         assert sizes[b] == hi - lo and archives[b] == oracle.compress(data[lo:hi])
+    # and back: the blocks are decoded side by side (two contexts per GPU for -d, host threads for -ds)
+    out = tmp_path / "o"
+    for flag in ("-d", "-ds"):
+        r = subprocess.run([EXE, flag, str(out), str(arc)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert out.read_bytes() == data
+    # a container whose table lies about a block's size is refused, not written
+    blob = bytearray(arc.read_bytes())
+    blob[12] ^= 1
+    bad = tmp_path / "bad.bcem"
+    bad.write_bytes(bytes(blob))
+    r = subprocess.run([EXE, "-d", str(out), str(bad)], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "Decompression failed" in r.stdout
