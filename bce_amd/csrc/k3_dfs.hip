@@ -567,7 +567,10 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
 // below it on both sides of the split, which has at least one each; the walked level must end at the next level's node
 // (checked; a mismatch abandons the tail, err 8).
 // ------------------------------------------------------------------------------------------------------
-constexpr uint32_t KD_SPINE_MIN = 64;            // rows from which a wave-walker at plane 0 tries a burst
+#ifndef KD_SPINE_MIN_VALUE
+#define KD_SPINE_MIN_VALUE 64
+#endif
+constexpr uint32_t KD_SPINE_MIN = KD_SPINE_MIN_VALUE;   // rows from which a wave-walker at plane 0 tries a burst
 constexpr uint32_t KD_SPINE_LEVELS = 64;         // byte levels per burst: one lane each
 struct SpineLds {
   uint32_t s[KD_SPINE_LEVELS + 1], x0[KD_SPINE_LEVELS + 1], x1[KD_SPINE_LEVELS + 1];   // the chain's node at plane 0, level by level
