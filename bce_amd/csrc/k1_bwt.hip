@@ -338,9 +338,10 @@ static int k1_sort_rotations(bce_hip_ctx *c, const uint8_t *T, uint32_t n, bool 
     return BCE_HIP_OK;
   };
   const bool trace = getenv("BCE_K1_TRACE") != nullptr;
+  double t_prev = now_s();
   if (trace) fprintf(stderr, "k1 %p: start n %u groups %u\n", (void *)c, n, groups);
   while (groups < n && h < n) {
-    if (trace) fprintf(stderr, "k1 %p: h %llu groups %u m %u list %d\n", (void *)c, (unsigned long long)h, groups, m, (int)have_list);
+    if (trace) { const double t = now_s(); fprintf(stderr, "k1 %p: h %llu groups %u m %u list %d (+%.2f ms)\n", (void *)c, (unsigned long long)h, groups, m, (int)have_list, (t - t_prev) * 1e3); t_prev = t; }
     if (!have_list && (uint64_t)(n - groups) * 10 < (uint64_t)n * K1_ACT_TENTHS + 10) {
       // few elements can still be in non-singleton groups (at most 2 per missing group... bound: n - groups < 0.4 n
       // means at most 0.8 n active): build the explicit list and check its real size
