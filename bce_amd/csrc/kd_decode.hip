@@ -1107,14 +1107,14 @@ struct Mailbox {               // a few host-coherent words the wave tail kernel
 // The very deep tail on the host.  A chain of a few nodes that goes on for millions of rounds (a megabyte run, a
 // whole-file duplicate) costs the wave kernel ~2 us per round -- the latency of one dependent load after the other
 // -- while a CPU core does the same round out of its caches in ~0.1 us.  So once the wave kernel has spent
-// max(kHostTailMin, n / 400) rounds on <= 64 nodes, the boundary ranks (8 x 4(n+1) B) and the node lists come to the host, the rounds
+// max(kHostTailMin, n / 1000) rounds on <= 64 nodes, the boundary ranks (8 x 4(n+1) B) and the node lists come to the host, the rounds
 // are finished here exactly as `bce -ds` runs them (decoder.cpp, BCE::code mode 0, bce.cpp:1246-1371, same decoders),
 // and the ranks go back for the plane fill.  The copies are ~2 x 60 ms per 10^8 bytes.
 __global__ void dec_scatter_kernel(uint32_t *__restrict__ R, const uint64_t *__restrict__ idx, const uint32_t *__restrict__ val, uint64_t m) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) R[idx[i]] = val[i];
 }
 
-constexpr uint32_t kHostTailMin = 50000;                    // ... rounds, or n / 400 if that is more (the copies cost ~n)
+constexpr uint32_t kHostTailMin = 50000;                    // ... rounds, or n / 1000 if that is more (the copies cost ~n)
 
 int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vector<Decoder> &dec, uint32_t n, uint32_t *round,
                   uint64_t *nodes_total, uint64_t *queries_total, bool *bad_out) {
@@ -1298,7 +1298,9 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   if (!getenv("BCE_DEC_NO_MAILBOX")) BCE_TRY(mbox.open(c));
   uint32_t next_seq = 1, last_answered = 0;
   const bool host_tail_ok = !getenv("BCE_DEC_NO_HOST_TAIL");
-  const uint32_t kHostTailAfter = n / 400u > kHostTailMin ? n / 400u : kHostTailMin;
+  // (ski rental: the copies cost ~1.2 ns per input byte, a round ~1.0 us less on the host than in the wave kernel, so the
+  //  switch pays once n / 830 rounds are still to come -- which nobody knows -- and is made after that many have gone by)
+  const uint32_t kHostTailAfter = n / 1000u > kHostTailMin ? n / 1000u : kHostTailMin;
   uint64_t mbox_rounds = 0, launches_wave = 0, launches_wg = 0, rounds_wg = 0;
   double t_wave = 0, t_wg = 0;
   BCE_TRY(ensure(c, c->runs, 64));
