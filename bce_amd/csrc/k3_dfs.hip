@@ -60,6 +60,7 @@ struct DfsCtl {
   uint64_t dbg_cyc[4];   // wave cycles: whole walk, chain-skip comparisons, staircases; [3] = staircase looks
   uint64_t dbg_gen[4];   // wave-walkers: general-path nodes, their cycles, pass-through-loop nodes, their cycles
   uint32_t dbg_spine[4]; // spine bursts: tried, done, byte levels, nodes queued
+  uint32_t dbg_cont[4];  // which boundary's run ended a scan's stretch: B only, E only, both, all lanes fine
   uint32_t dbg_why[8];   // why a burst's chain ended: small node, no c-row in A / B / E, full, run ended at once; [6] scans, [7] levels with x1 < 4
 };
 
@@ -85,6 +86,7 @@ typedef __attribute__((address_space(4))) Granule ConstGranule;
 struct DfsArgs {
   K3Args k;
   const uint8_t *text;
+  const uint8_t *bwt;    // K1's output: bwt[r] = the byte before row r (spine bursts)
   const uint32_t *sa, *isa;
   uint32_t skip_ok;
   DfsCtl *dctl;
@@ -575,6 +577,8 @@ constexpr uint32_t KD_SPINE_LEVELS = 64;         // byte levels per burst: one l
 struct SpineLds {
   uint32_t s[KD_SPINE_LEVELS + 1], x0[KD_SPINE_LEVELS + 1], x1[KD_SPINE_LEVELS + 1];   // the chain's node at plane 0, level by level
   uint32_t c[KD_SPINE_LEVELS];                   // the byte that leads from level i to level i + 1
+  uint32_t pA[64], pB[64], pE[64];               // text positions of the boundary candidates of the current look
+  uint8_t own[64];
   DNode side[8 * KD_SPINE_LEVELS];
 };
 
@@ -588,41 +592,93 @@ __device__ __forceinline__ uint32_t spine_burst(const DfsArgs &a, SpineLds *S, u
   auto rdl = [](uint32_t v, int l) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); };
   const uint64_t lt = (1ull << lane) - 1ull;
   uint32_t L = 0, cs = s, cx0 = x0, cx1 = x1;
+  const uint64_t tph0 = a.dbg ? clock64() : 0;
   if (lane == 0) { S->s[0] = s; S->x0[0] = x0; S->x1[0] = x1; }
+  // number of leading bytes (going backwards from p, capped at 64) on which position p agrees with position pm
+  auto agree = [&](uint32_t p, uint32_t pm) -> uint32_t {
+    if (p >= 64u && pm >= 64u) {
+      uint32_t m = 0;
+#pragma unroll
+      for (uint32_t kq = 0; kq < 16u; ++kq) {
+        const uint32_t d = ld32u(a.text + (p - 4u * kq - 4u)) ^ ld32u(a.text + (pm - 4u * kq - 4u));
+        // (little-endian: the nearest byte is the most significant one)
+        if (m == 4u * kq) m += d ? (uint32_t)__clz((int)d) >> 3 : 4u;
+      }
+      return m;
+    }
+    uint32_t m = 0;
+    while (m < 64u && a.text[cyc_back(p, m + 1u, n)] == a.text[cyc_back(pm, m + 1u, n)]) ++m;
+    return m;
+  };
+  auto wave_max = [](uint32_t v) -> uint32_t {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { const uint32_t w = (uint32_t)__shfl_xor((int)v, o); v = w > v ? w : v; }
+    return v;
+  };
+  // lane <- the first lane i (in lane order) with m_i > lane, i.e. the first candidate that is still in the chain lane + 1
+  // levels down (64 = none): the lanes publish the level ranges they are the first for (prefix maximum), then look up
+  auto first_alive = [&](uint32_t m, volatile uint8_t *own) -> uint32_t {
+    uint32_t pm = m;                                           // inclusive prefix max
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)pm, o); if (lane >= (uint32_t)o && t > pm) pm = t; }
+    uint32_t before = (uint32_t)__shfl_up((int)pm, 1);
+    if (lane == 0) before = 0;
+    own[lane] = 64;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = before; j < m; ++j) own[j] = (uint8_t)lane;   // levels before + 1 .. m: I am the first candidate alive
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t r = own[lane];
+    __builtin_amdgcn_wave_barrier();
+    return r;
+  };
   while (L < KD_SPINE_LEVELS) {
     const uint32_t x = cx0 + cx1;
     if (x < KD_SPINE_MIN) { if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_why[0], 1u); break; }
     if (a.dbg && lane == 0) { atomicAdd(&a.dctl->dbg_why[6], 1u); if (cx1 < 4u) atomicAdd(&a.dctl->dbg_why[7], 1u); }
-    // c: the byte before the middle row of the larger half.  The first c-row of each half and the last c-row of the
-    // node, among 64 rows each.
+    // The chain follows the MIDDLE row of the larger half: c_j = the byte j + 1 positions before it.  A row of the node
+    // is in the chain's node j + 1 levels down iff the j + 1 bytes before it are c_0 .. c_j, and the images keep their
+    // order, so that node is [LF^(j+1)(first such row), LF^(j+1)(last such row)], split at the image of the first such
+    // row of the x1 half -- LF^(j+1) of a row at text position p being the row of position p - (j + 1).  The first / last
+    // such rows are looked for among 64 CANDIDATES each (the first rows of either half, the last rows of the node): a
+    // candidate knows from the 64 bytes before it for how many levels it stays, and per level the first candidate that
+    // is still there is the boundary.  (The rows at the front of a context of zero runs are the run starts: each
+    // stays for as many levels as it has zeros before it, one more than the row before it -- 64 levels from 64 rows.)
     const uint32_t rmid = cx0 >= cx1 ? cs + cx0 / 2u : cs + cx0 + cx1 / 2u;
     const bool vA = lane < cx0, vB = lane < cx1;
-    const uint32_t pM = a.sa[rmid];
+    const uint32_t pM = uni(a.sa[rmid]);
     const uint32_t pA = vA ? a.sa[cs + lane] : 0u, pB = vB ? a.sa[cs + cx0 + lane] : 0u, pE = vB ? a.sa[cs + x - 1u - lane] : 0u;
-    const uint32_t c = uni(a.text[cyc_back(pM, 1u, n)]);
-    const bool hA = vA && a.text[cyc_back(pA, 1u, n)] == c, hB = vB && a.text[cyc_back(pB, 1u, n)] == c,
-               hE = vB && a.text[cyc_back(pE, 1u, n)] == c;
-    const uint64_t bA = __ballot(hA), bB = __ballot(hB), bE = __ballot(hE);
-    if (!bA || !bB || !bE) { if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_why[!bA ? 1 : !bB ? 2 : 3], 1u); break; }
-    const uint32_t PA = rdl(pA, __ffsll((long long)bA) - 1), PB = rdl(pB, __ffsll((long long)bB) - 1), PE = rdl(pE, __ffsll((long long)bE) - 1);
-    // Step i takes the rows at P - (i-1) to the rows at P - i, the first row, the first row of the second half and the last
-    // row of the node one byte level down, if the three are preceded by the SAME byte T[P - i] (that byte is the level's c;
-    // for i = 1 it is the c of the scan).  Lane j: level L + 1 + j, which needs the bytes of lanes 0..j.
+    const uint32_t mA = vA ? agree(pA, pM) : 0u, mB = vB ? agree(pB, pM) : 0u, mE = vB ? agree(pE, pM) : 0u;
     const uint32_t room = KD_SPINE_LEVELS - L;
-    const uint32_t qa = cyc_back(PA, lane + 1u, n), qb = cyc_back(PB, lane + 1u, n), qe = cyc_back(PE, lane + 1u, n);
-    const uint32_t ca = a.text[qa];
-    const bool cont = ca == a.text[qb] && ca == a.text[qe];
-    const uint32_t ia = a.isa[qa], ib = a.isa[qb], ie = a.isa[qe] + 1u;
-    const uint64_t stop = __ballot(!cont);                    // lane j set: the rows' images end before level L + 1 + j
-    uint32_t cnt = stop ? (uint32_t)__ffsll((long long)stop) - 1u : 64u;   // (lane 0 always goes on: its byte is the one the scan found)
-    if (cnt == 0) { if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_why[5], 1u); break; }
-    cnt = cnt < room ? cnt : room;
-    if (lane < cnt) { S->c[L + lane] = ca; S->s[L + 1u + lane] = ia; S->x0[L + 1u + lane] = ib - ia; S->x1[L + 1u + lane] = ie - ib; }
+    uint32_t J = wave_max(mA);
+    { const uint32_t jb = wave_max(mB), je = wave_max(mE); J = J < jb ? J : jb; J = J < je ? J : je; J = J < room ? J : room; }
+    if (J == 0) { if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_why[1], 1u); break; }
+    S->pA[lane] = pA; S->pB[lane] = pB; S->pE[lane] = pE;
+    const uint32_t fa = first_alive(mA, S->own), fb = first_alive(mB, S->own), fe = first_alive(mE, S->own);
+    uint32_t ia = 0, ib = 0, ie = 0, cj = 0;
+    if (lane < J) {                                            // level L + 1 + lane
+      ia = a.isa[cyc_back(S->pA[fa], lane + 1u, n)];
+      ib = a.isa[cyc_back(S->pB[fb], lane + 1u, n)];
+      ie = a.isa[cyc_back(S->pE[fe], lane + 1u, n)] + 1u;
+      cj = a.text[cyc_back(pM, lane + 1u, n)];
+    }
+    // stop before a level at which the chain keeps less than half of its rows: the middle row has left the main branch
+    // (its run has ended); the next look takes a new middle row.  At least one level is taken.
+    const uint32_t xj = ie - ia;
+    uint32_t xprev = (uint32_t)__shfl_up((int)xj, 1);
+    if (lane == 0) xprev = x;
+    const uint64_t thin = __ballot(lane < J && lane > 0 && 2u * xj < xprev);
+    uint32_t cnt = thin ? (uint32_t)__ffsll((long long)thin) - 1u : J;
+    if (cnt == 0) cnt = 1;
+    if (lane < cnt) { S->c[L + lane] = cj; S->s[L + 1u + lane] = ia; S->x0[L + 1u + lane] = ib - ia; S->x1[L + 1u + lane] = ie - ib; }
+    if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_cont[cnt < J ? 0 : 3], 1u);
     cs = rdl(ia, (int)cnt - 1); cx0 = rdl(ib, (int)cnt - 1) - cs; cx1 = rdl(ie, (int)cnt - 1) - cs - cx0;
     L += cnt;
+    __builtin_amdgcn_wave_barrier();
   }
   if (L == 0) return 0;
   __syncthreads();
+  const uint64_t tph1 = a.dbg ? clock64() : 0;
+  if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_why[4], (uint32_t)((tph1 - tph0) >> 10));
   // ---- the eight planes of every level, one lane per level ----
   uint32_t base = 0;
   if (lane == 0) base = atomicAdd(&a.dctl->nsym, 8u * L);
@@ -678,6 +734,7 @@ __device__ __forceinline__ uint32_t spine_burst(const DfsArgs &a, SpineLds *S, u
     for (uint32_t j = lane; j < nside; j += 64u) a.out[o + j] = S->side[j];
   }
   if (lane == 0) atomicAdd(&a.dctl->spine_levels, L);
+  if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_spine[3], (uint32_t)((clock64() - tph1) >> 10));
   next = DNode{S->s[L], S->x0[L], S->x1[L], 0u, round + 8ull * L};
   return L;
 }
@@ -1298,9 +1355,10 @@ retry:
   DfsArgs a;
   a.k = k3_make_args(c, c->round, 0);
   a.text = c->text.as<uint8_t>();
+  a.bwt = c->bwt.as<uint8_t>();
   a.sa = c->sa[c->sa_res].as<uint32_t>();
   a.isa = c->rank.as<uint32_t>();
-  a.skip_ok = (!c->dbg_no_skip && c->k1_valid && c->text.p && c->rank.p) ? 1u : 0u;
+  a.skip_ok = (!c->dbg_no_skip && c->k1_valid && c->text.p && c->rank.p && c->bwt.p) ? 1u : 0u;
   uint32_t *w = reinterpret_cast<uint32_t *>(base);
   a.tkey = w; a.tesc = w + cap; a.ts = w + 2 * (size_t)cap; a.trlo = w + 3 * (size_t)cap; a.trhi = w + 4 * (size_t)cap;
   uint32_t *sk[2] = {reinterpret_cast<uint32_t *>(base + o_sort), reinterpret_cast<uint32_t *>(base + o_sort) + cap};
@@ -1406,8 +1464,8 @@ retry:
       if (h.dbg_gen[0] || h.dbg_gen[2])
         fprintf(stderr, "   wave-walkers so far: %llu general nodes at %.0f cycles each, %llu pass-through-loop nodes at %.0f cycles each\n", (unsigned long long)h.dbg_gen[0],
                 h.dbg_gen[0] ? (double)h.dbg_gen[1] / h.dbg_gen[0] : 0.0, (unsigned long long)h.dbg_gen[2], h.dbg_gen[2] ? (double)h.dbg_gen[3] / h.dbg_gen[2] : 0.0);
-      if (h.dbg_spine[0]) fprintf(stderr, "   spine bursts so far: %u tried, %u done, %u byte levels; ended by: small node %u, no c-row in A %u / B %u / E %u, run over %u; %u scans, %u with x1 < 4\n", h.dbg_spine[0], h.dbg_spine[1], h.dbg_spine[2],
-                                  h.dbg_why[0], h.dbg_why[1], h.dbg_why[2], h.dbg_why[3], h.dbg_why[5], h.dbg_why[6], h.dbg_why[7]);
+      if (h.dbg_spine[0]) fprintf(stderr, "   spine bursts so far: %u tried, %u done, %u byte levels; ended by: small node %u, no c-row in A %u / B %u / E %u, run over %u; %u scans, %u with x1 < 4; K cycles finding the levels %u, walking their planes %u; stretches ended by B %u, by E %u, by both %u, by nothing %u\n", h.dbg_spine[0], h.dbg_spine[1], h.dbg_spine[2],
+                                  h.dbg_why[0], h.dbg_why[1], h.dbg_why[2], h.dbg_why[3], h.dbg_why[5], h.dbg_why[6], h.dbg_why[7], h.dbg_why[4], h.dbg_spine[3], h.dbg_cont[0], h.dbg_cont[1], h.dbg_cont[2], h.dbg_cont[3]);
       fprintf(stderr, "   wave cycles so far: walk %.0f M, chain-skip comparisons %.0f M, staircases %.0f M (%llu looks)\n", h.dbg_cyc[0] * 1e-6,
               h.dbg_cyc[1] * 1e-6, h.dbg_cyc[2] * 1e-6, (unsigned long long)h.dbg_cyc[3]);
       t_pass = now;
