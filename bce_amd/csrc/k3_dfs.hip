@@ -437,6 +437,7 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
   const K3Args &k = a.k;
   const uint32_t n = k.n, x = x0 + x1;
   if (x > KD_STAIRS_MAXX) return 0;
+  const uint64_t tz0 = a.dbg ? clock64() : 0;
   // stride: the smallest distance between neighbouring rows among 64 samples (rows of one region are neighbours
   // almost everywhere; a wrong guess fails the decomposition)
   uint32_t p;
@@ -476,8 +477,10 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
       nS += cs; nE += ce;
     }
   }
+  if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_hist[28], (uint32_t)((clock64() - tz0) >> 10));
   if (nS != nE || nS < 2) return 0;
   const uint32_t nr = nS;
+  const uint64_t tz1 = a.dbg ? clock64() : 0;
   __syncthreads();
   if (lane < nr) {                                            // sort both lists (distinct values): rank by counting
     uint32_t rs = 0, re = 0;
@@ -512,6 +515,8 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
     if (lane == 0) { R->Bv[r] = lce - span; R->D[r] = d; }
   }
   __syncthreads();
+  if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_hist[29], (uint32_t)((clock64() - tz1) >> 10));
+  const uint64_t tz2 = a.dbg ? clock64() : 0;
   // sides: every row is on the side of region 0's first row except, possibly, the regions' last rows
   const uint32_t beta = (a.isa[R->S[0]] - s >= x0) ? 1u : 0u;
   uint32_t nbar = 0;
@@ -550,7 +555,7 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
     next = DNode{smin, beta ? nbar : xb, beta ? xb : nbar, 0u, round + 8ull * tstop};
   }
   nodes_out = 8ull * tstop;
-  if (a.dbg && lane == 0) { atomicAdd(&a.dctl->dbg_stairs, 1u << 16); atomicAdd(&a.dctl->dbg_stairsyms, etot); }
+  if (a.dbg && lane == 0) { atomicAdd(&a.dctl->dbg_stairs, 1u << 16); atomicAdd(&a.dctl->dbg_stairsyms, etot); atomicAdd(&a.dctl->dbg_hist[30], (uint32_t)((clock64() - tz2) >> 10)); }
   return 1;
 }
 
@@ -1481,7 +1486,8 @@ retry:
     fprintf(stderr, "dfs: live %u passes %u err %u nsym %u (cap %u) nodes %llu maxround %llu maxvisited %u skips %u skipbytes %llu stairs %u + %u of several regions (%u symbols)\n", live,
             passes, h.err, h.nsym, cap, (unsigned long long)h.nodes, (unsigned long long)h.maxround, h.dbg_maxvis, h.dbg_skips,
             (unsigned long long)h.dbg_skipbytes, h.dbg_stairs & 0xFFFFu, h.dbg_stairs >> 16, h.dbg_stairsyms);
-    for (int i = 0; i < 32; ++i) if (h.dbg_hist[i]) fprintf(stderr, "  x in [2^%d, 2^%d): %u nodes\n", i, i + 1, h.dbg_hist[i]);
+    for (int i = 0; i < 28; ++i) if (h.dbg_hist[i]) fprintf(stderr, "  x in [2^%d, 2^%d): %u nodes\n", i, i + 1, h.dbg_hist[i]);
+    fprintf(stderr, "  several-region staircases, K cycles: decomposition %u, periodicity %u, sides + events %u\n", h.dbg_hist[28], h.dbg_hist[29], h.dbg_hist[30]);
   }
   if (h.err == 2 && cap64 < left + 64 && cap64 < (512u << 20)) { cap_scale *= 4; goto retry; }   // nothing was modified: once more with more room
   if (h.err) return BCE_HIP_OK;                     // fall back to the rounds; nothing was modified
