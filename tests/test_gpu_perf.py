@@ -35,3 +35,35 @@ def test_megabyte_runs_take_the_closed_forms():
     assert bce_amd.decompress_device(arch) == data
     t_dec = time.time() - t0
     assert t_enc < 10.0 and t_dec < 40.0, "encode %.1f s, decode %.1f s" % (t_enc, t_dec)
+
+
+def test_a_stream_through_three_contexts_beats_one_at_a_time():
+    """The point of gated contexts: the coding tail and K1 of one input overlap the enumeration of another.  On an idle
+    MI355X three contexts move 3 x 10^7-byte inputs at ~1.5x the rate of one context; the limit here only catches
+    the overlap silently not happening (the gate around everything, contexts serialised)."""
+    import numpy as np
+    data = np.frombuffer(oracle.synth_text(31, 30_000_000), dtype=np.uint8)
+    ins = [data] * 9
+
+    def rate(contexts):
+        with bce_amd.ContextPool(contexts, 0) as pool:
+            pool.compress_many(ins[:contexts])                  # warm-up: buffers
+            t0 = time.time()
+            got = pool.compress_many(ins)
+            return len(ins) * len(data) / (time.time() - t0), got
+
+    r1, a1 = rate(1)
+    r3, a3 = rate(3)
+    assert all(bytes(x) == bytes(a1[0]) for x in a1 + a3)
+    assert r3 > 1.1 * r1, "one context %.0f MB/s, three contexts %.0f MB/s" % (r1 / 1e6, r3 / 1e6)
+
+
+def test_spine_bursts_keep_zero_run_contexts_cheap():
+    """10^4 zero runs of up to 4 KB between random bytes: without the bursts the all-zero context is walked node by node by
+    one wave per trie (seconds at this size), with them the whole input takes a fraction of a second."""
+    import numpy as np
+    rng = np.random.RandomState(3)
+    data = b"".join(rng.bytes(int(rng.randint(1, 16))) + bytes(int(rng.randint(1, 4096))) for _ in range(10000))
+    arch, dt = _encode_s(data)
+    assert dt < 10.0, "encode took %.1f s" % dt
+    assert bce_amd.decompress_device(arch) == data
