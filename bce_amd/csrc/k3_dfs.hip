@@ -20,6 +20,11 @@
 //
 // Passes: lane = walker while many nodes are queued; wave = walker (scalar registers, scalar loads, a tight loop
 // over pass-through nodes) once <= KD_UNI_MAX are left.  A walker hands its work on after a.budget nodes.
+//
+// Chains of MANY rows that lose a few rows per byte (the all-zero context of a binary: neither a skip nor a staircase)
+// are taken 64 byte levels at a time by the wave-walkers: spine_burst below.
+//
+// Before the walkers, while more than KD_LOCAL_FROM nodes are alive: workgroup-local rounds (k3_local_kernel).
 #include <stdio.h>
 #include <stdlib.h>
 
