@@ -1447,7 +1447,8 @@ retry:
   while (walkers_next) {
     a.in = in; a.in_count = count; a.out = queue[passes & 1];
     const uint32_t walkers = count < wmax ? count : wmax;
-    if (passes > 0 && count <= KD_UNI_MAX && !getenv("BCE_HIP_DFS_NO_UNI"))   // few walkers left: one WAVE each
+    static const uint32_t uni_max = getenv("BCE_HIP_UNI_MAX") ? (uint32_t)strtoul(getenv("BCE_HIP_UNI_MAX"), nullptr, 10) : KD_UNI_MAX;
+    if (passes > 0 && count <= uni_max && !getenv("BCE_HIP_DFS_NO_UNI"))   // few walkers left: one WAVE each
       hipLaunchKernelGGL(k3_dfs_kernel<true>, dim3(count), dim3(KD_T), 0, c->stream, a);
     else {
       // (fewer walkers per wave -- BCE_HIP_DFS_LPW -- was measured on 62 K walkers: 64 lanes 16.7 ms, 32: 18.3, 16: 20.9, 4: 35.8:
@@ -1463,9 +1464,10 @@ retry:
     BCE_HIP_TRY(c, hipGetLastError());
     jobs_done = h.njobs < KD_JOBS ? h.njobs : KD_JOBS;
     if (a.dbg) {
+      const uint32_t uni_max_dbg = getenv("BCE_HIP_UNI_MAX") ? (uint32_t)strtoul(getenv("BCE_HIP_UNI_MAX"), nullptr, 10) : KD_UNI_MAX;
       const double now = now_s();
       fprintf(stderr, "dfs pass %u: %u walkers%s, %.3f ms, %u queued, %u symbols so far\n", passes, count,
-              (passes > 0 && count <= KD_UNI_MAX) ? " (waves)" : "", (now - t_pass) * 1e3, h.queued, h.nsym);
+              (passes > 0 && count <= uni_max_dbg) ? " (waves)" : "", (now - t_pass) * 1e3, h.queued, h.nsym);
       fprintf(stderr, "   staircase jobs so far: %u\n", jobs_done);
       fprintf(stderr, "   slowest chain-skip comparison so far: %llu K cycles, x = %llu, kk = %llu\n", h.dbg_slow >> 32, (h.dbg_slow >> 20) & 0xFFF, h.dbg_slow & 0xFFFFF);
       fprintf(stderr, "   slowest wave of this pass: %.2f M cycles, of which chain-skip comparisons %.2f M, staircases %.2f M\n",
