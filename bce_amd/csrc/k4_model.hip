@@ -416,7 +416,7 @@ int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   const uint32_t grid = (uint32_t)(gb < 8192 ? gb : 8192);
   hipLaunchKernelGGL(k4_iota_kernel, dim3(grid), dim3(K4_T), 0, ks, nsym, val[0]);
   int res = 0;
-  BCE_TRY(radix_sort_pairs_on(c, ks, own ? c->rs_hist_k4 : c->rs_hist, key, val, nsym, kSymRunShift, kSymRunBits, &res, 8));
+  BCE_TRY(radix_sort_pairs_on(c, ks, own ? c->rs_hist_k4 : c->rs_hist, key, val, nsym, kSymRunShift, kSymRunBits, &res, 10));
   // per-window work arrays, carved from one buffer: histT | stateW | winfo | queue | haltW | qcount
   const size_t nwin = ((size_t)nsym + 63) / 64;
   auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };

@@ -17,7 +17,7 @@ constexpr int RS_THREADS = 256;
 constexpr int RS_ITEMS = 16;
 constexpr int RS_CHUNK = RS_THREADS * RS_ITEMS;  // 4096 keys per block iteration
 constexpr int RS_MAXB = 768;                     // 3 blocks per CU (44 KB of LDS each) x 256 CUs
-constexpr int RS_MAXBITS = 9;                    // digit width per pass (<= 512 bins)
+constexpr int RS_MAXBITS = 10;                   // digit width per pass (<= 1024 bins; K1 uses 9, K4's 19-bit keys 10 + 9)
 constexpr int RS_MAXBINS = 1 << RS_MAXBITS;
 
 struct RsPlan { uint32_t nb, per_block; };
@@ -127,11 +127,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
                                                                 uint32_t per_block, uint32_t nb, int shift, int nbits,
                                                                 const uint32_t *__restrict__ hist,
                                                                 const uint32_t *__restrict__ rowtotal) {
-  __shared__ uint32_t wcnt[4][RS_MAXBINS];     // per-wave digit counts of the chunk, then per-wave local bases
-  __shared__ uint32_t goff[RS_MAXBINS];        // this block's next output position per digit
-  __shared__ uint32_t gdelta[RS_MAXBINS];      // output position - position in the chunk's LDS order (mod 2^32)
+  constexpr int BINS = NBITS > 0 ? (1 << NBITS) : RS_MAXBINS;   // (LDS for the digits this instantiation can see: 3 blocks per CU up to 9 bits)
+  __shared__ uint32_t wcnt[4][BINS];           // per-wave digit counts of the chunk, then per-wave local bases
+  __shared__ uint32_t goff[BINS];              // this block's next output position per digit
+  __shared__ uint32_t gdelta[BINS];            // output position - position in the chunk's LDS order (mod 2^32)
   __shared__ uint32_t skey[RS_CHUNK], sval[RS_CHUNK];
-  constexpr int BPT = RS_MAXBINS / RS_THREADS;  // digits per thread in the per-digit steps
+  constexpr int BPT = (BINS + RS_THREADS - 1) / RS_THREADS;  // digits per thread in the per-digit steps
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
   const uint32_t nbins = 1u << nbits, mask = nbins - 1u;
   // digit bases: exclusive scan of the row totals, plus this block's row offset
@@ -265,6 +266,7 @@ int radix_sort_pairs_on(bce_hip_ctx *c, hipStream_t stream, DevBuf &hbuf, uint32
   hipLaunchKernelGGL(rs_scatter_kernel<NB>, dim3(pl.nb), dim3(RS_THREADS), 0, stream, key[cur], val[cur], key[cur ^ 1], \
                      val[cur ^ 1], n, pl.per_block, pl.nb, (int)shift, nbits, hist, rowtotal)
     switch (nbits) {
+      case 10: RS_SCATTER(10); break;
       case 9: RS_SCATTER(9); break;
       case 8: RS_SCATTER(8); break;
       case 7: RS_SCATTER(7); break;
