@@ -215,7 +215,8 @@ inline double now_s() {
 constexpr uint32_t K3_TAIL_CAP = 1024;        // nodes the tail kernel holds in LDS (all 8 planes together)
 constexpr uint32_t K3_SMALL_MAXTILES = 2048;  // tile table of the one-launch round kernel
 #ifndef K3_SMALL_NODES_VALUE
-#define K3_SMALL_NODES_VALUE 2000000u   // (1/2 M: 19.8 ms of K3 on the natural corpus, 1 M: 19.7, 1.5 M: 19.4, 2 M: 19.3; its tile table holds 2048)
+#define K3_SMALL_NODES_VALUE 2000000u   // (1/2 M: 19.8 ms of K3 on the natural corpus, 1 M: 19.7, 1.5 M: 19.4, 2 M: 19.3; its tile table holds 2048.
+                                        //  With a table of 4096: 3 M 19.5 vs 19.7 in the same run, 4 M 20.5; text 13.0 / 13.1 vs 12.9)
 #endif
 constexpr uint32_t K3_SMALL_NODES = K3_SMALL_NODES_VALUE;   // rounds up to this many nodes use it
 constexpr uint32_t K3_TAIL_ENTER = 512;       // the host switches to the tail kernel at or below this many nodes
