@@ -329,7 +329,7 @@ class ContextPool:
 
         def worker(c):
             try:
-                c.check(c.lib.bce_hip_set_gated(c.h, 1 if len(ctxs) > 1 else 0), "bce_hip_set_gated")
+                c.check(c.lib.bce_hip_set_gated(c.h, 1), "bce_hip_set_gated")
                 while True:
                     with lock:
                         if errors or nxt[0] >= len(inputs):
@@ -347,7 +347,7 @@ class ContextPool:
                 with lock:
                     errors.append(e)
             finally:
-                c.lib.bce_hip_set_gated(c.h, 0)      # (gives the gate back if this context still holds it)
+                c.lib.bce_hip_set_gated(c.h, 1)      # (gives the gate back if this context still holds it)
 
         threads = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
         for t in threads:

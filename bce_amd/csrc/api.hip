@@ -10,6 +10,11 @@
 #include "scan_coder.h"
 
 #include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 using namespace bce;
 
@@ -56,22 +61,44 @@ int check_stage(bce_hip_ctx *c, int need) {
 // model flush, and lend it to the next context whenever they would wait for their own coder threads.
 // (Measured on MI355X, 10^8-byte inputs, two contexts: text 1096 -> 1256 MB/s, natural corpus 1065 -> 1200, binary corpus
 //  921 -> 1095 against a gate around the whole GPU phase; one context at a time: 758 / 887 / 725.)
-struct DeviceGate { std::mutex mu; std::condition_variable cv; bool busy = false; };
+// Between PROCESSES (two `bce -c` on one GPU, a pool beside another program's context) the same rule is kept by an
+// advisory file lock per device, keyed by the PCI address (/dev/shm/bce_hip_gate_<bdf>, flock): taken after the
+// in-process gate, given back with it.  A box without /dev/shm (or without permission) runs without the file lock.
+struct DeviceGate { std::mutex mu; std::condition_variable cv; bool busy = false; int fd = -2; };
 DeviceGate &device_gate(int device) {
   static DeviceGate gates[64];
   return gates[device >= 0 && device < 64 ? device : 0];
 }
+int gate_file(DeviceGate &g, int device) {          // (called with the in-process gate held: one thread at a time)
+  if (g.fd != -2) return g.fd;
+  g.fd = -1;
+  if (getenv("BCE_HIP_NO_FILE_GATE")) return g.fd;
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf - 1, device) != hipSuccess) { (void)hipGetLastError(); snprintf(bdf, sizeof bdf, "dev%d", device); }
+  for (char *q = bdf; *q; ++q) if (*q == ':' || *q == '.' || *q == '/') *q = '_';
+  char path[160];
+  snprintf(path, sizeof path, "/dev/shm/bce_hip_gate_%s", bdf);
+  const mode_t um = umask(0);
+  g.fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+  umask(um);
+  return g.fd;
+}
 void gate_acquire(bce_hip_ctx *c) {
   if (!c->gated || c->gate_held) return;
   DeviceGate &g = device_gate(c->device);
-  std::unique_lock<std::mutex> lk(g.mu);
-  g.cv.wait(lk, [&] { return !g.busy; });
-  g.busy = true;
+  {
+    std::unique_lock<std::mutex> lk(g.mu);
+    g.cv.wait(lk, [&] { return !g.busy; });
+    g.busy = true;
+  }
+  const int fd = gate_file(g, c->device);
+  if (fd >= 0) while (flock(fd, LOCK_EX) != 0 && errno == EINTR) {}
   c->gate_held = true;
 }
 void gate_release(bce_hip_ctx *c) {
   if (!c->gate_held) return;
   DeviceGate &g = device_gate(c->device);
+  if (g.fd >= 0) (void)flock(g.fd, LOCK_UN);
   { std::lock_guard<std::mutex> lk(g.mu); g.busy = false; }
   c->gate_held = false;
   g.cv.notify_one();
@@ -301,7 +328,7 @@ int bce_hip_set_progress(bce_hip_ctx *c, bce_hip_progress_fn fn, void *user) {
 
 int bce_hip_set_gated(bce_hip_ctx *c, int on) {
   if (!c) return BCE_HIP_E_ARG;
-  if (!on) gate_release(c);
+  gate_release(c);                               // either way a gate this context still holds is given back
   c->gated = on != 0;
   return BCE_HIP_OK;
 }
@@ -419,6 +446,7 @@ int bce_hip_enum_round(bce_hip_ctx *c, uint64_t *next_nodes) {
   else BCE_TRY(k3_rounds(c, 1, 0));
   EnumCtl ctl;
   BCE_TRY(k3_sync_ctl(c, &ctl));
+  if (ctl.stalled) { snprintf(c->err, sizeof c->err, "k3: a single-launch round waited too long for a predecessor tile (dispatch order not as assumed)"); return BCE_HIP_E_INTERNAL; }
   if (ctl.overflow) return BCE_HIP_E_OVERFLOW;
   if (ctl.need_flush) return BCE_HIP_E_OVERFLOW;   // the stepping interface never flushes
   BCE_TRY(k3_fetch_runs(c, first, 1));
@@ -567,6 +595,7 @@ static int encode_body(bce_hip_ctx *c) {
       BCE_TRY(k3_fetch_runs(c, first, executed));
     }
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms; }
+    if (ctl.stalled) { snprintf(c->err, sizeof c->err, "k3: a single-launch round waited too long for a predecessor tile (dispatch order not as assumed)"); return BCE_HIP_E_INTERNAL; }
     if (ctl.overflow) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
     c->round = first + executed;
     if (c->progress) c->progress(ctl.nodes_total, 8ull * n, c->progress_user);
@@ -636,19 +665,19 @@ static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes) {
   const uint32_t n = c->n;
   BCE_TRY(k4_prepare(c));
   BCE_TRY(k3_begin(c));
-  std::vector<ScanCoder> coders;
-  for (int i = 0; i < 8; ++i) coders.emplace_back(i);
+  c->stats.t_coder = 0;
+  ScanSet coders;                                          // planes 0-7 + the header coder, on a pool of host threads
   std::vector<uint32_t> host;
   auto consume = [&](uint64_t nsym) -> int {
     if (nsym) {
       host.resize((size_t)nsym * 5);
       BCE_HIP_TRY(c, hipMemcpy(host.data(), c->scanrec.p, (size_t)nsym * 20, hipMemcpyDeviceToHost));
+      std::vector<ScanSpan> spans[8];
       for (int p = 0; p < 8; ++p)
-        for (const RunEntry &e : c->run_log[p])
-          for (uint64_t i = e.start; i < e.start + e.count; ++i) {
-            const uint32_t *r = &host[(size_t)i * 5];
-            coders[p].set(r[0], r[1], r[2], r[3], r[4]);
-          }
+        for (const RunEntry &e : c->run_log[p]) spans[p].push_back(ScanSpan{e.start, e.count});
+      const double t0 = now_s();
+      coders.consume(host.data(), spans);
+      c->stats.t_coder += now_s() - t0;
     }
     return k3_reset_symbols(c);
   };
@@ -670,6 +699,7 @@ static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes) {
       executed = ctl.need_flush ? ctl.skip_round - first : batch;
       BCE_TRY(k3_fetch_runs(c, first, executed));
     }
+    if (ctl.stalled) { snprintf(c->err, sizeof c->err, "k3: a single-launch round waited too long for a predecessor tile (dispatch order not as assumed)"); return BCE_HIP_E_INTERNAL; }
     if (ctl.overflow) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
     c->round = first + executed;
     if (c->progress) c->progress(ctl.nodes_total, 8ull * n, c->progress_user);
@@ -689,13 +719,12 @@ static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes) {
   c->enum_active = false;
   uint8_t init[9][32];
   memset(init, 0, sizeof init);                            // ScanCoder::init_ is a zero-initialised static (:834)
-  for (int i = 0; i < 8; ++i) {                            // coder_[i].flush(), :1135-1138
-    const double r = coders[i].flush(init);
-    if (result_bytes) result_bytes[i] = r;
-  }
-  ScanCoder mainc(-1);                                     // coder_type main(-1), :1141-1149 (its set(s,k) are no-ops)
-  const double rm = mainc.flush(init);
-  if (result_bytes) result_bytes[8] = rm;
+  double res[9];
+  const double tf0 = now_s();
+  coders.flush(init, res);                                 // coder_[i].flush() :1135-1138, then main(-1).flush() :1141-1149
+  c->stats.t_coder += now_s() - tf0;
+  if (getenv("BCE_HIP_SCAN_DEBUG")) fprintf(stderr, "scan: host recording + optimisation %.3f s on %u threads\n", c->stats.t_coder, coders.threads());
+  if (result_bytes) memcpy(result_bytes, res, sizeof res);
   memcpy(config288, init, BCE_HIP_CONFIG_BYTES);
   return BCE_HIP_OK;
 }

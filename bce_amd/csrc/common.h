@@ -46,7 +46,7 @@ struct EnumCtl {
   uint32_t tail_rounds;      // rounds executed by the last k3_tail_kernel launch
   uint32_t small_bail;       // k3_small_kernel: the round (skip_round) does not fit its grid / tile table: run it wide
   uint32_t sm_ticket;        // (unused: k3_small_kernel took its tiles from this counter; one address takes ~88 atomics per us)
-  uint32_t pad2;
+  uint32_t stalled;          // a single-launch round waited K3_SPIN_LIMIT polls for a predecessor tile's word: fatal, loud (see wait_word)
 };
 
 // Pinned host staging of one model flush + the batch descriptor handed to the coder threads.
@@ -74,7 +74,7 @@ struct bce_hip_ctx {
   hipEvent_t ev_k3_batch = nullptr;              // the rounds whose symbols a flush takes are done (main stream)
   hipEvent_t ev_k4_done[2] = {nullptr, nullptr}; // flush f's kernels have read their symbol buffers (k4 stream), f & 1
   bool overlap = false;
-  bool gated = false;                            // bce_hip_set_gated: GPU stages of gated contexts of one device take turns
+  bool gated = true;                             // bce_hip_set_gated: the enumerations of one device's contexts take turns (default on)
   bool gate_held = false;
   uint32_t flush_seq = 0;                        // flushes issued by this context (parity selects ev_k4_done)
   hipEvent_t copy_busy = nullptr;                // last copy out of `sout` (the next K4 must not overwrite it earlier)

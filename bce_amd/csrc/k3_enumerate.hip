@@ -52,8 +52,8 @@ __device__ __forceinline__ void group_prefix(const uint32_t tp[9], uint32_t gp[9
 // Classify the K3_NPT nodes of one thread in PHASES so that the loads of all its nodes are in flight
 // together: (1) the node triples, (2) the two rank granules of every node, (3) the third granule only for
 // the nodes that code a symbol and whose split point falls in neither of the two granules already loaded.
-// (Measured: the kernel is VALU-issue bound, ~250 instructions per node; staging the tile's granule range
-// through LDS was tried and is slower.)
+// (Measured, round 2 SQ counters: latency-bound -- 91 VALU instructions per node, VALU 31 % busy, waves 51 % of their
+// cycles in s_waitcnt; staging the tile's granule range through LDS was tried and is slower.)
 // granule g of a plane: 32-bit byte offset from the plane's (uniform) base -- a plane's directory is < 2^32 bytes
 // (n < 2^31 positions / 96 * 16 B), so the address is base (scalar) + offset (one shift) instead of a 64-bit multiply-add
 __device__ __forceinline__ Granule gran_at(const Granule *G, uint32_t g) {
@@ -337,6 +337,21 @@ __global__ __launch_bounds__(1024) void k3_scan_kernel(K3Args a) {
 __device__ __forceinline__ uint64_t ld_word(const unsigned long long *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Wait for a round-tagged word.  The waits in this file rely on the predecessor's block running or done (in-order
+// dispatch, the device gate of api.hip); if that ever failed -- new firmware, a partition mode, a foreign spinning kernel
+// on the device -- the wait would be a silent GPU hang.  So it is bounded: after K3_SPIN_LIMIT polls (seconds) the
+// round is declared stalled, every later kernel no-ops (overflow flag) and the host returns an error.  The word
+// that comes back then carries the right tag and zero counts: offsets derived from it stay inside the lists.
+constexpr uint32_t K3_SPIN_LIMIT = 1u << 22;
+__device__ __forceinline__ uint64_t wait_word(const unsigned long long *p, int shift, uint64_t epoch, uint64_t w, EnumCtl *ctl) {
+  uint32_t spins = 0;
+  while ((w >> shift) != epoch) {
+    __builtin_amdgcn_s_sleep(1);
+    w = ld_word(p);
+    if (++spins == K3_SPIN_LIMIT) { ctl->stalled = 1; ctl->overflow = 1; return epoch << shift; }
+  }
+  return w;
+}
 __device__ __forceinline__ void st_word(unsigned long long *p, uint64_t v) {
   __hip_atomic_store(p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -395,7 +410,7 @@ __global__ __launch_bounds__(K3_T) void k3_count2_kernel(K3Args a) {
       const uint32_t j = tp[p] + gfirst + tid;
       const bool valid = tid < nin;
       uint64_t wv = 0;
-      if (valid) while (((wv = ld_word(&a.tw[j])) >> 33) != epoch) __builtin_amdgcn_s_sleep(1);
+      if (valid) wv = wait_word(&a.tw[j], 33, epoch, ld_word(&a.tw[j]), ctl);
       const uint64_t v = valid ? ((wv & 0x7FFu) | (((wv >> 11) & 0x7FFu) << 21) | (((wv >> 22) & 0x7FFu) << 42)) : 0ull;
       uint64_t tot;
       const uint64_t ex = block_excl_scan_sum64<K3_T>(v, &tot);
@@ -421,8 +436,9 @@ __global__ __launch_bounds__(K3_T) void k3_count2_kernel(K3Args a) {
           const bool ok = tid < NG;
           uint64_t wa = 0, wb = 0;
           if (ok) {
-            while (((wa = ld_word(&a.gwa[tid])) >> 38) != epoch) __builtin_amdgcn_s_sleep(1);
-            while (((wb = ld_word(&a.gwb[tid])) >> 38) != epoch) __builtin_amdgcn_s_sleep(1);
+            wa = ld_word(&a.gwa[tid]); wb = ld_word(&a.gwb[tid]);
+            wa = wait_word(&a.gwa[tid], 38, epoch, wa, ctl);
+            wb = wait_word(&a.gwb[tid], 38, epoch, wb, ctl);
           }
           const uint64_t v01 = ok ? ((wa & 0x7FFFFu) | (((wa >> 19) & 0x7FFFFu) << 32)) : 0ull;
           const uint32_t vs = ok ? (uint32_t)(wb & 0x7FFFFu) : 0u;
@@ -458,8 +474,9 @@ __global__ __launch_bounds__(K3_T) void k3_count2_kernel(K3Args a) {
             const bool ok = i < gp[q + 1];
             uint64_t wa = 0, wb = 0;
             if (ok) {
-              while (((wa = ld_word(&a.gwa[i])) >> 38) != epoch) __builtin_amdgcn_s_sleep(1);
-              while (((wb = ld_word(&a.gwb[i])) >> 38) != epoch) __builtin_amdgcn_s_sleep(1);
+              wa = ld_word(&a.gwa[i]); wb = ld_word(&a.gwb[i]);
+              wa = wait_word(&a.gwa[i], 38, epoch, wa, ctl);
+              wb = wait_word(&a.gwb[i], 38, epoch, wb, ctl);
             }
             const uint64_t v01 = ok ? ((wa & 0x7FFFFu) | (((wa >> 19) & 0x7FFFFu) << 32)) : 0ull;
             const uint32_t vs = ok ? (uint32_t)(wb & 0x7FFFFu) : 0u;
@@ -606,7 +623,7 @@ __global__ __launch_bounds__(K3_T) void k3_small_kernel(K3Args a, unsigned long 
       for (int q = 0; q < LB; ++q) {
         const uint32_t j = tid + (uint32_t)q * K3_T;
         if (j < tile) {
-          while ((wv[q] >> 33) != epoch) { __builtin_amdgcn_s_sleep(1); wv[q] = ld_word(&words[j]); }
+          wv[q] = wait_word(&words[j], 33, epoch, wv[q], ctl);
           cs += (wv[q] >> 22) & 0x7FFu;
           if (j >= tp[p]) { c0 += wv[q] & 0x7FFu; c1 += (wv[q] >> 11) & 0x7FFu; }
         }
@@ -632,7 +649,7 @@ __global__ __launch_bounds__(K3_T) void k3_small_kernel(K3Args a, unsigned long 
       const uint32_t j = tid + (uint32_t)q * K3_T;
       if (j < T) {
         const uint32_t p = tile_plane(tp, j);
-        while ((wv[q] >> 33) != epoch) { __builtin_amdgcn_s_sleep(1); wv[q] = ld_word(&words[j]); }
+        wv[q] = wait_word(&words[j], 33, epoch, wv[q], ctl);
         // per-plane totals fit 21-bit fields: a plane's children / symbols number at most its nodes < 2^21 (checked: M)
         atomicAdd(&s_tot[p], (unsigned long long)((wv[q] & 0x7FFu) | (((wv[q] >> 11) & 0x7FFu) << 21) | (((wv[q] >> 22) & 0x7FFu) << 42)));
       }

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <exception>
 #include <fstream>
 #include <string>
 #include <algorithm>
@@ -67,7 +68,6 @@ static int compress_blocks(const std::vector<uint8_t> &data, uint32_t nblocks, c
       for (bce_hip_ctx *o : ctx) bce_hip_destroy(o);
       return -1;
     }
-    (void)bce_hip_set_gated(ctx[i], ctx.size() > (size_t)ndev ? 1 : 0);
   }
   const size_t n = data.size(), base = n / nblocks, rem = n % nblocks;
   std::vector<std::vector<uint8_t>> arch(nblocks);
@@ -87,7 +87,7 @@ static int compress_blocks(const std::vector<uint8_t> &data, uint32_t nblocks, c
         if (rc == 0) { arch[b].resize(alen); rc = bce_hip_archive_copy(ctx[d], arch[b].data(), alen); }
         if (rc) { rcs[d] = rc; failed.store(true); break; }
       }
-      (void)bce_hip_set_gated(ctx[d], 0);                           // (gives the gate back if a failed stage left it held)
+      (void)bce_hip_set_gated(ctx[d], 1);                           // (gives the gate back if a failed stage left it held)
     });
   for (auto &t : th) t.join();
   int rc = 0;
@@ -253,9 +253,26 @@ int main(int argc, char **argv) {
     } else {
       // a container: the blocks are independent, their sizes are in the table -- decoded side by side, two contexts per GPU
       // (a block's decoding is mostly its eight sequential range decoders on the host) or, for -ds, up to 8 host threads
+      // The table's raw sizes are untrusted 64-bit values: each must be what the block's own header says (asked without
+      // an output buffer: the header is parsed, nothing is written), at least one byte and below the encoder's 2^31 limit,
+      // and the output is sized from the verified values only -- a wrapping or oversized table is "Could not read Archive".
       std::vector<size_t> at(blocks.size() + 1, 0);
-      for (size_t b = 0; b < blocks.size(); ++b) at[b + 1] = at[b] + (size_t)get_le(adata.data() + 12 + b * 16, 8);
-      out.resize(at.back());
+      for (size_t b = 0; b < blocks.size(); ++b) {
+        const uint64_t raw = get_le(adata.data() + 12 + b * 16, 8);
+        size_t hn = 0;
+        const int hr = bce_hip_decompress(adata.data() + blocks[b].first, blocks[b].second, nullptr, 0, &hn);
+        if (hr != 0 || raw < 1 || raw >= 0x80000000ull || (uint64_t)hn != raw || raw > SIZE_MAX - at[b]) {
+          printf("Could not read Archive.\n");
+          return -2;
+        }
+        at[b + 1] = at[b] + (size_t)raw;
+      }
+      try {
+        out.resize(at.back());
+      } catch (const std::exception &) {
+        printf("Could not read Archive.\n");
+        return -2;
+      }
       std::vector<bce_hip_ctx *> ctxs;
       if (use_gpu) {
         int ndev = 0;

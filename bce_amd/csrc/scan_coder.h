@@ -1,10 +1,16 @@
 // scan_coder.h -- `bce -s`: ScanCoder<31> (bce.cpp:726-834), the policy that records every coded symbol and
 // picks, per plane and per range size k, the number of context bits that minimises the simulated adaptive cost.
 // Host C++ (SURVEY section 8f "next #2"): the enumeration that feeds it runs on the GPU (K1-K3 in scan mode),
-// the optimisation itself is a small host computation.  The result must equal the reference's byte for byte,
+// the optimisation itself is a host computation.  The result must equal the reference's byte for byte,
 // which pins two implementation details: the symbols are kept in a
 // std::unordered_map<uint32_t, std::vector<uint8_t>> filled in stream order (its iteration order decides the
 // order of the double additions) and the cost is accumulated in double with log().
+//
+// What is NOT pinned is who does the work.  In the reference's flush every (k, j) pair owns its accumulator z and
+// its counter table, and only `z_ += z_min` is ordered over k (bce.cpp:754-796); stat_[k] of different k (and of
+// different coders) never meet.  So recording is split by (coder, class of k) and the optimisation by (coder, k, j)
+// over a pool of host threads (ScanSet below), every map keeping its insertion sequence and every sum its order:
+// the same bytes as the sequential reference, ~10 s -> ~1 s per 10^8 input bytes.
 #pragma once
 #include <stdint.h>
 
@@ -16,15 +22,44 @@ namespace bce {
 
 class ScanCoder {
  public:
-  explicit ScanCoder(int i) : z_(0), i_(i < 0 || i > 7 ? 8 : i) {}             // :733
-  void set(uint32_t s, uint32_t k, uint32_t c1, uint32_t c2, uint32_t cs);    // :737-744
+  explicit ScanCoder(int i) : nesc_(0), z_(0), i_(i < 0 || i > 7 ? 8 : i) {}    // :733
+  void set(uint32_t s, uint32_t k, uint32_t c1, uint32_t c2, uint32_t cs);     // :737-744 (sequential form)
   // :751-800; writes row i_ of `init` (entries never improved keep their value), returns the "Result size" in bytes
   double flush(uint8_t init[9][32]);
 
+  // ---- the pieces ScanSet runs side by side ----
+  static constexpr int kClasses = 4;                       // k = 2 | k = 3 | 4..7 | 8..31 (after the escape loop)
+  static int class_of(uint32_t k) { return k == 2 ? 0 : k == 3 ? 1 : k < 8 ? 2 : 3; }
+  // set() for ONE class of k: the escape loop runs for every record (it decides the class), the record is kept only if
+  // its final k is of class `cls`; the thread of class 0 also counts the escapes (z_ += log(2) each, :739)
+  void set_class(uint32_t s, uint32_t k, uint32_t c1, uint32_t c2, uint32_t cs, int cls);
+  double base_cost(uint32_t k) const;                      // z_min before any j (:757)
+  double trial_cost(uint32_t k, uint32_t j) const;         // z of context bits j (:759-785)
+  uint64_t symbols(uint32_t k) const;                      // records kept for k (task weights)
+  // the ordered part of flush (:786-797) from the costs computed above
+  double finish(uint8_t init[9][32], const double base[32], const double trial[32][6]);
+
  private:
   std::array<std::unordered_map<uint32_t, std::vector<uint8_t>>, 32> stat_;
+  std::array<std::vector<std::vector<uint8_t> *>, 32> fast_;   // set_class: key -> its vector in stat_[k]
+  uint64_t nesc_;          // escapes seen by set_class (each is one `z_ += log(2)`, added in order by finish)
   double z_;
   int i_;
+};
+
+// The nine coders of one `bce -s` run (planes 0-7 and the header coder, whose set(s, k) is a no-op: bce.cpp:745-749).
+struct ScanSpan { uint64_t start, count; };                // records [start, start + count) of the flush buffer, in stream order
+class ScanSet {
+ public:
+  explicit ScanSet(unsigned threads = 0);                  // 0 = the CPUs this process may run on, at most 32
+  // records = 5 x u32 (s, k, c1, c2, cs); spans[p] = plane p's runs of this buffer in stream order
+  void consume(const uint32_t *records, const std::vector<ScanSpan> spans[8]);
+  void flush(uint8_t init[9][32], double result_bytes[9]);
+  unsigned threads() const { return threads_; }
+
+ private:
+  std::vector<ScanCoder> coders_;
+  unsigned threads_;
 };
 
 }  // namespace bce

@@ -46,10 +46,13 @@ int bce_hip_set_config(bce_hip_ctx *ctx, const uint8_t *config288);
 /* Several contexts on ONE device (a stream of files or blocks, `bce -cN` with more blocks than GPUs): a compression is a
  * GPU phase followed by a host phase in which the eight coder threads finish the last batches, so contexts driven by
  * one host thread each overlap one's coding -- and one's rotation sort -- with the other's enumeration.  Gated contexts
- * (on != 0) of a device take turns for the ENUMERATION (its single-launch rounds must not run beside another context's):
+ * of a device take turns for the ENUMERATION (its single-launch rounds must not run beside another context's):
  * bce_hip_encode / bce_hip_scan take the device's gate, give it back when the last model flush is queued or when they
- * fail, and lend it to the next context while they wait for their own coder threads; bce_hip_destroy and on = 0 give it
- * back too.  Ungated contexts (default) ignore the gate: do not encode with them beside gated ones on the same device. */
+ * fail, and lend it to the next context while they wait for their own coder threads; bce_hip_destroy and this call (with
+ * either value) give it back too.  Every context is gated by default (an uncontended gate costs nothing); contexts of
+ * other PROCESSES on the same device are kept apart by an advisory file lock keyed by the device's PCI address
+ * (/dev/shm/bce_hip_gate_<bdf>; BCE_HIP_NO_FILE_GATE=1 switches that part off).  on = 0 opts a context out: only for
+ * a context that is alone on its device. */
 int bce_hip_set_gated(bce_hip_ctx *ctx, int on);
 /* capacity (in symbol records) of the device symbol buffer between model flushes; 0 = automatic */
 int bce_hip_set_symbol_capacity(bce_hip_ctx *ctx, uint64_t records);
@@ -141,7 +144,8 @@ int bce_hip_enum_model(bce_hip_ctx *ctx, uint32_t *out, uint64_t cap_records, ui
  * of the nine "Result size: %.1f B" lines (bce.cpp:799). */
 int bce_hip_scan(bce_hip_ctx *ctx, uint8_t config288[BCE_HIP_CONFIG_BYTES], double result_bytes[9]);
 
-/* ---- decoder (SURVEY section 8f "next #1"; host C++ this round, not a GPU path) ------------------------------ */
+/* ---- decoder (SURVEY section 8f "next #1"): bce_hip_decompress = plain host C++ (`bce -ds`),
+ *      bce_hip_decompress_device = the GPU-assisted decoder of kd_decode.hip (`bce -d`); same bytes ---------------- */
 /* BCE::decode + unbwt::bytewise + inverse BWT + rotate (bce.cpp:1169-1233, 1043-1102): archive -> original bytes.
  * out == NULL: only report the decoded size in *out_len.  Needs no context and no GPU. */
 int bce_hip_decompress(const uint8_t *archive, size_t len, uint8_t *out, size_t cap, size_t *out_len);

@@ -146,3 +146,49 @@ extern "C" uint64_t emul_check_recip(uint64_t seed, uint64_t samples_per_divisor
   }
   return bad;
 }
+
+// `bce -s` host part (scan_coder.cpp): symbol tuples (plane, s, k, c1, c2, cs) in the oracle's call order -> the 288-byte
+// table + the nine "Result size" values.  threads = 0: the sequential ScanCoder::set / flush; else ScanSet on that many
+// threads, fed in `chunks` consume() calls (as the flushes of bce_hip_scan feed it).
+#include "../bce_amd/csrc/scan_coder.h"
+#include <stdio.h>
+#include <chrono>
+static double emul_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+extern "C" int emul_scan(const uint32_t *syms6, size_t nsym, unsigned threads, unsigned chunks, uint8_t *config288, double *result9) {
+  uint8_t init[9][32];
+  memset(init, 0, sizeof init);
+  if (threads == 0) {
+    std::vector<ScanCoder> coders;
+    for (int i = 0; i < 8; ++i) coders.emplace_back(i);
+    for (size_t t = 0; t < nsym; ++t) { const uint32_t *r = syms6 + 6 * t; coders[r[0]].set(r[1], r[2], r[3], r[4], r[5]); }
+    const double t1 = emul_now();
+    for (int i = 0; i < 8; ++i) result9[i] = coders[i].flush(init);
+    if (getenv("EMUL_TIMING")) fprintf(stderr, "emul_scan: sequential flush %.3f s\n", emul_now() - t1);
+    ScanCoder mainc(-1);
+    result9[8] = mainc.flush(init);
+  } else {
+    ScanSet set(threads);
+    double t_cons = 0;
+    if (chunks == 0) chunks = 1;
+    for (unsigned ch = 0; ch < chunks; ++ch) {
+      const size_t lo = nsym * ch / chunks, hi = nsym * (ch + 1) / chunks;
+      std::vector<uint32_t> rec((hi - lo) * 5);
+      std::vector<ScanSpan> spans[8];
+      // lay the chunk out plane by plane (any layout will do: the spans say where a plane's records are, in stream order)
+      size_t w = 0;
+      for (int p = 0; p < 8; ++p) {
+        const size_t w0 = w;
+        for (size_t t = lo; t < hi; ++t) { const uint32_t *r = syms6 + 6 * t; if ((int)r[0] == p) { memcpy(&rec[w * 5], r + 1, 20); ++w; } }
+        if (w > w0) { const size_t mid = w0 + (w - w0) / 2; spans[p].push_back(ScanSpan{w0, mid - w0}); spans[p].push_back(ScanSpan{mid, w - mid}); }
+      }
+      const double t0 = emul_now();
+      set.consume(rec.data(), spans);
+      t_cons += emul_now() - t0;
+    }
+    const double t1 = emul_now();
+    set.flush(init, result9);
+    if (getenv("EMUL_TIMING")) fprintf(stderr, "emul_scan: consume %.3f s, flush %.3f s\n", t_cons, emul_now() - t1);
+  }
+  memcpy(config288, init, 288);
+  return 0;
+}

@@ -15,7 +15,8 @@ from conftest import ROOT, edge_inputs
 def emul():
     out = os.path.join(ROOT, "tests", "_build", "libcore_emul.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    srcs = [os.path.join(ROOT, "tests", "core_emul.cpp"), os.path.join(ROOT, "bce_amd", "csrc", "host_coder.cpp")]
+    srcs = [os.path.join(ROOT, "tests", "core_emul.cpp"), os.path.join(ROOT, "bce_amd", "csrc", "host_coder.cpp"),
+            os.path.join(ROOT, "bce_amd", "csrc", "scan_coder.cpp")]
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out] + srcs + ["-lpthread"])
     L = C.CDLL(out)
     L.emul_encode_from_bwt.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p),
@@ -24,6 +25,7 @@ def emul():
     L.emul_free.argtypes = [C.c_void_p]
     L.emul_check_recip.argtypes = [C.c_uint64, C.c_uint64]
     L.emul_check_recip.restype = C.c_uint64
+    L.emul_scan.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]
     return L
 
 
@@ -126,3 +128,25 @@ def test_context_index_u32_wrap_matches_reference(emul):
         b = int(rs.randint(1 << 26, (1 << 31) - 1))
         a = int(rs.randint(0, min((1 << 32) - 1, 32 * b - 1)))
         assert emul.emul_small_quotient(a, b) == a // b
+
+
+@pytest.mark.parametrize("gen,seed,n", [("synth_text", 1, 1 << 20), ("synth_rand", 5, 150000), ("synth_text", 9, 70000)])
+def test_scan_coder_sequential_and_threaded_equal_the_oracle(emul, gen, seed, n):
+    """`bce -s` host part (scan_coder.cpp): ScanCoder::set / flush and the threaded ScanSet (recording split by plane and
+    class of k, optimisation by (coder, k, j)) give the oracle's 288-byte table and the SAME doubles for the nine
+    "Result size" lines -- the order of every floating-point sum is kept.  synth-text 1 MiB is the
+    vector whose .bcc hash SURVEY 8c records."""
+    import hashlib
+    data = getattr(oracle, gen)(seed, n)
+    cfg, res = oracle.scan(data)
+    bwt, off = oracle.bwt_stage(data)
+    syms = np.ascontiguousarray(oracle.trace_encode_from_bwt(bwt, off)["syms"], dtype=np.uint32)   # plane, s, k, c1, c2, cs
+    if gen == "synth_text" and n == 1 << 20:
+        h = hashlib.sha256(cfg).hexdigest()
+        assert h.startswith("7f7c243b") and h.endswith("4cea2f")
+    for threads, chunks in ((0, 1), (1, 1), (5, 3), (16, 7)):
+        out = np.zeros(288, dtype=np.uint8)
+        r9 = np.zeros(9, dtype=np.float64)
+        emul.emul_scan(syms.ctypes.data, len(syms), threads, chunks, out.ctypes.data, r9.ctypes.data)
+        assert out.tobytes() == cfg, (threads, chunks)
+        assert list(r9) == res, (threads, chunks)

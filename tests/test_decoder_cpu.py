@@ -63,3 +63,34 @@ def test_cli_decompress(tmp_path):
         out.unlink()
         r = subprocess.run([exe, "-d", str(out), str(arc)], capture_output=True, text=True)
         assert r.returncode == 253 and "No usable HIP device" in r.stdout and not out.exists()
+
+
+def test_cli_container_with_hostile_size_table(tmp_path):
+    """A BCEM container's raw sizes are untrusted: wrapping (2^64 - k), oversized (>= 2^31), zero, or merely wrong values
+    must end in a clean "Could not read Archive." (exit -2), never in a write outside the output or an abort
+    (main.cpp, -d branch).  -ds runs on the host, so this needs no GPU."""
+    from bce_amd import container
+    exe = os.path.join(ROOT, "bce_amd", "bin", "bce")
+    parts = [oracle.synth_text(21, 3000), oracle.synth_text(22, 200)]
+    archives = [oracle.compress(p) for p in parts]
+    out = tmp_path / "o"
+    good = tmp_path / "good.bcem"
+    good.write_bytes(container.pack_blocks(archives, [len(p) for p in parts]))
+    r = subprocess.run([exe, "-ds", str(out), str(good)], capture_output=True, text=True)
+    assert r.returncode == 0 and out.read_bytes() == b"".join(parts)
+    tables = [
+        [2**64 - 100, 200],            # the sum wraps to 100: block 0 would be written into a 100-byte buffer
+        [2**64 - 3000 + 200 - 200, 200],
+        [3000, 2**64 - 3000],          # sum wraps to 0
+        [2**31, 200],                  # above the encoder's limit
+        [2**40, 200],                  # resize would throw
+        [0, 200],
+        [3001, 200], [2999, 200], [3000, 201],
+    ]
+    for t in tables:
+        out.unlink(missing_ok=True)
+        bad = tmp_path / "bad.bcem"
+        bad.write_bytes(container.pack_blocks(archives, t))
+        r = subprocess.run([exe, "-ds", str(out), str(bad)], capture_output=True, text=True)
+        assert r.returncode == 254 and "Could not read Archive." in r.stdout, (t, r.returncode, r.stdout, r.stderr)
+        assert not out.exists()

@@ -106,4 +106,12 @@ def test_cli_many_blocks_on_few_gpus(tmp_path):
     bad = tmp_path / "bad.bcem"
     bad.write_bytes(bytes(blob))
     r = subprocess.run([EXE, "-d", str(out), str(bad)], capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "Decompression failed" in r.stdout
+    assert r.returncode == 254 and "Could not read Archive." in r.stdout
+    # wrapping / oversized tables (tests/test_decoder_cpu.py runs the whole list through -ds): the GPU path refuses them too
+    import struct
+    for raw0 in (2**64 - 100, 2**31, 2**40):
+        blob = bytearray(arc.read_bytes())
+        blob[12:20] = struct.pack("<Q", raw0)
+        bad.write_bytes(bytes(blob))
+        r = subprocess.run([EXE, "-d", str(out), str(bad)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 254 and "Could not read Archive." in r.stdout, (raw0, r.stdout, r.stderr)

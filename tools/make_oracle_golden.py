@@ -36,6 +36,13 @@ JOBS = [
     ("binary-1e8", "binary", 100_000_000),
     ("natural-16Mi", "natural", 16 << 20),
     ("binary-16Mi", "binary", 16 << 20),
+    # BASELINE configs[2] stand-in (enwik9-sized): the only size at which bits = 3, 4 of get_context wrap (bce.cpp:674,
+    # c1 >= 2^29 / 2^28) and getv's 31-bit path (:374) matters.  ~8 min, ~13 GB.
+    ("synth-text-1e9", "synth_text", 1_000_000_000),
+    # BASELINE configs[4] stand-in (Silesia-sized, mixed): natural corpus || binary corpus, compressed with the table
+    # `bce -s` (oracle.scan) finds for it.  The 288-byte table itself is stored so that compress parity can be checked
+    # apart from scan parity.
+    ("mixed-2e8-scanned", "mixed", 200_000_000),
 ]
 
 
@@ -50,36 +57,50 @@ def corpus(kind, n, cache="/tmp"):
 def make_input(kind, n):
     if kind in ("synth_text", "synth_rand"):
         return np.frombuffer(getattr(oracle, kind)(1, n), dtype=np.uint8)
+    if kind == "mixed":
+        return np.concatenate([corpus("natural", n // 2), corpus("binary", n - n // 2)])
     return corpus(kind, n)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*")
+    ap.add_argument("--out", default=OUT, help="JSON to update (default: tests/golden/oracle_fullsize.json)")
     a = ap.parse_args()
     oracle.build()
     oracle.set_threads(1)
     res = {}
-    if os.path.exists(OUT):
-        res = {v["name"]: v for v in json.load(open(OUT))["vectors"]}
+    if os.path.exists(a.out):
+        res = {v["name"]: v for v in json.load(open(a.out))["vectors"]}
     for name, kind, n in JOBS:
         if a.only and name not in a.only:
             continue
         data = make_input(kind, n)
         assert len(data) == n, (name, len(data))
+        extra = {}
+        cfg = None
+        if kind == "mixed":
+            t0 = time.time()
+            cfg, sizes = oracle.scan(data)
+            extra = {"config_hex": cfg.hex(), "config_sha256": hashlib.sha256(cfg).hexdigest(),
+                     "scan_result_sizes": sizes, "oracle_scan_seconds": round(time.time() - t0, 1)}
         t0 = time.time()
-        arch = oracle.compress(data)
+        arch = oracle.compress(data, cfg)
         dt = time.time() - t0
         res[name] = {"name": name, "kind": kind, "seed": 1 if kind.startswith("synth") else None, "n": n,
                      "input_sha256": hashlib.sha256(data.tobytes()).hexdigest(),
                      "archive_bytes": len(arch), "archive_sha256": hashlib.sha256(arch).hexdigest(),
-                     "oracle_seconds_1_thread": round(dt, 1)}
+                     "oracle_seconds_1_thread": round(dt, 1), **extra}
         print(json.dumps(res[name]), flush=True)
         doc = {"provenance": "oracle/bce_oracle.c (CPU restatement of bce -c, single thread) run by tools/make_oracle_golden.py; "
                              "no GPU code involved.  The natural/binary corpora are built from the files of this container image, so "
                              "their input_sha256 only matches on a box with the same image (tests skip otherwise).",
                "vectors": [res[k] for k in sorted(res)]}
-        with open(OUT, "w") as f:
+        if os.path.exists(a.out):       # another job may have added vectors meanwhile
+            for v in json.load(open(a.out))["vectors"]:
+                res.setdefault(v["name"], v)
+            doc["vectors"] = [res[k] for k in sorted(res)]
+        with open(a.out, "w") as f:
             json.dump(doc, f, indent=1)
             f.write("\n")
 
