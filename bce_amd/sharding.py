@@ -44,6 +44,21 @@ def _parse_cpulist(text):
     return cpus
 
 
+def format_cpulist(cpus):
+    """{0,1,2,3,8} -> "0-3,8" (the kernel's cpulist notation)."""
+    out, run = [], []
+    for c in sorted(cpus):
+        if run and c == run[-1] + 1:
+            run.append(c)
+        else:
+            if run:
+                out.append(run)
+            run = [c]
+    if run:
+        out.append(run)
+    return ",".join("%d" % r[0] if len(r) == 1 else "%d-%d" % (r[0], r[-1]) for r in out)
+
+
 def pin_to_local_numa(device_index):
     """Restrict this process (and the threads it starts afterwards: the context's 8 range-coder threads) to the CPUs of
     the NUMA node the GPU hangs off, so that 8 ranks x 9 host threads do not wander over both sockets.  Call before the

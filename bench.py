@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 import bce_amd  # noqa: E402
 from bce_amd import sharding  # noqa: E402
 
+REF_ENCODE_RATIO = 1.82  # reference encode-stage seconds / oracle encode-stage seconds (BASELINE.md, round 3 calibration)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 K3_KERNELS = ("K3 interval-count (k3_count2_kernel + k3_tiles_kernel<write> for wide rounds, k3_small_kernel for narrow ones, "
               "k3_local_kernel / k3_dfs_kernel / k3_tail_kernel for the ends; all rounds of one compression = one launch unit)")
@@ -53,10 +54,11 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-stream", action="store_true", help="skip the two-context stream leg (N=1 only)")
     ap.add_argument("--stream-contexts", type=int, default=3, help="contexts of the stream leg")
-    ap.add_argument("--stream-steps", type=int, default=0, help="inputs of the stream leg (default: max(4, --steps))")
+    ap.add_argument("--stream-steps", type=int, default=0, help="inputs of the stream leg (default: max(12, --steps); 12 for the extra workloads)")
     ap.add_argument("--no-decode", action="store_true", help="skip the untimed decode-and-compare leg (N=1 only)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (H2D inside) leg")
     ap.add_argument("--no-workloads", action="store_true", help="skip the extra workloads (natural / binary corpus, synth-rand)")
+    ap.add_argument("--no-big", action="store_true", help="skip the 10^9-byte and the scanned 2x10^8-byte workloads (BASELINE configs 3 and 5)")
     ap.add_argument("--scan-config", action="store_true",
                     help="BASELINE config 5: run `bce -s` on the input first (untimed), compress with the scanned table")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -128,11 +130,11 @@ def stream_leg(pool, t_in, n, steps, arch, config=None):
     ts = time.perf_counter() - t0
     return {"value": round(n * steps / ts / 1e6, 3), "unit": "MB/s", "steps": steps, "ms_per_step": round(ts / steps * 1e3, 2), "contexts": nctx,
             "identical_to_headline": bool(all(bytes(a) == bytes(arch) for a, _ in res)),
-            "k3_ms_per_step": round(sum(s_["t_enum"] for _, s_ in res) / steps * 1e3, 3),
+            "k3_ms_per_step": round(sum(s_["k3_ms"] for _, s_ in res) / steps, 3),
             "coder_busy_ms": round(max(s_["t_coder_busy"] for _, s_ in res) * 1e3, 1)}
 
 
-def extra_workloads(ctx, dev, table, pool=None, stream_steps=12):
+def extra_workloads(ctx, dev, table, pool=None, stream_steps=12, decode=True):
     """The same measurement (input resident in HBM, 2 steps after 1 warm-up) on harder inputs."""
     out = []
     specs = [("natural corpus v2 (tools/make_corpus.py: this image's Python sources + ROCm headers; long repeats, ~2 M rounds)", "natural", 100_000_000),
@@ -161,7 +163,18 @@ def extra_workloads(ctx, dev, table, pool=None, stream_steps=12):
             del t_in
             r = roofline(n, sts)
             st = sts[-1]
-            out.append({"workload": desc, "bytes": n, "input_sha256": hashlib.sha256(data.tobytes()).hexdigest()[:16],
+            dec = None
+            if decode:
+                try:
+                    t0 = time.perf_counter()
+                    back = bce_amd.decompress_device(arch, ctx=ctx)
+                    td = time.perf_counter() - t0
+                    dec = {"seconds": round(td, 3), "value": round(n / td / 1e6, 2), "unit": "MB/s",
+                           "roundtrip_identical": bool(len(back) == n and hashlib.sha256(back).digest() == hashlib.sha256(data.tobytes()).digest())}
+                    del back
+                except Exception as e:
+                    dec = {"error": "%s: %s" % (type(e).__name__, e)}
+            out.append({"workload": desc, "decode": dec, "bytes": n, "input_sha256": hashlib.sha256(data.tobytes()).hexdigest()[:16],
                         "value": round(n * 2 / dt / 1e6, 3), "unit": "MB/s", "ms_per_step": round(dt / 2 * 1e3, 2),
                         "k3_ms": r["k3_ms_per_step"], "roofline_frac": r["frac"], "rounds": st["rounds"], "symbols": st["symbols"],
                         "sort_rounds": st["sort_rounds"], "k1_ms": round(st["t_bwt"] * 1e3, 2), "k4_ms": round(st["t_model"] * 1e3, 2),
@@ -173,6 +186,85 @@ def extra_workloads(ctx, dev, table, pool=None, stream_steps=12):
     return out
 
 
+def big_workload(local, dev, table, n=1_000_000_000):
+    """BASELINE configs[2] stand-in: 10^9 bytes of synth-text v1 seed 1 on ONE GPU, everything resident in HBM (SA and
+    rank arrays 36 n, node lists, symbol records).  1 warm-up + 1 timed step in a context of its own (closed afterwards:
+    its buffers are ~70 GB).  The archive is pinned to the ORACLE's (tests/golden/oracle_fullsize.json, synth-text-1e9:
+    the only size at which bits = 3, 4 of get_context wrap, bce.cpp:674)."""
+    desc = "synth-text v1 seed 1, 10^9 B (enwik9-sized stand-in, BASELINE configs[2])"
+    try:
+        data = bce_amd.synth_text(1, n)
+        t_in = torch.from_numpy(data).to(dev)
+        torch.cuda.synchronize()
+        ctx = bce_amd.api._Ctx(local)
+        try:
+            dt, arch, sts = timed_steps(ctx, t_in, n, 1, 1)
+        finally:
+            ctx.close()
+        del t_in
+        torch.cuda.empty_cache()
+        r = roofline(n, sts)
+        st = sts[-1]
+        return {"workload": desc, "bytes": n, "input_sha256": hashlib.sha256(data.tobytes()).hexdigest()[:16], "steps": 1, "warmup": 1,
+                "value": round(n / dt / 1e6, 3), "unit": "MB/s", "ms_per_step": round(dt * 1e3, 2),
+                "k3_ms": r["k3_ms_per_step"], "roofline_frac": r["frac"], "roofline_achieved_GBs": r["achieved"],
+                "rounds": st["rounds"], "symbols": st["symbols"], "sort_rounds": st["sort_rounds"],
+                "k1_ms": round(st["t_bwt"] * 1e3, 2), "k2_ms": round(st["t_planes"] * 1e3, 2), "k4_ms": round(st["t_model"] * 1e3, 2),
+                "coder_busy_ms": round(st["t_coder_busy"] * 1e3, 2),
+                "archive_bytes": len(arch), "archive_sha256": hashlib.sha256(arch).hexdigest(),
+                "oracle_golden": golden_verdict(table, data, arch)}
+    except Exception as e:
+        return {"workload": desc, "error": "%s: %s" % (type(e).__name__, e)}
+
+
+def scanned_workload(local, dev, table, n=200_000_000):
+    """BASELINE configs[4] stand-in (Silesia-sized, mixed content, tuned AdaptiveCoder): natural corpus || binary corpus,
+    2 x 10^8 bytes; `bce -s` first (GPU enumeration in scan mode + the host ScanSet, timed on its own), then `bce -c` with
+    that table.  Both the table and the archive are pinned to the oracle's (mixed-2e8-scanned)."""
+    desc = "natural corpus || binary corpus, 2x10^8 B, table scanned by bce -s (Silesia-sized stand-in, BASELINE configs[4])"
+    try:
+        parts = []
+        for kind, m in (("natural", n // 2), ("binary", n - n // 2)):
+            path = "/tmp/bce_%s_%d.bin" % (kind, m)
+            if not (os.path.exists(path) and os.path.getsize(path) == m):
+                tool = "make_corpus.py" if kind == "natural" else "make_binary_corpus.py"
+                subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "--out", path, "--size", str(m)],
+                               check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            parts.append(np.fromfile(path, dtype=np.uint8))
+        data = np.concatenate(parts)
+        del parts
+        sha = hashlib.sha256(data.tobytes()).hexdigest()
+        gold = table.get(sha)
+        t0 = time.perf_counter()
+        config, _sizes = bce_amd.scan(data, device=local)
+        t_scan = time.perf_counter() - t0
+        t_in = torch.from_numpy(data).to(dev)
+        torch.cuda.synchronize()
+        ctx = bce_amd.api._Ctx(local)
+        try:
+            dt, arch, sts = timed_steps(ctx, t_in, n, 2, 1, config=bytes(config))
+        finally:
+            ctx.close()
+        del t_in
+        torch.cuda.empty_cache()
+        r = roofline(n, sts)
+        st = sts[-1]
+        ok = None
+        if gold is not None:
+            ok = ("identical" if len(arch) == gold["archive_bytes"] and hashlib.sha256(arch).hexdigest() == gold["archive_sha256"] else "DIFFERENT")
+        return {"workload": desc, "bytes": n, "input_sha256": sha[:16],
+                "scan_seconds": round(t_scan, 3), "scan_MBps": round(n / t_scan / 1e6, 2),
+                "config_sha256": hashlib.sha256(bytes(config)).hexdigest(),
+                "config_equals_oracle_scan": (bytes(config).hex() == gold["config_hex"]) if gold is not None and "config_hex" in gold else None,
+                "value": round(n * 2 / dt / 1e6, 3), "unit": "MB/s", "ms_per_step": round(dt / 2 * 1e3, 2),
+                "k3_ms": r["k3_ms_per_step"], "roofline_frac": r["frac"], "rounds": st["rounds"], "symbols": st["symbols"],
+                "sort_rounds": st["sort_rounds"], "k1_ms": round(st["t_bwt"] * 1e3, 2), "k4_ms": round(st["t_model"] * 1e3, 2),
+                "coder_busy_ms": round(st["t_coder_busy"] * 1e3, 2),
+                "archive_bytes": len(arch), "archive_sha256": hashlib.sha256(arch).hexdigest(), "oracle_golden": ok}
+    except Exception as e:
+        return {"workload": desc, "error": "%s: %s" % (type(e).__name__, e)}
+
+
 def cpu_baseline(data, sample_bytes, ctx, dev):
     """The oracle (bit-exact CPU restatement of bce -c) timed on this host on a bounded sample: single thread (the
     reference built without OpenMP) and 8 threads (its OpenMP build: one thread per plane, joined every round,
@@ -181,12 +273,13 @@ def cpu_baseline(data, sample_bytes, ctx, dev):
     import oracle
     oracle.build()
     sample = np.ascontiguousarray(data[:sample_bytes])
-    runs = {}
+    runs, stages = {}, {}
     for threads in (1, 8):
         oracle.set_threads(threads)
         t0 = time.time()
         arch = oracle.compress(sample)
         runs[threads] = (time.time() - t0, len(arch), hashlib.sha256(arch).hexdigest())
+        stages[threads] = oracle.stage_seconds()
     oracle.set_threads(1)
     assert runs[1][2] == runs[8][2]
     best = min(runs, key=lambda t: runs[t][0])
@@ -201,6 +294,10 @@ def cpu_baseline(data, sample_bytes, ctx, dev):
             "sample": "first %d B of the workload, oracle/bce_oracle.c: 1 thread %.1f s (%.2f MB/s), 8 OpenMP threads %.1f s (%.2f MB/s), archive %d B" % (
                 n, runs[1][0], n / runs[1][0] / 1e6, runs[8][0], n / runs[8][0] / 1e6, runs[1][1]),
             "single_thread_value": round(n / runs[1][0] / 1e6, 3),
+            "stage_seconds": {k: round(v, 3) for k, v in stages[best].items()},
+            # BASELINE.md calibration: the reference's encode stage takes 1.82x the oracle's (2.69 s vs 1.48 s, 8 MiB synth-text, 1 thread)
+            "reference_equivalent_value": round(n / (runs[best][0] + (REF_ENCODE_RATIO - 1.0) * stages[best]["encode"]) / 1e6, 3),
+            "reference_equivalent_note": "oracle time with its encode stage scaled by %.2f = bce.cpp's `Encode:` timer / the oracle's, calibrated in the build container (BASELINE.md)" % REF_ENCODE_RATIO,
             "host_cpus": os.cpu_count(),
             "parity_sample_identical": identical,
             "gpu_value_same_sample": round(gpu_v, 3),
@@ -227,7 +324,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
-    sharding.pin_to_local_numa(local)            # the rank's 8 coder threads stay on the GPU's NUMA node
+    pinned = sharding.pin_to_local_numa(local)   # the rank's 8 coder threads stay on the GPU's NUMA node
 
     data, workload = make_input(args, rank, world)
     n = len(data)
@@ -248,17 +345,21 @@ def main():
         torch.cuda.synchronize()
 
     gathered = [None]
+    comm_s = [0.0]
 
     def step():
         arch, st = bce_amd.compress_device(t_in.data_ptr(), n, config=config, ctx=ctx)
         if dist is not None:
             # RCCL gather of the per-block coded streams to rank 0 (size exchange, then padded gather)
+            tg = time.perf_counter()
             gathered[0] = sharding.gather_streams(arch, dist, comm_dev)
+            comm_s[0] += time.perf_counter() - tg
         return arch, st
 
     for _ in range(args.warmup):
         step()
     barrier()
+    comm_s[0] = 0.0
     t0 = time.perf_counter()
     sts = []
     arch = None
@@ -275,6 +376,14 @@ def main():
         per_rank = [float(x.item()) for x in allt]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    # what a SCALE line needs to attribute a loss: per-rank gather time (inside the step), busiest coder thread, CPU set
+    mine = {"gather_ms": round(comm_s[0] / max(1, args.steps) * 1e3, 3), "coder_busy_ms": round(sts[-1]["t_coder_busy"] * 1e3, 2) if sts else None,
+            "k1_ms": round(sts[-1]["t_bwt"] * 1e3, 2) if sts else None, "cpus": len(os.sched_getaffinity(0)),
+            "cpu_set": sharding.format_cpulist(os.sched_getaffinity(0)), "numa_pinned": pinned is not None}
+    per_rank_info = [mine]
+    if dist is not None:
+        per_rank_info = [None] * world
+        dist.all_gather_object(per_rank_info, mine)
 
     if rank == 0:
         steps = max(1, args.steps)
@@ -308,7 +417,15 @@ def main():
             "breakdown_s": {k: round(st[k], 4) for k in ("t_load", "t_bwt", "t_planes", "t_enum", "t_model", "t_coder", "t_coder_busy")},
             "counts": {"nodes": st["nodes"], "symbols": st["symbols"], "rounds": st["rounds"], "sort_rounds": st["sort_rounds"], "flushes": st["flushes"]},
             "ms_per_step_per_rank": [round(t / steps * 1e3, 2) for t in per_rank],
+            "per_rank": per_rank_info,
         }
+        if dist is not None:
+            out["comm"] = {"backend": dist.get_backend(), "world": dist.get_world_size(),
+                           "collectives_per_step": "all_gather of 8-byte sizes + one padded gather to rank 0 (bce_amd/sharding.py)",
+                           "gather_ms": max(r["gather_ms"] for r in per_rank_info),
+                           "gather_ms_per_rank": [r["gather_ms"] for r in per_rank_info],
+                           "gather_bytes": int(sum(len(g) for g in gathered[0])) if gathered[0] is not None else None,
+                           "note": "gather_ms is inside ms_per_step; it includes waiting for the slowest rank's archive"}
         if n_gpus == 1 and not args.no_e2e:
             # SURVEY 8d's "file read -> archive bytes ready": the same workload from a (pageable) HOST buffer, H2D inside
             torch.cuda.synchronize()
@@ -340,7 +457,13 @@ def main():
                              "roundtrip_identical": bool(len(back) == n and hashlib.sha256(back).digest() == hashlib.sha256(data.tobytes()).digest()),
                              "note": "bce_hip_decompress_device: GPU passes + 8 host range decoders; not part of `value`"}
         if n_gpus == 1 and not args.no_workloads and not args.file and args.workload == "synth-text":
-            out["workloads"] = extra_workloads(ctx, dev, table, pool, args.stream_steps or 12)
+            out["workloads"] = extra_workloads(ctx, dev, table, pool, args.stream_steps or 12, decode=not args.no_decode)
+            if pool is not None:
+                pool.close()
+                pool = None
+            if not args.no_big:
+                out["workloads"].append(scanned_workload(local, dev, table))     # BASELINE configs[4] stand-in
+                out["workloads"].append(big_workload(local, dev, table))         # BASELINE configs[2] stand-in (10^9 B)
         if pool is not None:
             pool.close()
         if n_gpus == 1 and not args.no_cpu:

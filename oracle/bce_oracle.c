@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <stdio.h>
 
 /* ------------------------------------------------------------------------------------------------
@@ -462,18 +463,29 @@ static void load_cfg(const uint8_t *config) {        /* load_config :626-641 (fi
 
 /* main() -c branch (bce.cpp:1403-1427) minus file I/O: in -> malloc'd archive bytes.
  * returns 0, or -1 for n == 0 (the reference crashes on empty input). */
+/* The reference's -DM_TIME stage timers ("Rotate:" bce.cpp:864-866,886-891, "BWT:" :897-909, "Rank:" :941-943,974-979,
+ * "Encode:" :1118-1120,1159-1164) for the last bce_oracle_compress: seconds of rotate, bwt, plane build, encode. */
+static double g_stage_s[4];
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+void bce_oracle_stage_seconds(double out[4]) { memcpy(out, g_stage_s, sizeof g_stage_s); }
+
 int bce_oracle_compress(const uint8_t *in, uint32_t n, const uint8_t *config, uint8_t **out, size_t *out_len) {
   if (n == 0) return -1;
   load_cfg(config);
   uint8_t *map = (uint8_t *)malloc(n);
   memcpy(map, in, n);
+  double t0 = now_s();
   uint32_t off = bce_oracle_rotate(map, n);       /* RankFile ctor :935-936 */
+  double t1 = now_s();
   bce_oracle_bwt(map, n);
+  double t2 = now_s();
   Rank ranks[8];
   build_planes(map, n, ranks);
+  double t3 = now_s();
   free(map);
   vec16 data = {0};
   bce_encode(ranks, n, off, &data, NULL);
+  g_stage_s[0] = t1 - t0; g_stage_s[1] = t2 - t1; g_stage_s[2] = t3 - t2; g_stage_s[3] = now_s() - t3;
   for (int i = 0; i < 8; ++i) free(ranks[i].w);
   *out = (uint8_t *)data.p;                       /* native-endian u16 words, :1426 */
   *out_len = data.n * 2;

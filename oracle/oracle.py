@@ -27,6 +27,7 @@ def lib():
         L.bce_oracle_compress.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.bce_oracle_compress.restype = C.c_int
         L.bce_oracle_free.argtypes = [C.c_void_p]
+        L.bce_oracle_stage_seconds.argtypes = [C.POINTER(C.c_double)]
         L.bce_oracle_bwt_stage.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, u32p]
         L.bce_oracle_bwt_stage.restype = C.c_int
         L.bce_oracle_encode_from_bwt.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
@@ -84,6 +85,13 @@ def compress(data, config=None) -> bytes:
         return C.string_at(out, n.value)
     finally:
         lib().bce_oracle_free(out)
+
+
+def stage_seconds():
+    """Stage times of the last compress() as the reference's -DM_TIME build prints them: rotate, bwt, rank (planes), encode."""
+    t = (C.c_double * 4)()
+    lib().bce_oracle_stage_seconds(t)
+    return dict(zip(("rotate", "bwt", "rank", "encode"), t))
 
 
 def bwt_stage(data):

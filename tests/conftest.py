@@ -29,6 +29,11 @@ def fullsize_input(v):
     if v["kind"] in ("synth_text", "synth_rand"):
         import bce_amd
         data = getattr(bce_amd, v["kind"])(v["seed"], v["n"])
+    elif v["kind"] == "mixed":      # natural corpus || binary corpus, half each (tools/make_oracle_golden.py)
+        halves = [fullsize_input({"kind": k, "n": m, "input_sha256": None}) for k, m in (("natural", v["n"] // 2), ("binary", v["n"] - v["n"] // 2))]
+        if any(h is None for h in halves):
+            return None
+        data = np.concatenate(halves)
     else:
         path = "/tmp/bce_%s_%d.bin" % (v["kind"], v["n"])
         if not (os.path.exists(path) and os.path.getsize(path) == v["n"]):
@@ -38,7 +43,7 @@ def fullsize_input(v):
             if r.returncode != 0:
                 return None
         data = np.fromfile(path, dtype=np.uint8)
-    if hashlib.sha256(data.tobytes()).hexdigest() != v["input_sha256"]:
+    if v["input_sha256"] is not None and hashlib.sha256(data.tobytes()).hexdigest() != v["input_sha256"]:
         return None
     return data
 

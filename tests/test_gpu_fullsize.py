@@ -73,3 +73,27 @@ def test_stream_through_three_contexts_equals_the_oracles(name):
             assert [hashlib.sha256(a).hexdigest() for a in res] == [v["archive_sha256"]] * 6
     del t
     torch.cuda.empty_cache()
+
+
+@pytest.mark.timeout(900)
+def test_scanned_table_at_silesia_size_equals_the_oracles():
+    """BASELINE configs[4] (Silesia-sized, mixed, tuned AdaptiveCoder): 2 x 10^8 bytes of natural corpus || binary corpus.
+    `bce -s` on the GPU path (K1-K3 in scan mode + the threaded host ScanSet) must give the 288 bytes oracle.scan gave,
+    and `bce -c` with that table the oracle's archive.  The two are checked apart: the compression uses the ORACLE's
+    table from the golden file, so a scan difference cannot hide behind (or cause) an archive difference."""
+    v = GOLD["mixed-2e8-scanned"]
+    data = fullsize_input(v)
+    if data is None:
+        pytest.skip("this box cannot rebuild the corpora bit for bit (files of another image)")
+    cfg_oracle = bytes.fromhex(v["config_hex"])
+    assert hashlib.sha256(cfg_oracle).hexdigest() == v["config_sha256"]
+    cfg, sizes = bce_amd.scan(data)
+    assert bytes(cfg) == cfg_oracle
+    assert sizes == v["scan_result_sizes"]                      # the same doubles: every sum keeps the reference's order (Q11)
+    t = torch.from_numpy(data).to("cuda:0")
+    torch.cuda.synchronize()
+    arch, st = bce_amd.compress_device(t.data_ptr(), len(data), config=cfg_oracle)
+    del t
+    torch.cuda.empty_cache()
+    assert st["nodes"] == 8 * v["n"] - 8
+    assert len(arch) == v["archive_bytes"] and hashlib.sha256(arch).hexdigest() == v["archive_sha256"]

@@ -67,3 +67,16 @@ def test_spine_bursts_keep_zero_run_contexts_cheap():
     arch, dt = _encode_s(data)
     assert dt < 10.0, "encode took %.1f s" % dt
     assert bce_amd.decompress_device(arch) == data
+
+
+def test_scan_of_1e8_bytes_stays_under_seconds():
+    """`bce -s` at 10^8 bytes: the host part (recording 1.4 x 10^8 symbols in the reference's unordered_maps, then 9 x 29 x 6
+    simulated adaptive codings) runs on a thread pool (scan_coder.cpp ScanSet); sequentially it took ~10 s.  The table is the
+    one the sequential code gives (tests/test_core_cpu.py, tests/test_gpu_scan.py); this only guards the time."""
+    data = bce_amd.synth_text(1, 100_000_000)
+    bce_amd.scan(data[:1 << 20])                               # HIP init, kernels loaded
+    t0 = time.time()
+    cfg, sizes = bce_amd.scan(data)
+    dt = time.time() - t0
+    print("bce -s of 1e8 B: %.2f s" % dt)
+    assert len(cfg) == 288 and dt < 8.0, "scan took %.1f s" % dt

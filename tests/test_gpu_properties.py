@@ -54,18 +54,23 @@ def test_full_pipeline_properties(gen, n):
         assert bce_amd.decompress(arch1) == data.tobytes()
 
 
-# BASELINE.json configs[2] size (enwik9 = 10^9 B; synth-text stand-in).  The oracle would need ~7 minutes and 13 GB for this
-# input, so this one archive has no oracle hash: the pin below is the GPU path's own output (a regression pin, named as
-# such) and the PROPERTY is the round trip.  Oracle-compared archives: 10^8 B and 1.5 * 10^8 B (> 2^27, the uint32
-# context wrap) in tests/test_gpu_fullsize.py.
-def test_enwik9_size_round_trip():
-    n, own_sha_prefix = 1_000_000_000, "383c3b3c0acab6db"
+# BASELINE.json configs[2] size (enwik9 = 10^9 B; synth-text stand-in).  The known answer is the ORACLE's (round 3:
+# tools/make_oracle_golden.py ran oracle/bce_oracle.c on this input once in the build container -- 587 s, ~13 GB --
+# tests/golden/oracle_fullsize.json, synth-text-1e9).  It is the only end-to-end check of the bits = 3, 4 wraps of
+# get_context (bce.cpp:674: c1 >= 2^29 / 2^28 only happens at this size) and of getv's 31-bit path (:374).  The round trip
+# through the GPU-assisted decoder stays as the property.
+def test_enwik9_size_equals_the_oracle_and_round_trips():
+    from conftest import load_fullsize_golden
+    v = load_fullsize_golden()["synth-text-1e9"]
+    n = v["n"]
+    assert n == 1_000_000_000 and n > (1 << 29)
     data = bce_amd.synth_text(1, n)
+    assert hashlib.sha256(data.tobytes()).hexdigest() == v["input_sha256"]
     t = dev_input(data)
     arch, st = bce_amd.compress_device(t.data_ptr(), n)
     del t
     torch.cuda.empty_cache()
     assert st["nodes"] == 8 * n - 8
-    assert hashlib.sha256(arch).hexdigest().startswith(own_sha_prefix)
+    assert len(arch) == v["archive_bytes"] and hashlib.sha256(arch).hexdigest() == v["archive_sha256"]
     back = bce_amd.decompress_device(arch)
-    assert len(back) == n and hashlib.sha256(back).hexdigest() == hashlib.sha256(data.tobytes()).hexdigest()
+    assert len(back) == n and hashlib.sha256(back).hexdigest() == v["input_sha256"]

@@ -78,3 +78,59 @@ def test_gate_by_hand_two_contexts_one_thread_each():
         t.join()
     for i in range(2):
         assert out[i] == oracle.compress(data[i].tobytes())
+
+
+_BESIDE = r'''
+import ctypes as C, hashlib, sys, threading
+import numpy as np
+sys.path.insert(0, %(root)r)
+import bce_amd
+lib = bce_amd.load_library()
+data = [np.frombuffer(bce_amd.synth_text(50 + i, 6_000_000), dtype=np.uint8) for i in range(2)]
+res = [None, None]
+def run(i, gated):
+    h = C.c_void_p()
+    assert lib.bce_hip_create(C.byref(h), 0) == 0
+    lib.bce_hip_set_gated(h, gated)
+    out = []
+    for _ in range(4):
+        cap = len(data[i]) + 4096
+        buf = (C.c_uint8 * cap)()
+        ln = C.c_size_t()
+        rc = lib.bce_hip_compress(h, data[i].ctypes.data, len(data[i]), buf, cap, C.byref(ln))
+        out.append((rc, hashlib.sha256(bytes(buf[:ln.value])).hexdigest() if rc == 0 else lib.bce_hip_last_error(h).decode()))
+    lib.bce_hip_destroy(h)
+    res[i] = out
+ts = [threading.Thread(target=run, args=(0, 1)), threading.Thread(target=run, args=(1, %(second)d))]
+[t.start() for t in ts]
+[t.join() for t in ts]
+import json
+print(json.dumps(res))
+'''
+
+
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("second_gated", [1, 0])
+def test_a_context_beside_a_gated_one_completes_or_fails_loudly_never_hangs(second_gated):
+    """Contexts are gated by default; bce_hip_set_gated(ctx, 0) is the documented opt-out "only for a context that is alone
+    on its device".  This runs the documented DON'T in a child process -- an opted-out context encoding beside a gated one,
+    four 6 MB inputs each -- under a watchdog: every compression must either give the right archive or return an error
+    (the bounded tile waits of k3_enumerate.hip turn a starved single-launch round into BCE_HIP_E_INTERNAL after seconds);
+    the child must end by itself well inside the limit.  second_gated = 1 is the control: both gated, everything right."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import hashlib
+    from conftest import ROOT
+    src = _BESIDE % {"root": ROOT, "second": second_gated}
+    r = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, timeout=300)   # the watchdog: TimeoutExpired fails the test
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("[")][-1])
+    want = [hashlib.sha256(oracle.compress(bce_amd.synth_text(50 + i, 6_000_000).tobytes())).hexdigest() for i in range(2)]
+    for i in range(2):
+        for rc, what in res[i]:
+            if second_gated:
+                assert rc == 0 and what == want[i]
+            else:
+                assert (rc == 0 and what == want[i]) or (rc != 0 and what), (rc, what)

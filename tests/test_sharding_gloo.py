@@ -133,6 +133,13 @@ def test_bench_two_ranks_through_the_hip_path():
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
     assert len(j["ms_per_step_per_rank"]) == 2 and all(t > 0 for t in j["ms_per_step_per_rank"])
     assert j["config"]["bytes_per_gpu"] == 3000000
+    # what a first 8-GPU run needs to explain itself: backend, world size, gather time and bytes, per-rank host facts
+    c = j["comm"]
+    assert c["backend"] == "gloo" and c["world"] == 2 and c["gather_ms"] >= 0 and len(c["gather_ms_per_rank"]) == 2
+    assert c["gather_bytes"] > 2 * 100000
+    assert len(j["per_rank"]) == 2
+    for r_ in j["per_rank"]:
+        assert r_["coder_busy_ms"] > 0 and r_["k1_ms"] > 0 and r_["cpus"] >= 1 and isinstance(r_["cpu_set"], str) and "numa_pinned" in r_
     # rank 0's block is synth-text seed 1: its archive must be the oracle's
     import hashlib
 
