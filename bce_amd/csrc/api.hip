@@ -242,7 +242,7 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->k4_stream) (void)hipStreamSynchronize(c->k4_stream);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-  DevBuf *bufs[] = {&c->text, &c->bwt, &c->sa[0], &c->sa[1], &c->key[0], &c->key[1], &c->rank, &c->k2, &c->nrk, &c->act[0], &c->act[1],
+  DevBuf *bufs[] = {&c->text, &c->bwt, &c->sa[0], &c->sa[1], &c->key[0], &c->key[1], &c->rank, &c->k2, &c->nrk, &c->act[0], &c->act[1], &c->khi[0], &c->khi[1], &c->dl[0], &c->dl[1], &c->dl[2], &c->dl[3], &c->kflag, &c->actv[0], &c->actv[1],
                     &c->rs_hist, &c->blk, &c->ptmp[0], &c->ptmp[1], &c->gran, &c->nodes, &c->ctl, &c->tilecnt,
                     &c->tileoff, &c->runs, &c->smwords, &c->k3tw, &c->k3grp, &c->truns, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
                     &c->sesc, &c->stat, &c->dcfg, &c->k4w, &c->scanrec, &c->dfs, &c->skey_alt, &c->sesc_alt, &c->rs_hist_k4};

@@ -100,6 +100,8 @@ struct bce_hip_ctx {
   // device buffers (grow-only)
   bce::DevBuf text, bwt;                         // n bytes each
   bce::DevBuf sa[2], key[2], rank, k2, nrk, act[2];   // K1: 9 x 4n (act = active-set lists)
+  bce::DevBuf khi[2], dl[4], kflag, actv[2];                   // K1: high key words of the first sort, then new rank / suffix per active element;
+                                                      //     deferred (big-group) lists; per-element flags
   bce::DevBuf rs_hist, blk;                      // radix histograms [256][nb]; per-block scratch
   bce::DevBuf ptmp[2];                           // K2 byte ping-pong
   bce::DevBuf gran;                              // 8 planes x ngran x 16 B
@@ -253,6 +255,9 @@ int radix_sort_pairs(bce_hip_ctx *c, uint32_t *key[2], uint32_t *val[2], uint32_
                      uint32_t max_digit_bits = 8);
 int radix_sort_pairs_on(bce_hip_ctx *c, hipStream_t stream, DevBuf &hist, uint32_t *key[2], uint32_t *val[2], uint32_t n,
                         uint32_t first_bit, uint32_t bits, int *res, uint32_t max_digit_bits = 8);
+// the same with 64-bit keys in two u32 arrays (hi:lo) on key bits [0, bits), bits <= 64 (K1's first sort)
+int radix_sort_wide(bce_hip_ctx *c, uint32_t *lo[2], uint32_t *hi[2], uint32_t *val[2], uint32_t n, uint32_t bits, int *res,
+                    uint32_t max_digit_bits = 10);
 bool k4_in_flight(bce_hip_ctx *c);                  // a model flush may still be running beside the main stream
 
 }  // namespace bce

@@ -234,6 +234,217 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
   }
 }
 
+// ---- 64-bit keys (K1's first sort: up to 12 symbols per key) ---------------------------------------------------------
+// The key is two u32 arrays (lo, hi), the value a third; a digit is (hi:lo >> shift) & mask and may straddle the words.
+// Same three kernels per pass; the scatter moves three words per element through LDS.  ITEMS is smaller than the pair
+// sort's (chunk of 2048) so that four blocks still fit a CU.
+constexpr int RW_ITEMS = 8;
+constexpr int RW_CHUNK = RS_THREADS * RW_ITEMS;
+static RsPlan rw_plan(uint32_t n) {
+  uint32_t chunks = (uint32_t)(((uint64_t)n + RW_CHUNK - 1) / RW_CHUNK);
+  if (chunks == 0) chunks = 1;
+  const uint32_t maxb = 1024;                               // 4 per CU
+  uint32_t nb = chunks < maxb ? chunks : maxb;
+  uint32_t cpb = (chunks + nb - 1) / nb;
+  nb = (chunks + cpb - 1) / cpb;
+  return {nb, cpb * (uint32_t)RW_CHUNK};
+}
+__device__ __forceinline__ uint32_t digit64(uint32_t lo, uint32_t hi, int shift, uint32_t mask) {
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> shift) & mask;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rw_hist_kernel(const uint32_t *__restrict__ lo, const uint32_t *__restrict__ hi,
+                                                             uint32_t n, uint32_t per_block, uint32_t nb, int shift, int nbits,
+                                                             uint32_t *__restrict__ hist) {
+  __shared__ uint32_t lh[4][RS_MAXBINS];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+  const uint32_t nbins = 1u << nbits, mask = nbins - 1u;
+  for (uint32_t d = tid; d < nbins; d += RS_THREADS) { lh[0][d] = 0; lh[1][d] = 0; lh[2][d] = 0; lh[3][d] = 0; }
+  __syncthreads();
+  const uint64_t beg = (uint64_t)blockIdx.x * per_block;
+  uint64_t end = beg + per_block;
+  if (end > n) end = n;
+  const bool need_lo = shift < 32, need_hi = shift + nbits > 32;       // (uniform: a pass reads only the words its digit touches)
+  for (uint64_t base = beg; base < end; base += (uint64_t)RS_THREADS * 16) {
+    uint32_t kl[16], kh[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const uint64_t i = base + (uint64_t)it * RS_THREADS + tid;
+      kl[it] = (need_lo && i < end) ? lo[i] : 0u;
+      kh[it] = (need_hi && i < end) ? hi[i] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const uint64_t i = base + (uint64_t)it * RS_THREADS + tid;
+      const bool valid = i < end;
+      const uint32_t d = digit64(kl[it], kh[it], shift, mask);
+      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+      if (__all(valid && d == d0)) {
+        if (lane == 0) atomicAdd(&lh[w][d0], 64u);
+      } else if (valid) {
+        atomicAdd(&lh[w][d], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t d = tid; d < nbins; d += RS_THREADS) hist[(size_t)d * nb + blockIdx.x] = lh[0][d] + lh[1][d] + lh[2][d] + lh[3][d];
+}
+
+template <int NBITS>
+__global__ __launch_bounds__(RS_THREADS) void rw_scatter_kernel(const uint32_t *__restrict__ lo_in, const uint32_t *__restrict__ hi_in,
+                                                                const uint32_t *__restrict__ vals_in,
+                                                                uint32_t *__restrict__ lo_out, uint32_t *__restrict__ hi_out,
+                                                                uint32_t *__restrict__ vals_out, uint32_t n,
+                                                                uint32_t per_block, uint32_t nb, int shift, int nbits,
+                                                                const uint32_t *__restrict__ hist,
+                                                                const uint32_t *__restrict__ rowtotal) {
+  constexpr int BINS = NBITS > 0 ? (1 << NBITS) : RS_MAXBINS;
+  __shared__ uint32_t wcnt[4][BINS];
+  __shared__ uint32_t goff[BINS];
+  __shared__ uint32_t gdelta[BINS];
+  __shared__ uint32_t slo[RW_CHUNK], shi[RW_CHUNK], sval[RW_CHUNK];
+  constexpr int BPT = (BINS + RS_THREADS - 1) / RS_THREADS;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+  const uint32_t nbins = 1u << nbits, mask = nbins - 1u;
+  {
+    uint32_t v[BPT], sum = 0;
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+      const uint32_t d = tid * BPT + q;
+      v[q] = d < nbins ? rowtotal[d] : 0u;
+      sum += v[q];
+    }
+    uint32_t tot;
+    uint32_t run = block_excl_scan_sum<RS_THREADS>(sum, &tot);
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+      const uint32_t d = tid * BPT + q;
+      if (d < nbins) goff[d] = run + hist[(size_t)d * nb + blockIdx.x];
+      run += v[q];
+    }
+  }
+  const uint64_t beg = (uint64_t)blockIdx.x * per_block;
+  uint64_t end = beg + per_block;
+  if (end > n) end = n;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  for (uint64_t base = beg; base < end; base += RW_CHUNK) {
+    const uint32_t cnt = (uint32_t)(end - base < (uint64_t)RW_CHUNK ? end - base : (uint64_t)RW_CHUNK);
+    for (uint32_t d = tid; d < nbins; d += RS_THREADS) { wcnt[0][d] = 0; wcnt[1][d] = 0; wcnt[2][d] = 0; wcnt[3][d] = 0; }
+    __syncthreads();
+    uint32_t kl[RW_ITEMS], kh[RW_ITEMS], val[RW_ITEMS], lr[RW_ITEMS];
+#pragma unroll
+    for (int it = 0; it < RW_ITEMS; ++it) {
+      const uint32_t q = w * (RW_CHUNK / 4) + (uint32_t)it * 64u + lane;
+      const bool valid = q < cnt;
+      kl[it] = valid ? lo_in[base + q] : 0u;
+      kh[it] = valid ? hi_in[base + q] : 0u;
+      val[it] = valid ? vals_in[base + q] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < RW_ITEMS; ++it) {
+      const uint32_t q = w * (RW_CHUNK / 4) + (uint32_t)it * 64u + lane;
+      const bool valid = q < cnt;
+      const uint32_t d = digit64(kl[it], kh[it], shift, mask);
+      const uint64_t peers = match_digit<NBITS>(d, nbits, valid);
+      const uint32_t leader = valid ? (uint32_t)(__ffsll((long long)peers) - 1) : lane;
+      uint32_t pre = 0;
+      if (valid && lane == leader) pre = atomicAdd(&wcnt[w][d], (uint32_t)__popcll(peers));
+      pre = __shfl(pre, (int)leader);
+      lr[it] = pre + (uint32_t)__popcll(peers & lt);
+    }
+    __syncthreads();
+    {
+      uint32_t c[BPT][4], sum = 0;
+#pragma unroll
+      for (int q = 0; q < BPT; ++q) {
+        const uint32_t d = tid * BPT + q;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) { c[q][ww] = d < nbins ? wcnt[ww][d] : 0u; sum += c[q][ww]; }
+      }
+      uint32_t tot;
+      uint32_t run = block_excl_scan_sum<RS_THREADS>(sum, &tot);
+#pragma unroll
+      for (int q = 0; q < BPT; ++q) {
+        const uint32_t d = tid * BPT + q;
+        if (d < nbins) {
+          const uint32_t t4 = c[q][0] + c[q][1] + c[q][2] + c[q][3];
+          wcnt[0][d] = run; wcnt[1][d] = run + c[q][0]; wcnt[2][d] = run + c[q][0] + c[q][1];
+          wcnt[3][d] = run + c[q][0] + c[q][1] + c[q][2];
+          const uint32_t g = goff[d];
+          gdelta[d] = g - run;
+          goff[d] = g + t4;
+          run += t4;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RW_ITEMS; ++it) {
+      const uint32_t q = w * (RW_CHUNK / 4) + (uint32_t)it * 64u + lane;
+      if (q < cnt) {
+        const uint32_t d = digit64(kl[it], kh[it], shift, mask);
+        const uint32_t pos = wcnt[w][d] + lr[it];
+        slo[pos] = kl[it];
+        shi[pos] = kh[it];
+        sval[pos] = val[it];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < RW_ITEMS; ++it) {
+      const uint32_t q = (uint32_t)it * RS_THREADS + tid;
+      if (q < cnt) {
+        const uint32_t l = slo[q], hh = shi[q];
+        const uint32_t pos = gdelta[digit64(l, hh, shift, mask)] + q;
+        lo_out[pos] = l;
+        hi_out[pos] = hh;
+        vals_out[pos] = sval[q];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Stable LSD sort of (64-bit key = hi:lo, u32 value) triples on key bits [0, bits), bits <= 64.  Result in lo[res] / hi[res] / val[res].
+int radix_sort_wide(bce_hip_ctx *c, uint32_t *lo[2], uint32_t *hi[2], uint32_t *val[2], uint32_t n, uint32_t bits, int *res,
+                    uint32_t max_digit_bits) {
+  *res = 0;
+  if (n <= 1 || bits == 0) return BCE_HIP_OK;
+  if (bits > 64) return BCE_HIP_E_ARG;
+  if (max_digit_bits < 1 || max_digit_bits > (uint32_t)RS_MAXBITS) max_digit_bits = 8;
+  const RsPlan pl = rw_plan(n);
+  BCE_TRY(ensure(c, c->rs_hist, ((size_t)RS_MAXBINS * pl.nb + RS_MAXBINS) * sizeof(uint32_t)));
+  uint32_t *hist = c->rs_hist.as<uint32_t>();
+  uint32_t *rowtotal = hist + (size_t)RS_MAXBINS * pl.nb;
+  const uint32_t npass = (bits + max_digit_bits - 1) / max_digit_bits;
+  int cur = 0;
+  uint32_t done = 0;
+  for (uint32_t pass = 0; pass < npass; ++pass) {
+    const uint32_t left = bits - done, pleft = npass - pass;
+    const int nbits = (int)((left + pleft - 1) / pleft);
+    const uint32_t nbins = 1u << nbits;
+    hipLaunchKernelGGL(rw_hist_kernel, dim3(pl.nb), dim3(RS_THREADS), 0, c->stream, lo[cur], hi[cur], n, pl.per_block, pl.nb,
+                       (int)done, nbits, hist);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(nbins), dim3(RS_THREADS), 0, c->stream, hist, pl.nb, rowtotal);
+#define RW_SCATTER(NB)                                                                                                      \
+  hipLaunchKernelGGL(rw_scatter_kernel<NB>, dim3(pl.nb), dim3(RS_THREADS), 0, c->stream, lo[cur], hi[cur], val[cur], lo[cur ^ 1], \
+                     hi[cur ^ 1], val[cur ^ 1], n, pl.per_block, pl.nb, (int)done, nbits, hist, rowtotal)
+    switch (nbits) {
+      case 10: RW_SCATTER(10); break;
+      case 9: RW_SCATTER(9); break;
+      case 8: RW_SCATTER(8); break;
+      case 7: RW_SCATTER(7); break;
+      default: RW_SCATTER(0); break;
+    }
+#undef RW_SCATTER
+    cur ^= 1;
+    done += (uint32_t)nbits;
+  }
+  BCE_HIP_TRY(c, hipGetLastError());
+  *res = cur;
+  return BCE_HIP_OK;
+}
+
 int radix_sort_pairs(bce_hip_ctx *c, uint32_t *key[2], uint32_t *val[2], uint32_t n, uint32_t first_bit, uint32_t bits,
                      int *res, uint32_t max_digit_bits) {
   return radix_sort_pairs_on(c, c->stream, c->rs_hist, key, val, n, first_bit, bits, res, max_digit_bits);
