@@ -88,6 +88,19 @@ struct StairJob {
 };
 typedef __attribute__((address_space(4))) Granule ConstGranule;
 
+// A wave-walker's block has KD_HELP waves when few walkers are left (round 3): wave 0 walks, the others sleep on an LDS word
+// and wake up for the one thing a single wave is hopeless at -- the scan of ALL rows of a large node for the starts and
+// ends of its staircases (three dependent loads per 256 rows: 8 M cycles for a 10^6-row node, a whole pass waiting).
+constexpr int KD_HELP = 8;
+constexpr uint32_t KD_HELP_MINX = 4096;          // rows from which the helpers are called
+constexpr uint32_t KD_HELP_MAXW = 1024;          // walkers of a pass up to which every walker gets helpers
+struct ScanJob { uint32_t seq, s, x, p, nS, nE, fail, done; };
+// LDS written by this wave is visible to this wave (one wave = in-order LDS): fence the compiler, nothing to wait for
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
 struct DfsArgs {
   K3Args k;
   const uint8_t *text;
@@ -437,28 +450,17 @@ __global__ __launch_bounds__(256) void kd_jobs_kernel(DfsArgs a, uint32_t first)
   }
 }
 
-__device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, uint32_t s, uint32_t x0, uint32_t x1, uint64_t round,
-                                               uint32_t lane, DNode &next, uint64_t &nodes_out) {
-  const K3Args &k = a.k;
-  const uint32_t n = k.n, x = x0 + x1;
-  if (x > KD_STAIRS_MAXX) return 0;
-  const uint64_t tz0 = a.dbg ? clock64() : 0;
-  // stride: the smallest distance between neighbouring rows among 64 samples (rows of one region are neighbours
-  // almost everywhere; a wrong guess fails the decomposition)
-  uint32_t p;
-  {
-    const uint32_t i = (uint32_t)(((uint64_t)(x - 2u) * lane) / 63u);
-    const uint32_t qa = a.sa[s + i], qb = a.sa[s + i + 1u];
-    p = wave_min_u32(qa > qb ? qa - qb : qb - qa);
-  }
-  if (p == 0 || p > 65536u) return 0;
-  // starts and ends of the progressions
-  uint32_t nS = 0, nE = 0;
+// The scan of a node's rows for the starts and the ends of its progressions (stride p): wave wv of nw takes the chunks
+// wv, wv + nw, ... (256 rows each, 4 per lane so that the dependent loads of 4 rows overlap; from both ends inwards: the
+// starts and ends of many regions gather there, and too many = give up early).  Results go to R->tS / R->tE through the
+// counters of the job; more than KD_REGIONS of either sets job->fail.
+__device__ __forceinline__ void stairs_scan_share(const DfsArgs &a, StairRegs *R, ScanJob *job, uint32_t wv, uint32_t nw, uint32_t lane) {
+  const uint32_t n = a.k.n;
+  const uint32_t s = job->s, x = job->x, p = job->p;
   const uint64_t lt = (1ull << lane) - 1ull;
-  // (chunks of 256 rows, 4 per lane so that the dependent loads of 4 rows overlap; from both ends inwards: starts
-  //  and ends of many regions gather there, and too many = give up early)
   const uint32_t nchunk = (x + 255u) / 256u;
-  for (uint32_t it = 0; it < nchunk; ++it) {
+  for (uint32_t it = wv; it < nchunk; it += nw) {
+    if (__hip_atomic_load(&job->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
     const uint32_t base = 256u * ((it & 1u) ? nchunk - 1u - (it >> 1) : (it >> 1));
     uint32_t q[4];
     bool have[4], st[4], en[4];
@@ -476,24 +478,126 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
       en[j] = have[j] && !(rn[j] != 0xFFFFFFFFu && rn[j] - s < x);
       const uint64_t bs = __ballot(st[j]), be = __ballot(en[j]);
       const uint32_t cs = (uint32_t)__popcll(bs), ce = (uint32_t)__popcll(be);
-      if (nS + cs > KD_REGIONS || nE + ce > KD_REGIONS) return 0;
-      if (st[j]) R->tS[nS + (uint32_t)__popcll(bs & lt)] = q[j];
-      if (en[j]) R->tE[nE + (uint32_t)__popcll(be & lt)] = q[j];
-      nS += cs; nE += ce;
+      if (cs | ce) {
+        uint32_t oS = 0, oE = 0;
+        if (lane == 0) { if (cs) oS = atomicAdd(&job->nS, cs); if (ce) oE = atomicAdd(&job->nE, ce); }
+        oS = (uint32_t)__builtin_amdgcn_readfirstlane((int)oS);
+        oE = (uint32_t)__builtin_amdgcn_readfirstlane((int)oE);
+        if (oS + cs > KD_REGIONS || oE + ce > KD_REGIONS) {
+          if (lane == 0) __hip_atomic_store(&job->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          return;
+        }
+        if (st[j]) R->tS[oS + (uint32_t)__popcll(bs & lt)] = q[j];
+        if (en[j]) R->tE[oE + (uint32_t)__popcll(be & lt)] = q[j];
+      }
     }
+  }
+}
+// the waves 1 .. KD_HELP - 1 of a wave-walker's block: sleep until the walker posts a scan, take a share, report, sleep
+__device__ __forceinline__ void stairs_helper(const DfsArgs &a, StairRegs *R, ScanJob *job, uint32_t wv, uint32_t lane) {
+  uint32_t seen = 0;
+  for (;;) {
+    uint32_t sq;
+    do {
+      __builtin_amdgcn_s_sleep(16);
+      sq = __hip_atomic_load(&job->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } while (sq == seen);
+    if (sq == 0xFFFFFFFFu) return;
+    seen = sq;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    stairs_scan_share(a, R, job, wv, (uint32_t)KD_HELP, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(&job->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
+__device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, ScanJob *job, bool job_helpers, uint32_t s, uint32_t x0, uint32_t x1, uint64_t round,
+                                               uint32_t lane, DNode &next, uint64_t &nodes_out) {
+  const K3Args &k = a.k;
+  const uint32_t n = k.n, x = x0 + x1;
+  if (x > KD_STAIRS_MAXX) return 0;
+  const uint64_t tz0 = a.dbg ? clock64() : 0;
+  // stride: the smallest distance between neighbouring rows among 64 samples (rows of one region are neighbours
+  // almost everywhere; a wrong guess fails the decomposition)
+  uint32_t p;
+  {
+    const uint32_t i = (uint32_t)(((uint64_t)(x - 2u) * lane) / 63u);
+    const uint32_t qa = a.sa[s + i], qb = a.sa[s + i + 1u];
+    p = wave_min_u32(qa > qb ? qa - qb : qb - qa);
+  }
+  if (p == 0 || p > 65536u) return 0;
+  // starts and ends of the progressions
+  uint32_t nS = 0, nE = 0;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  // Fast path (round 3): 64 sample rows GALLOP along the stride -- q, q + p, q + 2p, q + 4p, ... while the position is a
+  // row of the node, then bisect -- to the two ends of their progression: O(64 log x) dependent loads instead of the scan
+  // of all x rows below (one wave, three dependent loads per 256 rows: 8 M cycles for the 10^6-row nodes of the binary
+  // corpus, which made a whole pass wait for one wave).  A progression found this way is only a claim that every step
+  // between its ends is a row; the checks below do not rely on it: the periodicity test proves it (lo and lo + p are
+  // rows, so the period reaches the node's depth before lo, and every lo + jp <= hi has the context of lo), the
+  // intervals must be disjoint, and the rows must add up to x -- x distinct rows of an x-row node are the node.  If
+  // the samples miss a region the sum falls short and the scan runs as before.
+  bool fast = false;
+  if (x >= 1024u) {
+    const uint32_t i = (uint32_t)(((uint64_t)(x - 1u) * lane) / 63u);
+    const uint32_t q0 = a.sa[s + i];
+    auto member = [&](uint64_t q) -> bool { return q < n && (a.isa[q] - s) < x; };
+    uint32_t kf = 0, kb = 0;
+    {
+      uint64_t k = 1;
+      while (k <= x && member((uint64_t)q0 + k * p)) { kf = (uint32_t)k; k <<= 1; }
+      uint64_t hi_k = k;                                     // not a row (or beyond the text, or more steps than rows)
+      while (hi_k - kf > 1) { const uint64_t mid = (kf + hi_k) >> 1; if (member((uint64_t)q0 + mid * p)) kf = (uint32_t)mid; else hi_k = mid; }
+    }
+    {
+      uint64_t k = 1;
+      while (k <= x && k * p <= q0 && member((uint64_t)q0 - k * p)) { kb = (uint32_t)k; k <<= 1; }
+      uint64_t hi_k = k;
+      while (hi_k - kb > 1) { const uint64_t mid = (kb + hi_k) >> 1; if (mid * p <= q0 && member((uint64_t)q0 - mid * p)) kb = (uint32_t)mid; else hi_k = mid; }
+    }
+    const uint32_t S0 = q0 - kb * p, E0 = q0 + kf * p;
+    bool first = true;                                       // the first lane of every distinct progression keeps it
+    for (uint32_t j = 0; j < 64u; ++j) { const uint32_t sj = (uint32_t)__shfl((int)S0, (int)j); if (j < lane && sj == S0) first = false; }
+    const uint64_t bf = __ballot(first);
+    const uint32_t nr0 = (uint32_t)__popcll(bf);
+    const uint32_t rows = wave_sum_u32(first ? kf + kb + 1u : 0u);
+    if (nr0 >= 2u && nr0 <= KD_REGIONS && rows == x) {
+      if (first) { const uint32_t r = (uint32_t)__popcll(bf & lt); R->tS[r] = S0; R->tE[r] = E0; }
+      nS = nE = nr0;
+      fast = true;
+    }
+    if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_hist[fast ? 26 : 27], 1u);
+  }
+  if (!fast) {
+    const uint32_t nw = (job_helpers && x >= KD_HELP_MINX) ? (uint32_t)KD_HELP : 1u;
+    if (lane == 0) { job->s = s; job->x = x; job->p = p; job->nS = 0; job->nE = 0; job->fail = 0; job->done = 0; }
+    wsync();
+    if (nw > 1u) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(&job->seq, job->seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    stairs_scan_share(a, R, job, 0u, nw, lane);
+    if (nw > 1u) {
+      while (__hip_atomic_load(&job->done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < nw - 1u) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    wsync();
+    if (__hip_atomic_load(&job->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return 0;
+    nS = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&job->nS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    nE = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&job->nE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
   }
   if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_hist[28], (uint32_t)((clock64() - tz0) >> 10));
   if (nS != nE || nS < 2) return 0;
   const uint32_t nr = nS;
   const uint64_t tz1 = a.dbg ? clock64() : 0;
-  __syncthreads();
+  wsync();
   if (lane < nr) {                                            // sort both lists (distinct values): rank by counting
     uint32_t rs = 0, re = 0;
     const uint32_t vs = R->tS[lane], ve = R->tE[lane];
     for (uint32_t j = 0; j < nr; ++j) { rs += R->tS[j] < vs ? 1u : 0u; re += R->tE[j] < ve ? 1u : 0u; }
     R->S[rs] = vs; R->E[re] = ve;
   }
-  __syncthreads();
+  wsync();
   {
     bool bad = false;
     uint32_t xr = 0;
@@ -506,7 +610,7 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
     const uint32_t tot = wave_sum_u32(xr);
     if (__any(bad) || tot != x) return 0;
   }
-  __syncthreads();
+  wsync();
   // periodicity of every region, the bytes before its start, and the same pattern in all regions
   const uint32_t hi0 = R->E[0];
   for (uint32_t r = 0; r < nr; ++r) {
@@ -519,7 +623,7 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
     if (d == a.text[as + p - 1u]) return 0;                   // (only when as == 0: the period goes on around the end)
     if (lane == 0) { R->Bv[r] = lce - span; R->D[r] = d; }
   }
-  __syncthreads();
+  wsync();
   if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_hist[29], (uint32_t)((clock64() - tz1) >> 10));
   const uint64_t tz2 = a.dbg ? clock64() : 0;
   // sides: every row is on the side of region 0's first row except, possibly, the regions' last rows
@@ -539,7 +643,7 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
     etot += e;
   }
   if (lane == 0) R->PE[nr] = etot;
-  __syncthreads();
+  wsync();
   uint32_t base = 0;
   if (etot) {
     if (lane == 0) base = atomicAdd(&a.dctl->nsym, etot);
@@ -550,7 +654,7 @@ __device__ __forceinline__ uint32_t stairs_run(const DfsArgs &a, StairRegs *R, u
     R->kind = 2; R->p = p; R->x0 = x0; R->x1 = x1; R->base = base; R->events = etot; R->round = round;
     R->nr = nr; R->beta = beta; R->nbar = nbar; R->hi0 = hi0;
   }
-  __syncthreads();
+  wsync();
   if (!stair_defer(a, *R, lane, true))
     for (uint32_t e = lane; e < etot; e += 64) stairs_event(a, *R, e);
   {
@@ -604,15 +708,22 @@ __device__ __forceinline__ uint32_t spine_burst(const DfsArgs &a, SpineLds *S, u
   uint32_t L = 0, cs = s, cx0 = x0, cx1 = x1;
   const uint64_t tph0 = a.dbg ? clock64() : 0;
   if (lane == 0) { S->s[0] = s; S->x0[0] = x0; S->x1[0] = x1; }
-  // number of leading bytes (going backwards from p, capped at 64) on which position p agrees with position pm
-  auto agree = [&](uint32_t p, uint32_t pm) -> uint32_t {
+  // number of leading bytes (going backwards from p, capped at 64) on which position p agrees with position pm, whose 64
+  // bytes are in `mid` when pm >= 64 (loaded once per look: every candidate is compared with the same middle row).  16 bytes
+  // per load: a look was ~200 four-byte loads per lane and bound by issuing them (58 K cycles per burst on the binary corpus).
+  auto load16 = [&](uint32_t pos) -> uint4 { uint4 v; __builtin_memcpy(&v, a.text + pos, 16); return v; };
+  auto agree = [&](uint32_t p, uint32_t pm, const uint4 *mid) -> uint32_t {
     if (p >= 64u && pm >= 64u) {
       uint32_t m = 0;
 #pragma unroll
-      for (uint32_t kq = 0; kq < 16u; ++kq) {
-        const uint32_t d = ld32u(a.text + (p - 4u * kq - 4u)) ^ ld32u(a.text + (pm - 4u * kq - 4u));
-        // (little-endian: the nearest byte is the most significant one)
-        if (m == 4u * kq) m += d ? (uint32_t)__clz((int)d) >> 3 : 4u;
+      for (uint32_t kq = 0; kq < 4u; ++kq) {
+        const uint4 v = load16(p - 16u * kq - 16u);
+        // (little-endian: the nearest byte is the most significant one of the highest word)
+        const uint32_t d3 = v.w ^ mid[kq].w, d2 = v.z ^ mid[kq].z, d1 = v.y ^ mid[kq].y, d0 = v.x ^ mid[kq].x;
+        if (m == 16u * kq) m += d3 ? (uint32_t)__clz((int)d3) >> 3 : 4u;
+        if (m == 16u * kq + 4u) m += d2 ? (uint32_t)__clz((int)d2) >> 3 : 4u;
+        if (m == 16u * kq + 8u) m += d1 ? (uint32_t)__clz((int)d1) >> 3 : 4u;
+        if (m == 16u * kq + 12u) m += d0 ? (uint32_t)__clz((int)d0) >> 3 : 4u;
       }
       return m;
     }
@@ -657,7 +768,12 @@ __device__ __forceinline__ uint32_t spine_burst(const DfsArgs &a, SpineLds *S, u
     const bool vA = lane < cx0, vB = lane < cx1;
     const uint32_t pM = uni(a.sa[rmid]);
     const uint32_t pA = vA ? a.sa[cs + lane] : 0u, pB = vB ? a.sa[cs + cx0 + lane] : 0u, pE = vB ? a.sa[cs + x - 1u - lane] : 0u;
-    const uint32_t mA = vA ? agree(pA, pM) : 0u, mB = vB ? agree(pB, pM) : 0u, mE = vB ? agree(pE, pM) : 0u;
+    uint4 mid[4] = {};
+    if (pM >= 64u) {
+#pragma unroll
+      for (uint32_t kq = 0; kq < 4u; ++kq) mid[kq] = load16(pM - 16u * kq - 16u);
+    }
+    const uint32_t mA = vA ? agree(pA, pM, mid) : 0u, mB = vB ? agree(pB, pM, mid) : 0u, mE = vB ? agree(pE, pM, mid) : 0u;
     const uint32_t room = KD_SPINE_LEVELS - L;
     uint32_t J = wave_max(mA);
     { const uint32_t jb = wave_max(mB), je = wave_max(mE); J = J < jb ? J : jb; J = J < je ? J : je; J = J < room ? J : room; }
@@ -686,7 +802,7 @@ __device__ __forceinline__ uint32_t spine_burst(const DfsArgs &a, SpineLds *S, u
     __builtin_amdgcn_wave_barrier();
   }
   if (L == 0) return 0;
-  __syncthreads();
+  wsync();
   const uint64_t tph1 = a.dbg ? clock64() : 0;
   if (a.dbg && lane == 0) atomicAdd(&a.dctl->dbg_why[4], (uint32_t)((tph1 - tph0) >> 10));
   // ---- the eight planes of every level, one lane per level ----
@@ -735,7 +851,7 @@ __device__ __forceinline__ uint32_t spine_burst(const DfsArgs &a, SpineLds *S, u
   const bool bad = act && (nd.s != S->s[lane + 1u] || nd.x0 != S->x0[lane + 1u] || nd.x1 != S->x1[lane + 1u]);
   if (__any(bad)) { a.dctl->err = 8; return 0xFFFFFFFFu; }
   for (uint32_t j = used + lane; j < 8u * L; j += 64u) { a.ts[base + j] = 0; a.trlo[base + j] = 0; a.trhi[base + j] = KD_HOLE; }
-  __syncthreads();
+  wsync();
   if (nside) {
     uint32_t o = 0;
     if (lane == 0) o = atomicAdd(&a.dctl->queued, nside);
@@ -756,9 +872,18 @@ __device__ __forceinline__ uint32_t spine_burst(const DfsArgs &a, SpineLds *S, u
 // depth-first; after a.budget classified nodes it hands everything it still holds (current node, stack, queued
 // nodes not started) to the next pass, where each of those gets a walker of its own: that is the load balancing.
 template <bool UNI>
-__global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
+__global__ __launch_bounds__(UNI ? KD_T * KD_HELP : KD_T) void k3_dfs_kernel(DfsArgs a) {
   __shared__ DNode lstack[UNI ? KD_STACK : 1];
   __shared__ StairRegs sregs;
+  __shared__ ScanJob sjob;
+  const bool helpers = UNI && blockDim.x > (unsigned)KD_T;
+  if (UNI && threadIdx.x == 0) sjob.seq = 0;
+  if (helpers) {
+    __syncthreads();                                         // (the only workgroup barrier of this kernel: before anything diverges)
+    if (threadIdx.x >= (unsigned)KD_T) { stairs_helper(a, &sregs, &sjob, threadIdx.x >> 6, threadIdx.x & 63u); return; }
+  }
+  // wave 0 walks; on every way out it sends the helpers home
+  struct Bye { ScanJob *j; bool on; __device__ ~Bye() { if (on && (threadIdx.x & 63u) == 0) __hip_atomic_store(&j->seq, 0xFFFFFFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); } } bye{&sjob, helpers};
   __shared__ __attribute__((aligned(8))) uint32_t spine_raw[UNI ? sizeof(SpineLds) / 4 : 1];
   SpineLds *const spine = reinterpret_cast<SpineLds *>(spine_raw);
   const K3Args &k = a.k;
@@ -895,7 +1020,7 @@ __global__ __launch_bounds__(KD_T) void k3_dfs_kernel(DfsArgs a) {
         DNode nx{0u, 1u, 1u, 0u, 0ull};
         const uint64_t tq = UNI ? 0 : clock64();
         if ((singles >> L) & 1ull) ok = uni(stair_run(a, sL, x0L, x1L, rL, lane, nn, mr) ? 1u : 0u) != 0u;
-        if (!ok) res = uni(stairs_run(a, &sregs, sL, x0L, x1L, rL, lane, nx, nn));
+        if (!ok) res = uni(stairs_run(a, &sregs, &sjob, helpers, sL, x0L, x1L, rL, lane, nx, nn));
         if (UNI || (int)lane == L) {
           if (!UNI) visited += (uint32_t)((clock64() - tq) >> 12);
           if (ok) { consumed = true; nodes += nn; maxround = mr > maxround ? mr : maxround; }
@@ -1449,7 +1574,7 @@ retry:
     const uint32_t walkers = count < wmax ? count : wmax;
     static const uint32_t uni_max = getenv("BCE_HIP_UNI_MAX") ? (uint32_t)strtoul(getenv("BCE_HIP_UNI_MAX"), nullptr, 10) : KD_UNI_MAX;
     if (passes > 0 && count <= uni_max && !getenv("BCE_HIP_DFS_NO_UNI"))   // few walkers left: one WAVE each
-      hipLaunchKernelGGL(k3_dfs_kernel<true>, dim3(count), dim3(KD_T), 0, c->stream, a);
+      hipLaunchKernelGGL(k3_dfs_kernel<true>, dim3(count), dim3((count <= KD_HELP_MAXW && !getenv("BCE_HIP_DFS_NO_HELP")) ? KD_T * KD_HELP : KD_T), 0, c->stream, a);
     else {
       // (fewer walkers per wave -- BCE_HIP_DFS_LPW -- was measured on 62 K walkers: 64 lanes 16.7 ms, 32: 18.3, 16: 20.9, 4: 35.8:
       //  a pass lasts as long as its longest walk, not as the comparisons a wave serves one after the other)
@@ -1494,7 +1619,7 @@ retry:
             passes, h.err, h.nsym, cap, (unsigned long long)h.nodes, (unsigned long long)h.maxround, h.dbg_maxvis, h.dbg_skips,
             (unsigned long long)h.dbg_skipbytes, h.dbg_stairs & 0xFFFFu, h.dbg_stairs >> 16, h.dbg_stairsyms);
     for (int i = 0; i < 28; ++i) if (h.dbg_hist[i]) fprintf(stderr, "  x in [2^%d, 2^%d): %u nodes\n", i, i + 1, h.dbg_hist[i]);
-    fprintf(stderr, "  several-region staircases, K cycles: decomposition %u, periodicity %u, sides + events %u\n", h.dbg_hist[28], h.dbg_hist[29], h.dbg_hist[30]);
+    fprintf(stderr, "  several-region staircases, K cycles: decomposition %u, periodicity %u, sides + events %u; decompositions by galloping %u, by scanning all rows %u\n", h.dbg_hist[28], h.dbg_hist[29], h.dbg_hist[30], h.dbg_hist[26], h.dbg_hist[27]);
   }
   if (h.err == 2 && cap64 < left + 64 && cap64 < (512u << 20)) { cap_scale *= 4; goto retry; }   // nothing was modified: once more with more room
   if (h.err) return BCE_HIP_OK;                     // fall back to the rounds; nothing was modified
