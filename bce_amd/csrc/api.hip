@@ -1,6 +1,7 @@
 // api.hip -- the C ABI of libbcehip.so (include/bce_hip.h): context lifetime, stage entry points and
 // the host-side driver of BCE::encode (bce.cpp:1117-1167).
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <utility>
@@ -249,6 +250,7 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   for (DevBuf *b : bufs) release(*b);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   if (c->h_small) (void)hipHostFree(c->h_small);
+  if (c->h_big) (void)hipHostFree(c->h_big);
   if (c->h_runs) (void)hipHostFree(c->h_runs);
   if (c->h_truns) (void)hipHostFree(c->h_truns);
   if (c->coder) c->coder->drain();
@@ -493,6 +495,7 @@ int bce_hip_enum_model(bce_hip_ctx *c, uint32_t *out, uint64_t cap_records, uint
 
 // ---- BCE::encode ------------------------------------------------------------------------------------
 static int encode_body(bce_hip_ctx *c);
+static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(uint64_t)> &sink);
 int bce_hip_encode(bce_hip_ctx *c) { return gate_on_error(c, bce_guarded(c, [&] { return encode_body(c); })); }
 static int encode_body(bce_hip_ctx *c) {
   BCE_TRY(check_stage(c, 3));
@@ -506,9 +509,33 @@ static int encode_body(bce_hip_ctx *c) {
   c->coder->begin(c->config, C, n);
   c->stats.symbols = 0; c->stats.flushes = 0; c->stats.t_model = 0; c->stats.t_coder = 0;
 
-  uint64_t cur_nodes = 0;
-  for (int i = 0; i < 8; ++i) cur_nodes += (C[i] && n - C[i]) ? 1 : 0;
   EnumCtl ctl;
+  BCE_TRY(enumerate_body(c, ctl, [&](uint64_t nsym) { return flush_symbols(c, nsym); }));
+  gate_release(c);                               // the GPU phase is over (the last flush and its copy are queued): next context
+  {
+    const double tw = now_s();
+    c->coder->drain();                           // coding of the last batches (the exposed part)
+    c->stats.t_coder += now_s() - tw;
+    for (FlushSlot &sl : c->slot) account_slot(c, sl);
+  }
+  if (c->coder->failed()) { snprintf(c->err, sizeof c->err, "host allocation failed in a range-coder thread"); return BCE_HIP_E_NOMEM; }
+  c->stats.t_coder_busy = c->coder->busy_seconds();
+  c->stats.rounds = ctl.done_round;
+  c->stats.nodes = ctl.nodes_total;
+  c->coder->finish(c->config, n, c->offset);     // the archive is laid out by bce_hip_archive_copy, straight into the caller's buffer
+  c->enum_active = false;
+  c->stage = 4;
+  c->stats.t_enum = c->stats.k3_ms * 1e-3;      // GPU time of the enumeration; K4, copies and coding overlap it and each other
+  return BCE_HIP_OK;
+}
+
+// The round loop of BCE::code (bce.cpp:1246-1371) as the host drives it: wide rounds in batches, one-launch rounds, the
+// LDS tail kernel, the depth-first tail.  `sink(nsym)` takes the symbol records buffered so far (the model flush of -c,
+// the ScanCoders of -s) and leaves the buffer empty.
+static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(uint64_t)> &sink) {
+  const uint32_t n = c->n;
+  uint64_t cur_nodes = 0;
+  for (int i = 0; i < 8; ++i) { const uint32_t Ci = c->zeros[(i + 7) & 7]; cur_nodes += (Ci && n - Ci) ? 1 : 0; }
   bool decaying = false;
   bool have_ctl = false, wide_once = false;
   const uint32_t early_max = 4;                   // early small flushes: 1M, 2M, 4M, 8M records (0..5 measured: +3 % on text, neutral on random data)
@@ -524,7 +551,7 @@ static int encode_body(bce_hip_ctx *c) {
       // come after everything emitted so far, so flush that first.
       const uint64_t all = 8ull * (n - 1);
       if (dfs_try < 2 && ctl.next_nodes && ctl.next_nodes <= kDfsEnter[dfs_try] && (ctl.nodes_total >= all / 8 || c->round >= 1024u || c->dbg_tail_round)) {
-        BCE_TRY(flush_symbols(c, ctl.sym_total));
+        BCE_TRY(sink(ctl.sym_total));
         ctl.sym_total = 0;
         bool dfs_done = false;
         BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -535,7 +562,7 @@ static int encode_body(bce_hip_ctx *c) {
         { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms; }
         if (dfs_done) {
           BCE_TRY(k3_sync_ctl(c, &ctl));
-          BCE_TRY(flush_symbols(c, ctl.sym_total));
+          BCE_TRY(sink(ctl.sym_total));
           break;
         }
         ++dfs_try;                                // out of room (symbols / queue): carry on with rounds
@@ -612,36 +639,21 @@ static int encode_body(bce_hip_ctx *c) {
         BCE_TRY(k3_grow_symbols(c, want));
         continue;
       }
-      BCE_TRY(flush_symbols(c, ctl.sym_total));
+      BCE_TRY(sink(ctl.sym_total));
       continue;
     }
     if (done) {
-      BCE_TRY(flush_symbols(c, ctl.sym_total));
+      BCE_TRY(sink(ctl.sym_total));
       break;
     }
     // The host coders are the critical path from the first batch on: hand them small batches early (1M, 2M, 4M, 8M
     // records) instead of waiting for the symbol buffer to fill, so that they are never idle while the GPU works on
     // the next 16M.
     if (c->stats.flushes < early_max && ctl.sym_total >= ((uint64_t)1 << (20 + c->stats.flushes))) {
-      BCE_TRY(flush_symbols(c, ctl.sym_total));
+      BCE_TRY(sink(ctl.sym_total));
       ctl.sym_total = 0;                         // the host copy is consulted again at the top of the loop
     }
   }
-  gate_release(c);                               // the GPU phase is over (the last flush and its copy are queued): next context
-  {
-    const double tw = now_s();
-    c->coder->drain();                           // coding of the last batches (the exposed part)
-    c->stats.t_coder += now_s() - tw;
-    for (FlushSlot &sl : c->slot) account_slot(c, sl);
-  }
-  if (c->coder->failed()) { snprintf(c->err, sizeof c->err, "host allocation failed in a range-coder thread"); return BCE_HIP_E_NOMEM; }
-  c->stats.t_coder_busy = c->coder->busy_seconds();
-  c->stats.rounds = ctl.done_round;
-  c->stats.nodes = ctl.nodes_total;
-  c->coder->finish(c->config, n, c->offset);     // the archive is laid out by bce_hip_archive_copy, straight into the caller's buffer
-  c->enum_active = false;
-  c->stage = 4;
-  c->stats.t_enum = c->stats.k3_ms * 1e-3;      // GPU time of the enumeration; K4, copies and coding overlap it and each other
   return BCE_HIP_OK;
 }
 
@@ -662,60 +674,33 @@ static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes) {
   c->coder->drain();
   c->scan_mode = true;
   struct Reset { bce_hip_ctx *c; ~Reset() { c->scan_mode = false; } } reset{c};
-  const uint32_t n = c->n;
   BCE_TRY(k4_prepare(c));
   BCE_TRY(k3_begin(c));
   c->stats.t_coder = 0;
   ScanSet coders;                                          // planes 0-7 + the header coder, on a pool of host threads
   std::vector<uint32_t> host;
+  double t_copy = 0, t_record = 0;
   auto consume = [&](uint64_t nsym) -> int {
     if (nsym) {
+      const double tc0 = now_s();
       host.resize((size_t)nsym * 5);
       BCE_HIP_TRY(c, hipMemcpy(host.data(), c->scanrec.p, (size_t)nsym * 20, hipMemcpyDeviceToHost));
+      t_copy += now_s() - tc0;
       std::vector<ScanSpan> spans[8];
       for (int p = 0; p < 8; ++p)
         for (const RunEntry &e : c->run_log[p]) spans[p].push_back(ScanSpan{e.start, e.count});
       const double t0 = now_s();
       coders.consume(host.data(), spans);
       c->stats.t_coder += now_s() - t0;
+      t_record += now_s() - t0;
     }
     return k3_reset_symbols(c);
   };
-  uint64_t cur_nodes = 0;
-  for (int i = 0; i < 8; ++i) { const uint32_t C = c->zeros[(i + 7) & 7]; cur_nodes += (C && n - C) ? 1 : 0; }
   EnumCtl ctl;
-  for (;;) {
-    const uint32_t first = c->round;
-    uint32_t executed = 0;
-    if (cur_nodes <= K3_TAIL_ENTER) {
-      BCE_TRY(k3_tail(c));
-      BCE_TRY(k3_sync_ctl(c, &ctl));
-      executed = ctl.tail_rounds;
-      BCE_TRY(k3_fetch_tail_runs(c, executed));
-    } else {
-      const uint32_t batch = cur_nodes > (1u << 20) ? 4u : 16u;
-      BCE_TRY(k3_rounds(c, batch, 0));
-      BCE_TRY(k3_sync_ctl(c, &ctl));
-      executed = ctl.need_flush ? ctl.skip_round - first : batch;
-      BCE_TRY(k3_fetch_runs(c, first, executed));
-    }
-    if (ctl.stalled) { snprintf(c->err, sizeof c->err, "k3: a single-launch round waited too long for a predecessor tile (dispatch order not as assumed)"); return BCE_HIP_E_INTERNAL; }
-    if (ctl.overflow) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
-    c->round = first + executed;
-    if (c->progress) c->progress(ctl.nodes_total, 8ull * n, c->progress_user);
-    cur_nodes = ctl.next_nodes;
-    if (ctl.need_flush) {
-      if (ctl.sym_total == 0) {
-        const uint64_t want = ctl.want_syms + (ctl.want_syms >> 3) + 1024;
-        if (want >= (1ull << 31)) return BCE_HIP_E_OVERFLOW;
-        BCE_TRY(k3_grow_symbols(c, want));
-        continue;
-      }
-      BCE_TRY(consume(ctl.sym_total));
-      continue;
-    }
-    if (ctl.done_round != 0xFFFFFFFFu) { BCE_TRY(consume(ctl.sym_total)); break; }
-  }
+  c->stats.flushes = 0; c->stats.symbols = 0;
+  BCE_TRY(enumerate_body(c, ctl, [&](uint64_t nsym) { c->stats.flushes++; c->stats.symbols += nsym; return consume(nsym); }));
+  c->stats.rounds = ctl.done_round;
+  c->stats.nodes = ctl.nodes_total;
   c->enum_active = false;
   uint8_t init[9][32];
   memset(init, 0, sizeof init);                            // ScanCoder::init_ is a zero-initialised static (:834)
@@ -723,7 +708,9 @@ static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes) {
   const double tf0 = now_s();
   coders.flush(init, res);                                 // coder_[i].flush() :1135-1138, then main(-1).flush() :1141-1149
   c->stats.t_coder += now_s() - tf0;
-  if (getenv("BCE_HIP_SCAN_DEBUG")) fprintf(stderr, "scan: host recording + optimisation %.3f s on %u threads\n", c->stats.t_coder, coders.threads());
+  if (getenv("BCE_HIP_SCAN_DEBUG"))
+    fprintf(stderr, "scan: %llu symbols in %llu batches: device-to-host copies %.3f s, recording %.3f s, optimisation %.3f s on %u host threads; K3 %.1f ms\n",
+            (unsigned long long)c->stats.symbols, (unsigned long long)c->stats.flushes, t_copy, t_record, now_s() - tf0, coders.threads(), c->stats.k3_ms);
   if (result_bytes) memcpy(result_bytes, res, sizeof res);
   memcpy(config288, init, BCE_HIP_CONFIG_BYTES);
   return BCE_HIP_OK;

@@ -127,6 +127,8 @@ struct bce_hip_ctx {
   // pinned host staging
   void *h_ctl = nullptr, *h_runs = nullptr;
   void *h_small = nullptr;                       // 4 KB of pinned host memory for read_back()
+  void *h_big = nullptr;                         // pinned host memory for the decoder's host tail (the boundary ranks: 32 (n + 1) bytes), grow-only
+  size_t h_big_cap = 0;
   bce::FlushSlot slot[3];                        // flushes in flight: GPU fills one while the coders drain the others
   int slot_next = 0;
 

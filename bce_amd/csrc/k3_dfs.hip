@@ -103,6 +103,7 @@ __device__ __forceinline__ void wsync() {
 
 struct DfsArgs {
   K3Args k;
+  uint32_t *traw;        // scan mode: 5 words per tagged symbol (raw_symbol), else null
   const uint8_t *text;
   const uint8_t *bwt;    // K1's output: bwt[r] = the byte before row r (spine bursts)
   const uint32_t *sa, *isa;
@@ -266,6 +267,10 @@ __device__ __forceinline__ uint32_t chain_bytes(const DfsArgs &a, uint32_t s, ui
 // symbol's sort key) follows through j* pass-through levels.  So the events are independent of each other: one
 // lane each.  Everything is checked exactly (suffix-array stride, periodicity by comparing the text), nothing is
 // assumed about why the rows are there.  Whole wave, uniform arguments; returns false if the node is no staircase.
+// `bce -s` (scan mode): the coders want the raw tuple (sym, k, c1, c2, cs) of every symbol, not the model record
+__device__ __forceinline__ void raw_symbol(const DfsArgs &a, uint32_t i, uint32_t sym, uint32_t kk, uint32_t c1, uint32_t c2, uint32_t cs) {
+  if (a.traw) { uint32_t *r = a.traw + (size_t)i * 5; r[0] = sym; r[1] = kk; r[2] = c1; r[3] = c2; r[4] = cs; }
+}
 __device__ __forceinline__ uint32_t rank1_plane(const K3Args &k, uint32_t p, uint32_t pos) {
   const uint32_t g = div96(pos);
   return granule_rank1((k.gran + (size_t)p * k.ngran)[g], pos - g * 96u);
@@ -285,6 +290,7 @@ __device__ __forceinline__ void stair_event(const DfsArgs &a, const StairJob &J,
   const uint64_t r = J.round + 8ull * ((uint64_t)J.B + (uint64_t)e * p) + js;
   const uint32_t i = J.base + e;
   a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = pos;
+  raw_symbol(a, i, cb ? L0 : 1u - L0, 2u, cb ? 1u : xe - 1u, xe1, xe);
   a.trlo[i] = (uint32_t)r;
   a.trhi[i] = (uint32_t)(r >> 32) | (js << 8);
 }
@@ -424,6 +430,7 @@ __device__ __forceinline__ void stairs_event(const DfsArgs &a, const StairJob &J
         const uint64_t rr = J.round + 8ull * t + q;
         const uint32_t i = J.base + le[nsy];
         a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = pos;
+        raw_symbol(a, i, n0x0 - mn, mx - mn + 1u, n0x, x1n, xn);
         a.trlo[i] = (uint32_t)rr;
         a.trhi[i] = (uint32_t)(rr >> 32) | (q << 8);
         atomicAdd(&a.dctl->cntp[q], 1u);
@@ -832,6 +839,7 @@ __device__ __forceinline__ uint32_t spine_burst(const DfsArgs &a, SpineLds *S, u
       uint32_t kw, ew;
       pack_symbol(k.cfg[q], q, sym, kq, nf.n0x, nd.x1, nd.x0 + nd.x1, kw, ew);
       a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = nd.s;
+      raw_symbol(a, i, sym, kq, nf.n0x, nd.x1, nd.x0 + nd.x1);
       a.trlo[i] = (uint32_t)rr;
       a.trhi[i] = (uint32_t)(rr >> 32) | (q << 8);
     }
@@ -1123,6 +1131,7 @@ __global__ __launch_bounds__(UNI ? KD_T * KD_HELP : KD_T) void k3_dfs_kernel(Dfs
           pack_symbol(k.cfg[p], p, sym, kq, nf.n0x, nd.x1, nd.x0 + nd.x1, kw, ew);
           if (writer) {
             a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = nd.s;
+            raw_symbol(a, i, sym, kq, nf.n0x, nd.x1, nd.x0 + nd.x1);
             a.trlo[i] = (uint32_t)cur.round;
             a.trhi[i] = (uint32_t)(cur.round >> 32) | (p << 8);      // round < 2^40
             atomicAdd(&a.dctl->cntp[p], 1u);
@@ -1381,6 +1390,7 @@ __global__ __launch_bounds__(LB_T) void k3_local_kernel(DfsArgs a) {
           pack_symbol(k.cfg[p], p, sym[it], kq[it], nf[it].n0x, nd[it].x1, nd[it].x0 + nd[it].x1, kw, ew);
           const uint64_t r = a.round0 + (uint64_t)(nd[it].meta >> LB_RSH);
           a.tkey[i] = kw; a.tesc[i] = ew; a.ts[i] = nd[it].s;      // (five 4-byte stores: without them the pass is as long)
+          raw_symbol(a, i, sym[it], kq[it], nf[it].n0x, nd[it].x1, nd[it].x0 + nd[it].x1);
           a.trlo[i] = (uint32_t)r;
           a.trhi[i] = (uint32_t)(r >> 32) | (p << 8);
           atomicAdd(&s_cntp[p], 1u);
@@ -1441,6 +1451,14 @@ __global__ void kd_place_kernel(const uint32_t *__restrict__ tkey, const uint32_
   }
 }
 
+__global__ void kd_place_raw_kernel(const uint32_t *__restrict__ traw, const uint32_t *__restrict__ perm, uint32_t m, uint32_t *__restrict__ rec) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    const uint32_t *r = traw + (size_t)perm[i] * 5;
+    uint32_t *o = rec + (size_t)i * 5;
+    o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = r[4];
+  }
+}
+
 // Host side.  The tail starts when the node count has stopped growing, at most `enter` nodes are alive and an
 // eighth of all nodes has been visited (i.e. not in the ramp-up).  With more than KD_LOCAL_FROM nodes alive the
 // workgroup-local rounds come first (k3_local_kernel: one launch over the planes' lists, further ones while it
@@ -1454,7 +1472,7 @@ constexpr uint32_t KD_LOCAL_QUEUE = 16u << 20;  // walker queue / spill queue ca
 constexpr uint32_t KD_LOCAL_BUDGET = 192;       // rounds per workgroup and pass (BCE_HIP_LOCAL_BUDGET overrides; natural corpus, K3 in all: 96: 23.3 ms, 128: 21.4, 192: 21.2, 256: 21.7, 384: 21.9)
 int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done) {
   *done = false;
-  if (c->scan_mode || c->dbg_no_dfs) return BCE_HIP_OK;
+  if (c->dbg_no_dfs || (c->scan_mode && getenv("BCE_HIP_SCAN_NO_DFS"))) return BCE_HIP_OK;
   const uint32_t n = c->n;
   const uint32_t live = ctl.next_nodes;
   const uint64_t all = 8ull * (n - 1);
@@ -1485,7 +1503,8 @@ retry:
   const size_t o_sort = (size_t)cap * 4 * 5, o_ctl = o_sort + (size_t)cap * 4 * 4, o_q = o_ctl + 512,
                o_stack = o_q + 2 * (size_t)qcap * sizeof(DNode), o_jobs = o_stack + (size_t)wmax * KD_STACK * sizeof(DNode),
                o_spill = o_jobs + (size_t)KD_JOBS * sizeof(StairJob);
-  BCE_TRY(ensure(c, c->dfs, o_spill + 2 * (size_t)scap * sizeof(DNode)));
+  const size_t o_raw = o_spill + 2 * (size_t)scap * sizeof(DNode);
+  BCE_TRY(ensure(c, c->dfs, o_raw + (c->scan_mode ? (size_t)cap * 20 : 0)));
   uint8_t *base = c->dfs.as<uint8_t>();
   DfsArgs a;
   a.k = k3_make_args(c, c->round, 0);
@@ -1494,6 +1513,7 @@ retry:
   a.sa = c->sa[c->sa_res].as<uint32_t>();
   a.isa = c->rank.as<uint32_t>();
   a.skip_ok = (!c->dbg_no_skip && c->k1_valid && c->text.p && c->rank.p && c->bwt.p) ? 1u : 0u;
+  a.traw = c->scan_mode ? reinterpret_cast<uint32_t *>(base + o_raw) : nullptr;
   uint32_t *w = reinterpret_cast<uint32_t *>(base);
   a.tkey = w; a.tesc = w + cap; a.ts = w + 2 * (size_t)cap; a.trlo = w + 3 * (size_t)cap; a.trhi = w + 4 * (size_t)cap;
   uint32_t *sk[2] = {reinterpret_cast<uint32_t *>(base + o_sort), reinterpret_cast<uint32_t *>(base + o_sort) + cap};
@@ -1642,8 +1662,11 @@ retry:
     uint32_t *k3[2] = {k2[r ^ 1], k2[r]}, *v3[2] = {v2[r], v2[r ^ 1]};
     hipLaunchKernelGGL(kd_gather_kernel, dim3(g), dim3(256), 0, c->stream, a.trhi, v3[0], m, k3[0]);
     BCE_TRY(radix_sort_pairs(c, k3, v3, m, hfirst, 11u - hfirst, &r, 9));
-    hipLaunchKernelGGL(kd_place_kernel, dim3(g), dim3(256), 0, c->stream, a.tkey, a.tesc, v3[r], mv,   // the holes sorted last
-                       c->skey[0].as<uint32_t>(), c->sesc.as<uint32_t>());
+    if (c->scan_mode)
+      hipLaunchKernelGGL(kd_place_raw_kernel, dim3(g), dim3(256), 0, c->stream, a.traw, v3[r], mv, c->scanrec.as<uint32_t>());
+    else
+      hipLaunchKernelGGL(kd_place_kernel, dim3(g), dim3(256), 0, c->stream, a.tkey, a.tesc, v3[r], mv,   // the holes sorted last
+                         c->skey[0].as<uint32_t>(), c->sesc.as<uint32_t>());
   }
   // control block: the enumeration is finished
   EnumCtl *d = c->ctl.as<EnumCtl>();

@@ -76,6 +76,11 @@ double ScanCoder::trial_cost(uint32_t k, uint32_t j) const {
   const bool tabled = k <= 4;
   std::vector<double> tab;
   if (tabled) tab.assign((size_t)(255 * k + 1) * 256, -1.0);     // (a cost is never negative: l >= c)
+  // larger k: a direct-mapped cache of the same values (the full table would be 16 MB at k = 31, a handful of (l, c)
+  // pairs are hot); an entry holds the pair it was computed for
+  struct Ent { uint32_t key; double v; };
+  std::vector<Ent> cache;
+  if (!tabled) cache.assign(1u << 15, Ent{0u, 0.0});
   double z = 0;
   for (auto &g : stat_[k]) {
     uint16_t q1 = (uint16_t)(g.first >> 0), q2 = (uint16_t)(g.first >> 16);   // 8-bit quantised c1, c2
@@ -90,7 +95,10 @@ double ScanCoder::trial_cost(uint32_t k, uint32_t j) const {
         if (t < 0) t = std::log(static_cast<double>(l) / (1 + ctx[sym]));
         z += t;
       } else {
-        z += std::log(static_cast<double>(l) / (1 + ctx[sym]));
+        const uint32_t cc = 1u + ctx[sym], key = (l << 8) | cc;      // (l <= 255 k < 2^13, c <= 255: never 0)
+        Ent &e = cache[(key * 2654435761u) >> 17];
+        if (e.key != key) { e.key = key; e.v = std::log(static_cast<double>(l) / (1 + ctx[sym])); }
+        z += e.v;
       }
       if (++ctx[sym] == 0xFF)
         for (uint32_t i = 0; i < k; ++i) ctx[i] >>= 1;
@@ -128,7 +136,7 @@ ScanSet::ScanSet(unsigned threads) : threads_(threads) {
     cpu_set_t set;
     CPU_ZERO(&set);
     threads_ = sched_getaffinity(0, sizeof set, &set) == 0 ? (unsigned)CPU_COUNT(&set) : std::thread::hardware_concurrency();
-    threads_ = std::max(1u, std::min(threads_, 32u));
+    threads_ = std::max(1u, std::min(threads_, 64u));
   }
 }
 

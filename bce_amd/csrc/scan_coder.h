@@ -28,8 +28,8 @@ class ScanCoder {
   double flush(uint8_t init[9][32]);
 
   // ---- the pieces ScanSet runs side by side ----
-  static constexpr int kClasses = 4;                       // k = 2 | k = 3 | 4..7 | 8..31 (after the escape loop)
-  static int class_of(uint32_t k) { return k == 2 ? 0 : k == 3 ? 1 : k < 8 ? 2 : 3; }
+  static constexpr int kClasses = 7;                       // k = 2 | 3 | 4 | 5 | 6..7 | 8..15 | 16..31 (after the escape loop)
+  static int class_of(uint32_t k) { return k <= 5 ? (int)k - 2 : k < 8 ? 4 : k < 16 ? 5 : 6; }
   // set() for ONE class of k: the escape loop runs for every record (it decides the class), the record is kept only if
   // its final k is of class `cls`; the thread of class 0 also counts the escapes (z_ += log(2) each, :739)
   void set_class(uint32_t s, uint32_t k, uint32_t c1, uint32_t c2, uint32_t cs, int cls);
@@ -51,7 +51,7 @@ class ScanCoder {
 struct ScanSpan { uint64_t start, count; };                // records [start, start + count) of the flush buffer, in stream order
 class ScanSet {
  public:
-  explicit ScanSet(unsigned threads = 0);                  // 0 = the CPUs this process may run on, at most 32
+  explicit ScanSet(unsigned threads = 0);                  // 0 = the CPUs this process may run on, at most 64
   // records = 5 x u32 (s, k, c1, c2, cs); spans[p] = plane p's runs of this buffer in stream order
   void consume(const uint32_t *records, const std::vector<ScanSpan> spans[8]);
   void flush(uint8_t init[9][32], double result_bytes[9]);
