@@ -1114,7 +1114,7 @@ __global__ void dec_scatter_kernel(uint32_t *__restrict__ R, const uint64_t *__r
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) R[idx[i]] = val[i];
 }
 
-constexpr uint32_t kHostTailMin = 50000;                    // ... rounds, or n / 1000 if that is more (the copies cost ~n)
+constexpr uint32_t kHostTailMin = 20000;                    // ... rounds, or n / 1000 if that is more (the copies cost ~n)
 
 int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vector<Decoder> &dec, uint32_t n, uint32_t *round,
                   uint64_t *nodes_total, uint64_t *queries_total, bool *bad_out) {
@@ -1145,54 +1145,151 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
   BCE_HIP_TRY(c, hipMemcpyAsync(Rh, a.R, 8 * stride * 4, hipMemcpyDeviceToHost, c->stream));
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (getenv("BCE_DEC_TIMING")) fprintf(stderr, "gpu decode: host tail: pinned buffer %.3f s, boundary ranks to the host %.3f s (%.1f GB)\n", tcp1 - tcp0, now_s() - tcp1, 8 * stride * 4 / 1e9);
-  std::vector<uint64_t> widx;                                              // what the host learns goes back as (index, value) pairs
-  std::vector<uint32_t> wval;
-  bool bad = false;
-  uint64_t nodes = 0, queries = 0;
-  uint32_t rounds = 0;
-  for (bool again = true; again && !bad;) {
-    for (uint32_t i = 0; i < 8 && !bad; ++i) {
-      uint32_t *R = Rh + (size_t)i * stride;
-      const uint32_t zi = a.zeros[i];
-      for (int j = 0; j < 2 && !bad; ++j)
-        for (const Node &nd : cur[i][j]) {
-          const uint32_t s = nd.s, x0 = nd.x0, x1 = nd.x1, x = x0 + x1;
-          if ((uint64_t)s + x > n || R[s] == kUnknown || R[s + x] == kUnknown) { bad = true; break; }
-          const uint32_t s1 = R[s], n1x = R[s + x] - s1, s0 = s - s1;
-          if (n1x > x) { bad = true; break; }
-          uint32_t n1x0;
-          if (!n1x) { nxt[(i + 1) & 7][0].push_back(Node{s0, x0, x1}); n1x0 = 0; }
-          else if (n1x == x) { nxt[(i + 1) & 7][1].push_back(Node{zi + s1, x0, x1}); n1x0 = x0; }
-          else {
-            const uint32_t n0x = x - n1x;
-            uint32_t mn = x0 - n1x, mx = n1x - x1;
-            mn = ((int32_t)mn < 0) ? 0u : mn;
-            mx = ((int32_t)mx < 0) ? 0u : mx;
-            mx = x0 - mx;
-            uint32_t n0x0 = mn;
-            if (mx != mn) { n0x0 = mn + dec[i].get_adaptive(mx - mn + 1, n0x, x1, x); ++queries; }
-            if (n0x0 > mx) { bad = true; break; }
-            const uint32_t n0x1 = n0x - n0x0;
-            if (n0x0 && n0x1) nxt[(i + 1) & 7][0].push_back(Node{s0, n0x0, n0x1});
-            const uint32_t n1x1 = x1 - n0x1;
-            n1x0 = n1x - n1x1;
-            if (n1x0 && n1x1) nxt[(i + 1) & 7][1].push_back(Node{zi + s1, n1x0, n1x1});
-          }
-          R[s + x0] = s1 + n1x0;
-          if (widx.size() <= stride) { widx.push_back((uint64_t)i * stride + s + x0); wval.push_back(s1 + n1x0); }   // beyond that the whole array goes back
-          ++nodes;
+  // what the host learns goes back as (index, value) pairs, kept per plane (the planes are worked on side by side)
+  // (each plane's output on cache lines of its own: the headers of neighbouring std::vectors share a line, and eight threads
+  //  appending to neighbouring vectors took 13 us per round for what is 3 us of work)
+  struct alignas(128) PlaneOut {
+    std::vector<Node> o0, o1;                  // the children: next round's lists of plane i + 1
+    std::vector<uint64_t> wi;
+    std::vector<uint32_t> wv;
+    uint64_t nodes = 0, queries = 0;
+  };
+  std::unique_ptr<PlaneOut[]> po(new PlaneOut[8]);
+  const size_t pairs_max = stride / 8 + 1;                                 // beyond that (per plane) the whole array goes back
+  std::atomic<bool> bad_flag{false};
+  // One plane of one round (BCE::code mode 0, bce.cpp:1261-1351): reads and writes plane i's boundary ranks only, appends to the
+  // lists of plane i + 1 only -- the planes of a round are independent, which is the reference's own OpenMP split (:1250-1252).
+  auto do_plane = [&](uint32_t i) {
+    uint32_t *R = Rh + (size_t)i * stride;
+    const uint32_t zi = a.zeros[i];
+    PlaneOut &P = po[i];
+    std::vector<Node> &o0 = P.o0, &o1 = P.o1;
+    std::vector<uint64_t> &wi = P.wi;
+    std::vector<uint32_t> &wv = P.wv;
+    uint64_t nn = 0, qq = 0;
+    for (int j = 0; j < 2; ++j)
+      for (const Node &nd : cur[i][j]) {
+        const uint32_t s = nd.s, x0 = nd.x0, x1 = nd.x1, x = x0 + x1;
+        if ((uint64_t)s + x > n || R[s] == kUnknown || R[s + x] == kUnknown) { bad_flag.store(true); return; }
+        const uint32_t s1 = R[s], n1x = R[s + x] - s1, s0 = s - s1;
+        if (n1x > x) { bad_flag.store(true); return; }
+        uint32_t n1x0;
+        if (!n1x) { o0.push_back(Node{s0, x0, x1}); n1x0 = 0; }
+        else if (n1x == x) { o1.push_back(Node{zi + s1, x0, x1}); n1x0 = x0; }
+        else {
+          const uint32_t n0x = x - n1x;
+          uint32_t mn = x0 - n1x, mx = n1x - x1;
+          mn = ((int32_t)mn < 0) ? 0u : mn;
+          mx = ((int32_t)mx < 0) ? 0u : mx;
+          mx = x0 - mx;
+          uint32_t n0x0 = mn;
+          if (mx != mn) { n0x0 = mn + dec[i].get_adaptive(mx - mn + 1, n0x, x1, x); ++qq; }
+          if (n0x0 > mx) { bad_flag.store(true); return; }
+          const uint32_t n0x1 = n0x - n0x0;
+          if (n0x0 && n0x1) o0.push_back(Node{s0, n0x0, n0x1});
+          const uint32_t n1x1 = x1 - n0x1;
+          n1x0 = n1x - n1x1;
+          if (n1x0 && n1x1) o1.push_back(Node{zi + s1, n1x0, n1x1});
         }
+        R[s + x0] = s1 + n1x0;
+        if (wi.size() <= pairs_max) { wi.push_back((uint64_t)i * stride + s + x0); wv.push_back(s1 + n1x0); }
+        ++nn;
+      }
+    P.nodes += nn; P.queries += qq;
+  };
+  // Rounds of a few nodes run on this thread (a round of two nodes is ~0.2 us: no barrier is worth that); from kParMin nodes
+  // on the eight planes go to eight threads -- this one and seven helpers that spin on the round number (and doze off when
+  // nothing has come for a while).  The GPU's resident tail kernels managed 35-160 ns per node on such rounds (dependent
+  // loads, a mailbox round trip per query round); a host core does a node in ~40-100 ns, eight of them side by side.
+  constexpr size_t kParMin = 16;              // (a round on eight threads costs ~1 us of barrier; a node ~0.1 us)
+  constexpr uint32_t kParkAfter = 4096;       // serial rounds in a row after which the helpers stop spinning
+  struct Pool {
+    std::atomic<uint64_t> epoch{0};
+    std::atomic<uint32_t> done{0};
+    std::atomic<bool> quit{false}, parked{false};
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::thread> th;
+  } pool;
+  bool threaded = !getenv("BCE_DEC_TAIL_SERIAL") && std::thread::hardware_concurrency() >= 8u;
+  if (threaded) try {
+    for (uint32_t w = 1; w < 8; ++w)
+      pool.th.emplace_back([&, w] {
+        uint64_t seen = 0;
+        uint32_t idle = 0;
+        for (;;) {
+          const uint64_t e = pool.epoch.load(std::memory_order_acquire);
+          if (e != seen) {
+            seen = e;
+            do_plane(w);
+            pool.done.fetch_add(1, std::memory_order_release);
+            idle = 0;
+            continue;
+          }
+          if (pool.quit.load(std::memory_order_acquire)) return;
+          if (pool.parked.load(std::memory_order_acquire)) {             // the chains have begun: sleep until rounds get wide again
+            std::unique_lock<std::mutex> lk(pool.mu);
+            pool.cv.wait(lk, [&] { return !pool.parked.load() || pool.quit.load(); });
+            continue;
+          }
+          (void)idle;
+          __builtin_ia32_pause();
+        }
+      });
+  } catch (...) {                                                          // no threads to be had: the rounds run on this one
+    { std::lock_guard<std::mutex> lk(pool.mu); pool.quit.store(true, std::memory_order_release); }
+    pool.cv.notify_all();
+    for (auto &t : pool.th) t.join();
+    pool.th.clear();
+    threaded = false;
+  }
+  uint64_t par_rounds = 0;
+  uint32_t rounds = 0, serial_run = 0;
+  auto unpark = [&] { { std::lock_guard<std::mutex> lk(pool.mu); pool.parked.store(false); } pool.cv.notify_all(); };
+  for (bool again = true; again && !bad_flag.load();) {
+    size_t tot = 0;
+    for (int i = 0; i < 8; ++i) tot += cur[i][0].size() + cur[i][1].size();
+    if (threaded && tot >= kParMin) {
+      if (pool.parked.load(std::memory_order_relaxed)) unpark();
+      serial_run = 0;
+      pool.done.store(0, std::memory_order_relaxed);
+      pool.epoch.fetch_add(1, std::memory_order_release);
+      do_plane(0);
+      while (pool.done.load(std::memory_order_acquire) < 7u) __builtin_ia32_pause();
+      ++par_rounds;
+    } else {
+      for (uint32_t i = 0; i < 8 && !bad_flag.load(std::memory_order_relaxed); ++i) do_plane(i);
+      if (threaded && ++serial_run == kParkAfter) pool.parked.store(true, std::memory_order_release);
     }
     ++rounds;
     again = false;
-    for (int i = 0; i < 8; ++i)
-      for (int j = 0; j < 2; ++j) { cur[i][j].swap(nxt[i][j]); nxt[i][j].clear(); if (!cur[i][j].empty()) again = true; }
+    for (int i = 0; i < 8; ++i) {                                          // plane i's children are plane i + 1's nodes
+      const int q = (i + 1) & 7;
+      cur[q][0].swap(po[i].o0); po[i].o0.clear();
+      cur[q][1].swap(po[i].o1); po[i].o1.clear();
+      if (!cur[q][0].empty() || !cur[q][1].empty()) again = true;
+    }
   }
+  { std::lock_guard<std::mutex> lk(pool.mu); pool.quit.store(true, std::memory_order_release); }
+  pool.cv.notify_all();
+  for (auto &t : pool.th) t.join();
+  const bool bad = bad_flag.load();
+  uint64_t nodes = 0, queries = 0;
+  bool whole = false;
+  std::vector<uint64_t> widx;
+  std::vector<uint32_t> wval;
+  for (int i = 0; i < 8; ++i) {
+    nodes += po[i].nodes; queries += po[i].queries;
+    if (po[i].wi.size() > pairs_max) whole = true;
+  }
+  if (!whole)
+    for (int i = 0; i < 8; ++i) { widx.insert(widx.end(), po[i].wi.begin(), po[i].wi.end()); wval.insert(wval.end(), po[i].wv.begin(), po[i].wv.end()); }
+  if (getenv("BCE_DEC_TIMING")) fprintf(stderr, "gpu decode: host tail: %llu of %u rounds on eight threads\n", (unsigned long long)par_rounds, rounds);
   *bad_out = bad;
   if (bad) return BCE_HIP_OK;
   const double tcp2 = now_s();
   if (getenv("BCE_DEC_TIMING")) fprintf(stderr, "gpu decode: host tail: %u rounds, %llu nodes in %.3f s\n", rounds, (unsigned long long)nodes, tcp2 - tcp0);
-  if (widx.size() > stride) {                                            // (more than an eighth of everything: the whole array)
+  if (whole) {                                                           // (more than an eighth of everything: the whole array)
     BCE_HIP_TRY(c, hipMemcpyAsync(a.R, Rh, 8 * stride * 4, hipMemcpyHostToDevice, c->stream));
     BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
   } else if (!widx.empty()) {
@@ -1312,8 +1409,15 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   const bool host_tail_ok = !getenv("BCE_DEC_NO_HOST_TAIL");
   // (ski rental: the copies cost ~1.2 ns per input byte, a round ~1.0 us less on the host than in the wave kernel, so the
   //  switch pays once n / 830 rounds are still to come -- which nobody knows -- and is made after that many have gone by)
-  const uint32_t kHostTailAfter = n / 1000u > kHostTailMin ? n / 1000u : kHostTailMin;
-  uint64_t mbox_rounds = 0, launches_wave = 0, launches_wg = 0, rounds_wg = 0;
+  const uint32_t kHostTailAfter = n / 2500u > kHostTailMin ? n / 2500u : kHostTailMin;
+  // Query-heavy tails (executables: something is coded in half of the rounds) go to the host as a whole: a query round costs the
+  // resident kernels a mailbox round trip (~10 us), the host -- eight threads, one per plane -- nothing.  Whether a tail is
+  // query-heavy is measured: the first kProbeRounds rounds of the tail kernels count their mailbox rounds.
+  constexpr uint32_t kProbeRounds = 4096;
+  uint32_t probe_rounds = 0;
+  uint64_t probe_mbox0 = 0;
+  bool probe_done = getenv("BCE_DEC_NO_PROBE") != nullptr, query_heavy = false;
+  uint64_t mbox_rounds = 0, launches_wave = 0, launches_wg = 0, rounds_wg = 0, nodes_wave = 0, nodes_wg = 0, rounds_wave = 0;
   double t_wave = 0, t_wg = 0;
   BCE_TRY(ensure(c, c->runs, 64));
   uint32_t *d_rounds = c->runs.as<uint32_t>();
@@ -1350,8 +1454,13 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
         at.mbox = mbox.dev;
         at.seq_base = next_seq;
         if (at.mbox) __atomic_store_n(&mbox.host[2], 0u, __ATOMIC_RELEASE);
-        if (wave) hipLaunchKernelGGL(dec_tail64_kernel, dim3(1), dim3(64), 0, c->stream, at, host_tail_ok ? kHostTailAfter : (1u << 30), d_rounds, resume ? 1u : 0u);
-        else hipLaunchKernelGGL(dec_tail_kernel, dim3(1), dim3(DT_T), 0, c->stream, at, 1u << 30, d_rounds, (resume ? 1u : 0u) | 2u);
+        const uint64_t all_nodes = 8ull * (n - 1u);
+        const bool probing = host_tail_ok && !probe_done && all_nodes - nodes_total >= (n >> 6) + (1u << 18);   // (a tail worth a copy of the ranks)
+        if (probing && probe_rounds == 0) probe_mbox0 = mbox_rounds;
+        const uint32_t probe_left = kProbeRounds > probe_rounds ? kProbeRounds - probe_rounds : 1u;
+        const uint32_t max_wave = !host_tail_ok ? (1u << 30) : (probing && probe_left < kHostTailAfter ? probe_left : kHostTailAfter);
+        if (wave) hipLaunchKernelGGL(dec_tail64_kernel, dim3(1), dim3(64), 0, c->stream, at, max_wave, d_rounds, resume ? 1u : 0u);
+        else hipLaunchKernelGGL(dec_tail_kernel, dim3(1), dim3(DT_T), 0, c->stream, at, probing ? probe_left : (1u << 30), d_rounds, (resume ? 1u : 0u) | 2u);
         if (at.mbox) {
           // (before the copies below are queued: a device-to-host copy into pageable memory blocks the host until the kernel is done)
           // the tail kernel stays resident over query rounds: serve its mailbox until it says it has left
@@ -1374,7 +1483,8 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
         BCE_HIP_TRY(c, hipGetLastError());
         if (getenv("BCE_DEC_TRACE")) fprintf(stderr, "tail: round %u wave %d resume %d -> done %u why %u next %u\n", round, (int)wave, (int)resume, done[0], done[1], ctl.next_nodes);
         round += done[0]; tail_rounds += done[0];
-        if (wave) { ++launches_wave; t_wave += now_s() - t_launch; } else { ++launches_wg; rounds_wg += done[0]; t_wg += now_s() - t_launch; }
+        if (wave) { ++launches_wave; rounds_wave += done[0]; nodes_wave += ctl.nodes_total - nodes_total; t_wave += now_s() - t_launch; }
+        else { ++launches_wg; rounds_wg += done[0]; nodes_wg += ctl.nodes_total - nodes_total; t_wg += now_s() - t_launch; }
         cur_nodes = ctl.next_nodes;
         nodes_total = ctl.nodes_total;
         // a resumed launch that could not even start its round (children outgrow the kernel, or an inconsistency):
@@ -1397,7 +1507,12 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
           continue;
         }
         answered_pending = stuck;
-        if (wave && host_tail_ok && done[1] == 0 && done[0] >= kHostTailAfter && cur_nodes && cur_nodes <= 64) {
+        if (probing) {
+          probe_rounds += done[0];
+          if (probe_rounds >= kProbeRounds) { probe_done = true; query_heavy = (mbox_rounds - probe_mbox0) * 3u >= probe_rounds * 2u;   // two rounds in three ask the decoders something }
+        }
+        if (host_tail_ok && done[1] == 0 && !stuck && cur_nodes &&
+            ((wave && done[0] >= kHostTailAfter && cur_nodes <= 64) || (query_heavy && cur_nodes <= DT_CAP))) {
           // a long chain of a few nodes: the rest of the rounds on the host (dec_host_tail)
           bool bad = false;
           const double th = now_s();
@@ -1475,8 +1590,9 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   if (timing) { fprintf(stderr, "gpu decode: %u rounds (%llu of them in the tail kernels, %llu query rounds answered through the mailbox), %llu nodes, %llu queries: %.3f s (query pass %.3f, copy out %.3f, host decoders %.3f, children pass %.3f)\n",
                         round, (unsigned long long)tail_rounds, (unsigned long long)mbox_rounds, (unsigned long long)nodes_total, (unsigned long long)queries_total, now_s() - tp0, t_q, t_copy, t_host, t_c); tp0 = now_s(); }
 
-  if (timing) fprintf(stderr, "gpu decode: tail kernels: wave %llu launches %.3f s, workgroup %llu launches (%llu rounds) %.3f s\n",
-                      (unsigned long long)launches_wave, t_wave, (unsigned long long)launches_wg, (unsigned long long)rounds_wg, t_wg);
+  if (timing) fprintf(stderr, "gpu decode: tail kernels: wave %llu launches (%llu rounds, %llu nodes) %.3f s, workgroup %llu launches (%llu rounds, %llu nodes) %.3f s\n",
+                      (unsigned long long)launches_wave, (unsigned long long)rounds_wave, (unsigned long long)nodes_wave, t_wave,
+                      (unsigned long long)launches_wg, (unsigned long long)rounds_wg, (unsigned long long)nodes_wg, t_wg);
   // ---- R -> planes -> granules -> BWT bytes ----
   FillArgs f;
   f.R = R; f.n = n;
