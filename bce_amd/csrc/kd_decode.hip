@@ -1509,7 +1509,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
         answered_pending = stuck;
         if (probing) {
           probe_rounds += done[0];
-          if (probe_rounds >= kProbeRounds) { probe_done = true; query_heavy = (mbox_rounds - probe_mbox0) * 3u >= probe_rounds * 2u;   // two rounds in three ask the decoders something }
+          if (probe_rounds >= kProbeRounds) { probe_done = true; query_heavy = (mbox_rounds - probe_mbox0) * 3u >= probe_rounds * 2u; /* two rounds in three ask the decoders something */ }
         }
         if (host_tail_ok && done[1] == 0 && !stuck && cur_nodes &&
             ((wave && done[0] >= kHostTailAfter && cur_nodes <= 64) || (query_heavy && cur_nodes <= DT_CAP))) {
