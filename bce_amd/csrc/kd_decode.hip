@@ -18,6 +18,7 @@
 // The archive format, the model and the coder arithmetic are the reference's; parity = decode(reference
 // archive) == input (tests/test_gpu_decode.py).  Inputs whose LF mapping is not one cycle (periodic inputs, on which
 // the reference's decoder fails) are unrolled from the cycle through row 0.
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1114,6 +1115,33 @@ __global__ void dec_scatter_kernel(uint32_t *__restrict__ R, const uint64_t *__r
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) R[idx[i]] = val[i];
 }
 
+// Eight CPUs of the calling thread's L3 domain that its affinity mask allows (empty: fewer than eight, or no sysfs):
+// where the eight threads of dec_host_tail sit so that their per-round barrier stays inside one CCX.
+static std::vector<int> tail_cpus() {
+  std::vector<int> ccx;
+  cpu_set_t aff;
+  if (getenv("BCE_DEC_TAIL_NOPIN") || sched_getaffinity(0, sizeof aff, &aff) != 0) return ccx;
+  char path[128];
+  snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", sched_getcpu());
+  if (FILE *f = fopen(path, "r")) {
+    char buf[512] = {0};
+    if (fgets(buf, sizeof buf, f)) {
+      for (char *q = buf; *q && ccx.size() < 8;) {
+        char *e;
+        long lo = strtol(q, &e, 10), hi = lo;
+        if (e == q) break;
+        if (*e == '-') { q = e + 1; hi = strtol(q, &e, 10); }
+        for (long v = lo; v <= hi && ccx.size() < 8; ++v) if (v >= 0 && v < CPU_SETSIZE && CPU_ISSET((int)v, &aff)) ccx.push_back((int)v);
+        if (*e != ',') break;
+        q = e + 1;
+      }
+    }
+    fclose(f);
+  }
+  if (ccx.size() != 8) ccx.clear();
+  return ccx;
+}
+
 constexpr uint32_t kHostTailMin = 20000;                    // ... rounds, or n / 1000 if that is more (the copies cost ~n)
 
 int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vector<Decoder> &dec, uint32_t n, uint32_t *round,
@@ -1212,9 +1240,24 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
     std::vector<std::thread> th;
   } pool;
   bool threaded = !getenv("BCE_DEC_TAIL_SERIAL") && std::thread::hardware_concurrency() >= 8u;
+  // The eight threads meet at a barrier every round: on cores that share an L3 (one CCX of the EPYC hosts) that is ~1 us, across
+  // the package 4-5 us -- more than the round's work.  So for the duration of the tail they sit on eight CPUs of this
+  // thread's L3 domain, if the affinity mask has that many (otherwise wherever the scheduler puts them).
+  std::vector<int> ccx;
+  cpu_set_t old_aff;
+  bool repin = false;
+  if (threaded && sched_getaffinity(0, sizeof old_aff, &old_aff) == 0) {
+    ccx = tail_cpus();
+    if (ccx.size() == 8) {
+      cpu_set_t one; CPU_ZERO(&one); CPU_SET(ccx[0], &one);
+      repin = sched_setaffinity(0, sizeof one, &one) == 0;
+    }
+  }
+  struct Unpin { bool on; cpu_set_t *aff; ~Unpin() { if (on) (void)sched_setaffinity(0, sizeof *aff, aff); } } unpin{repin, &old_aff};
   if (threaded) try {
     for (uint32_t w = 1; w < 8; ++w)
       pool.th.emplace_back([&, w] {
+        if (repin) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(ccx[w], &one); (void)sched_setaffinity(0, sizeof one, &one); }
         uint64_t seen = 0;
         uint32_t idle = 0;
         for (;;) {
@@ -1413,10 +1456,17 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   // Query-heavy tails (executables: something is coded in half of the rounds) go to the host as a whole: a query round costs the
   // resident kernels a mailbox round trip (~10 us), the host -- eight threads, one per plane -- nothing.  Whether a tail is
   // query-heavy is measured: the first kProbeRounds rounds of the tail kernels count their mailbox rounds.
-  constexpr uint32_t kProbeRounds = 4096;
+  constexpr uint32_t kProbeRounds = 1024;
   uint32_t probe_rounds = 0;
   uint64_t probe_mbox0 = 0;
   bool probe_done = getenv("BCE_DEC_NO_PROBE") != nullptr, query_heavy = false;
+  if (getenv("BCE_DEC_FORCE_HOST_TAIL")) { probe_done = true; query_heavy = true; }
+  // With eight CPUs on one L3 for its threads the host does a node of a tail round in ~20 ns (measured: 18.8 M nodes of the
+  // binary corpus in 0.37 s, against 1.4 s in the resident kernels; the natural corpus' 20 M nodes in 0.6 s against 1.1 s):
+  // then every tail that is worth the copy goes there and nothing is probed.
+  // ... every LONG tail, that is: the copy and the threads cost ~0.1 s, which a tail of a few hundred rounds (text) does not have
+  // to spare -- so the resident kernels always get the first kProbeRounds rounds.
+  const bool host_has_ccx = std::thread::hardware_concurrency() >= 8u && !getenv("BCE_DEC_TAIL_SERIAL") && tail_cpus().size() == 8;
   uint64_t mbox_rounds = 0, launches_wave = 0, launches_wg = 0, rounds_wg = 0, nodes_wave = 0, nodes_wg = 0, rounds_wave = 0;
   double t_wave = 0, t_wg = 0;
   BCE_TRY(ensure(c, c->runs, 64));
@@ -1448,6 +1498,18 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
       };
       for (;;) {
         uint32_t done[5] = {0, 0, 0, 0, 0};
+        if (host_tail_ok && query_heavy && !resume && !answered_pending && cur_nodes && cur_nodes <= DT_CAP &&
+            8ull * (n - 1u) - nodes_total >= (n >> 6) + (1u << 18) && 8ull * (n - 1u) - nodes_total <= 8ull * (n - 1u) / 8u) {
+          // the whole tail on the host (see above): nothing of this round has been asked or answered yet
+          bool bad = false;
+          const double th = now_s();
+          const uint32_t r0 = round;
+          BCE_TRY(dec_host_tail(c, a, ctl, hd.dec, n, &round, &nodes_total, &queries_total, &bad));
+          if (bad) { snprintf(c->err, sizeof c->err, "decode: inconsistent archive (round %u)", round); return BCE_HIP_E_INTERNAL; }
+          if (timing) fprintf(stderr, "gpu decode: %u rounds of the tail on the host, %.3f s with the copies\n", round - r0, now_s() - th);
+          cur_nodes = 0;
+          break;
+        }
         const bool wave = !force_wg && cur_nodes <= 64;
         at.par = round & 1u;
         const double t_launch = now_s();
@@ -1509,7 +1571,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
         answered_pending = stuck;
         if (probing) {
           probe_rounds += done[0];
-          if (probe_rounds >= kProbeRounds) { probe_done = true; query_heavy = (mbox_rounds - probe_mbox0) * 3u >= probe_rounds * 2u; /* two rounds in three ask the decoders something */ }
+          if (probe_rounds >= kProbeRounds) { probe_done = true; query_heavy = host_has_ccx || (mbox_rounds - probe_mbox0) * 3u >= probe_rounds * 2u; /* two rounds in three ask the decoders something */ }
         }
         if (host_tail_ok && done[1] == 0 && !stuck && cur_nodes &&
             ((wave && done[0] >= kHostTailAfter && cur_nodes <= 64) || (query_heavy && cur_nodes <= DT_CAP))) {
