@@ -678,19 +678,31 @@ static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes) {
   BCE_TRY(k3_begin(c));
   c->stats.t_coder = 0;
   ScanSet coders;                                          // planes 0-7 + the header coder, on a pool of host threads
-  std::vector<uint32_t> host;
+  // the records come over through pinned memory (a copy into a fresh std::vector ran at a fifth of the bus)
+  struct PinnedWords {
+    uint32_t *p = nullptr; size_t cap = 0;
+    ~PinnedWords() { if (p) (void)hipHostFree(p); }
+    int ensure(size_t words) {
+      if (words <= cap) return 0;
+      if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+      if (hipHostMalloc(reinterpret_cast<void **>(&p), words * 4, hipHostMallocDefault) != hipSuccess) { p = nullptr; return 1; }
+      cap = words;
+      return 0;
+    }
+  } host;
   double t_copy = 0, t_record = 0;
   auto consume = [&](uint64_t nsym) -> int {
     if (nsym) {
       const double tc0 = now_s();
-      host.resize((size_t)nsym * 5);
-      BCE_HIP_TRY(c, hipMemcpy(host.data(), c->scanrec.p, (size_t)nsym * 20, hipMemcpyDeviceToHost));
+      if (host.ensure((size_t)nsym > (size_t)c->sym_cap ? (size_t)nsym : (size_t)c->sym_cap)) return BCE_HIP_E_NOMEM;
+      BCE_HIP_TRY(c, hipMemcpyAsync(host.p, c->scanrec.p, (size_t)nsym * 4, hipMemcpyDeviceToHost, c->stream));
+      BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
       t_copy += now_s() - tc0;
       std::vector<ScanSpan> spans[8];
       for (int p = 0; p < 8; ++p)
         for (const RunEntry &e : c->run_log[p]) spans[p].push_back(ScanSpan{e.start, e.count});
       const double t0 = now_s();
-      coders.consume(host.data(), spans);
+      coders.consume(host.p, spans);
       c->stats.t_coder += now_s() - t0;
       t_record += now_s() - t0;
     }

@@ -220,6 +220,21 @@ BCE_HD void pack_symbol(const PlaneCfg &cfg, uint32_t plane, uint32_t sym, uint3
   key_word = sym | (k << 5) | (slot << 10) | (plane << 26);
   esc_word = esc | (nesc << 27);
 }
+// `bce -s`: what ScanCoder<31>::set (bce.cpp:737-744) keeps of a symbol, in ONE word (the kernels used to hand the host the
+// raw 20-byte tuple): the k > 31 escape loop with ScanCoder's OWN halving (k >> 1) + (~s & 1) (quirk Q2: not AdaptiveCoder's)
+// is run here -- it is integer arithmetic -- and so are the two 8-bit quotients of the map key, uint32 wrap included (:743).
+//   [4:0] sym  [9:5] k (2..31)  [17:10] (c1 << 8) / cs  [25:18] (c2 << 8) / cs  [30:26] escapes (each one log(2) of cost)
+BCE_HD uint32_t scan_pack(uint32_t sym, uint32_t k, uint32_t c1, uint32_t c2, uint32_t cs) {
+  uint32_t nesc = 0;
+  while (k > (uint32_t)kMaxK) {
+    ++nesc;
+    const uint32_t s0 = sym;
+    sym = s0 >> 1;
+    k = (k >> 1) + ((~s0) & 1u);
+  }
+  const uint32_t q1 = (uint32_t)(c1 << 8) / cs, q2 = (uint32_t)(c2 << 8) / cs;      // both < 256: c < cs, a wrap only shrinks the numerator
+  return sym | (k << 5) | (q1 << 10) | (q2 << 18) | (nesc << 26);
+}
 BCE_HD uint32_t key_sym(uint32_t k) { return k & 31u; }
 BCE_HD uint32_t key_k(uint32_t k) { return (k >> 5) & 31u; }
 BCE_HD uint32_t key_slot(uint32_t k) { return (k >> 10) & 0xFFFFu; }

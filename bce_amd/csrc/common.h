@@ -119,7 +119,7 @@ struct bce_hip_ctx {
   bce::DevBuf skey[2], sval[2], sout, sesc;       // K3->K4: symbol keys (skey[0]) + escape words (sesc); sort ping-pong; outputs
   bce::DevBuf skey_alt, sesc_alt, rs_hist_k4;     // the other pair of symbol buffers (see k4_stream); K4's radix histograms
   uint64_t sym_cap = 0;
-  bool scan_mode = false;                        // `bce -s`: K3 emits raw (sym,k,c1,c2,cs) tuples into scanrec
+  bool scan_mode = false;                        // `bce -s`: K3 emits scan_pack words (bce_core.h) into scanrec
   bce::DevBuf scanrec;
   bce::DevBuf stat, dcfg, k4w;                   // K4 counters, device copy of PlaneCfg[8], per-window work arrays
   uint32_t stat_off[8] = {0};

@@ -19,7 +19,7 @@ struct K3Args {
   const PlaneCfg *cfg;    // [8]
   uint32_t *symkey;       // symbol records: key words (K4 sort input)
   uint32_t *symesc;       // symbol records: escape words
-  uint32_t *scanrec;      // scan mode (`bce -s`): raw (sym, k, c1, c2, cs) per record instead of key/escape words
+  uint32_t *scanrec;      // scan mode (`bce -s`): one scan_pack word per record instead of key/escape words
   uint32_t *tilecnt;      // [tiles][4]
   uint32_t *tileoff;      // [tiles][4]
   RunEntry *runs;         // [K3_MAXBATCH][8]

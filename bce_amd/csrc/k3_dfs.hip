@@ -103,7 +103,7 @@ __device__ __forceinline__ void wsync() {
 
 struct DfsArgs {
   K3Args k;
-  uint32_t *traw;        // scan mode: 5 words per tagged symbol (raw_symbol), else null
+  uint32_t *traw;        // scan mode: scan_pack's word per tagged symbol (raw_symbol), else null
   const uint8_t *text;
   const uint8_t *bwt;    // K1's output: bwt[r] = the byte before row r (spine bursts)
   const uint32_t *sa, *isa;
@@ -267,9 +267,9 @@ __device__ __forceinline__ uint32_t chain_bytes(const DfsArgs &a, uint32_t s, ui
 // symbol's sort key) follows through j* pass-through levels.  So the events are independent of each other: one
 // lane each.  Everything is checked exactly (suffix-array stride, periodicity by comparing the text), nothing is
 // assumed about why the rows are there.  Whole wave, uniform arguments; returns false if the node is no staircase.
-// `bce -s` (scan mode): the coders want the raw tuple (sym, k, c1, c2, cs) of every symbol, not the model record
+// `bce -s` (scan mode): the ScanCoders want scan_pack's word of every symbol (bce_core.h), not the model record
 __device__ __forceinline__ void raw_symbol(const DfsArgs &a, uint32_t i, uint32_t sym, uint32_t kk, uint32_t c1, uint32_t c2, uint32_t cs) {
-  if (a.traw) { uint32_t *r = a.traw + (size_t)i * 5; r[0] = sym; r[1] = kk; r[2] = c1; r[3] = c2; r[4] = cs; }
+  if (a.traw) a.traw[i] = scan_pack(sym, kk, c1, c2, cs);
 }
 __device__ __forceinline__ uint32_t rank1_plane(const K3Args &k, uint32_t p, uint32_t pos) {
   const uint32_t g = div96(pos);
@@ -1452,11 +1452,7 @@ __global__ void kd_place_kernel(const uint32_t *__restrict__ tkey, const uint32_
 }
 
 __global__ void kd_place_raw_kernel(const uint32_t *__restrict__ traw, const uint32_t *__restrict__ perm, uint32_t m, uint32_t *__restrict__ rec) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-    const uint32_t *r = traw + (size_t)perm[i] * 5;
-    uint32_t *o = rec + (size_t)i * 5;
-    o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; o[4] = r[4];
-  }
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) rec[i] = traw[perm[i]];
 }
 
 // Host side.  The tail starts when the node count has stopped growing, at most `enter` nodes are alive and an
@@ -1504,7 +1500,7 @@ retry:
                o_stack = o_q + 2 * (size_t)qcap * sizeof(DNode), o_jobs = o_stack + (size_t)wmax * KD_STACK * sizeof(DNode),
                o_spill = o_jobs + (size_t)KD_JOBS * sizeof(StairJob);
   const size_t o_raw = o_spill + 2 * (size_t)scap * sizeof(DNode);
-  BCE_TRY(ensure(c, c->dfs, o_raw + (c->scan_mode ? (size_t)cap * 20 : 0)));
+  BCE_TRY(ensure(c, c->dfs, o_raw + (c->scan_mode ? (size_t)cap * 4 : 0)));
   uint8_t *base = c->dfs.as<uint8_t>();
   DfsArgs a;
   a.k = k3_make_args(c, c->round, 0);

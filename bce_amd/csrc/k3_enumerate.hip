@@ -166,8 +166,7 @@ __device__ __forceinline__ void k3_place(const K3Args &a, uint32_t p, const Tile
     if (t.has1[it]) dst[a.capP - 1u - (o1 + b1 + pre1[it])] = t.c1[it];
     if (t.hassym[it]) {
       if (SCAN) {
-        uint32_t *r = a.scanrec + (os + bs + pres[it]) * 5;
-        r[0] = t.kw[it]; r[1] = t.ew[it]; r[2] = t.raw[it][0]; r[3] = t.raw[it][1]; r[4] = t.raw[it][2];
+        a.scanrec[os + bs + pres[it]] = scan_pack(t.kw[it], t.ew[it], t.raw[it][0], t.raw[it][1], t.raw[it][2]);
       } else {
         a.symkey[os + bs + pres[it]] = t.kw[it];
         a.symesc[os + bs + pres[it]] = t.ew[it];
@@ -837,8 +836,7 @@ __global__ __launch_bounds__(KT_T) void k3_tail_kernel(K3Args a, RunEntry *truns
           if (so[it].hassym) {
             const uint64_t si = sym_total + ((run >> 32) & 0xFFFFu);
             if (SCAN) {
-              uint32_t *r = a.scanrec + si * 5;
-              r[0] = so[it].sym; r[1] = so[it].k; r[2] = so[it].ctx1; r[3] = so[it].ctx2; r[4] = so[it].ctxs;
+              a.scanrec[si] = scan_pack(so[it].sym, so[it].k, so[it].ctx1, so[it].ctx2, so[it].ctxs);
             } else {
               uint32_t kw, ew;
               pack_symbol(cfgs[p], p, so[it].sym, so[it].k, so[it].ctx1, so[it].ctx2, so[it].ctxs, kw, ew);
@@ -961,7 +959,7 @@ int k3_begin(bce_hip_ctx *c) {
     BCE_TRY(ensure(c, c->skey_alt, (size_t)cap * 4));
     BCE_TRY(ensure(c, c->sesc_alt, (size_t)cap * 4));
   }
-  if (c->scan_mode) BCE_TRY(ensure(c, c->scanrec, (size_t)cap * 20));
+  if (c->scan_mode) BCE_TRY(ensure(c, c->scanrec, (size_t)cap * 4));
   // roots: (0, C[i], n - C[i]) with C[i] = zeros(plane (i+7)%8), only where both are non-zero (bce.cpp:1237-1240)
   EnumCtl ctl;
   memset(&ctl, 0, sizeof ctl);
@@ -1116,7 +1114,7 @@ int k3_grow_symbols(bce_hip_ctx *c, uint64_t cap) {
     BCE_TRY(ensure(c, c->skey_alt, (size_t)cap * 4));
     BCE_TRY(ensure(c, c->sesc_alt, (size_t)cap * 4));
   }
-  if (c->scan_mode) BCE_TRY(ensure(c, c->scanrec, (size_t)cap * 20));
+  if (c->scan_mode) BCE_TRY(ensure(c, c->scanrec, (size_t)cap * 4));
   c->sym_cap = cap;
   EnumCtl *d = c->ctl.as<EnumCtl>();
   BCE_HIP_TRY(c, hipMemcpyAsync(&d->sym_cap, &c->sym_cap, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));

@@ -238,12 +238,15 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const uint32_t *
 // The key is two u32 arrays (lo, hi), the value a third; a digit is (hi:lo >> shift) & mask and may straddle the words.
 // Same three kernels per pass; the scatter moves three words per element through LDS.  ITEMS is smaller than the pair
 // sort's (chunk of 2048) so that four blocks still fit a CU.
-constexpr int RW_ITEMS = 8;
+#ifndef RW_ITEMS_VALUE
+#define RW_ITEMS_VALUE 8
+#endif
+constexpr int RW_ITEMS = RW_ITEMS_VALUE;
 constexpr int RW_CHUNK = RS_THREADS * RW_ITEMS;
 static RsPlan rw_plan(uint32_t n) {
   uint32_t chunks = (uint32_t)(((uint64_t)n + RW_CHUNK - 1) / RW_CHUNK);
   if (chunks == 0) chunks = 1;
-  const uint32_t maxb = 1024;                               // 4 per CU
+  const uint32_t maxb = RW_ITEMS <= 8 ? 1024 : 768;         // 4 (3) per CU
   uint32_t nb = chunks < maxb ? chunks : maxb;
   uint32_t cpb = (chunks + nb - 1) / nb;
   nb = (chunks + cpb - 1) / cpb;

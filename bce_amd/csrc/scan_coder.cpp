@@ -38,22 +38,18 @@ void ScanCoder::set(uint32_t s, uint32_t k, uint32_t c1, uint32_t c2, uint32_t c
   stat_[k][scan_key(c1, c2, cs)].push_back((uint8_t)s);
 }
 
-void ScanCoder::set_class(uint32_t s, uint32_t k, uint32_t c1, uint32_t c2, uint32_t cs, int cls) {
-  while (k > 31u) {
-    if (cls == 0) ++nesc_;
-    const uint32_t s0 = s;
-    s = s0 >> 1;
-    k = (k >> 1) + ((~s0) & 1u);
-  }
+void ScanCoder::set_packed(uint32_t word, int cls) {
+  const uint32_t k = (word >> 5) & 31u;
+  if (cls == 0) nesc_ += word >> 26;
   if (class_of(k) != cls) return;
   // the map decides the ORDER (of its iteration, later); finding a key's vector again goes through a flat table of the
-  // 2^16 possible keys (both quotients are < 256: c < cs, and the uint32 wrap only makes the numerator smaller)
-  const uint32_t key = scan_key(c1, c2, cs);
+  // 2^16 possible keys (both quotients are < 256)
+  const uint32_t q1 = (word >> 10) & 0xFFu, q2 = (word >> 18) & 0xFFu;
   std::vector<std::vector<uint8_t> *> &fast = fast_[k];
   if (fast.empty()) fast.assign(65536, nullptr);
-  std::vector<uint8_t> *&v = fast[((key >> 16) << 8 | (key & 0xFFu)) & 0xFFFFu];
-  if (!v) v = &stat_[k][key];                                // (references into an unordered_map survive rehashing)
-  v->push_back((uint8_t)s);
+  std::vector<uint8_t> *&v = fast[(q2 << 8) | q1];
+  if (!v) v = &stat_[k][(q2 << 16) | q1];                     // the reference's key: (c2 << 8) / cs << 16 | (c1 << 8) / cs  (:743)
+  v->push_back((uint8_t)(word & 31u));
 }
 
 uint64_t ScanCoder::symbols(uint32_t k) const {
@@ -146,10 +142,7 @@ void ScanSet::consume(const uint32_t *records, const std::vector<ScanSpan> spans
     const int p = (int)(t / ScanCoder::kClasses), cls = (int)(t % ScanCoder::kClasses);
     ScanCoder &c = coders_[p];
     for (const ScanSpan &e : spans[p])
-      for (uint64_t i = e.start; i < e.start + e.count; ++i) {
-        const uint32_t *r = records + (size_t)i * 5;
-        c.set_class(r[0], r[1], r[2], r[3], r[4], cls);
-      }
+      for (uint64_t i = e.start; i < e.start + e.count; ++i) c.set_packed(records[i], cls);
   });
 }
 

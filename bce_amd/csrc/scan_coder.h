@@ -30,9 +30,10 @@ class ScanCoder {
   // ---- the pieces ScanSet runs side by side ----
   static constexpr int kClasses = 7;                       // k = 2 | 3 | 4 | 5 | 6..7 | 8..15 | 16..31 (after the escape loop)
   static int class_of(uint32_t k) { return k <= 5 ? (int)k - 2 : k < 8 ? 4 : k < 16 ? 5 : 6; }
-  // set() for ONE class of k: the escape loop runs for every record (it decides the class), the record is kept only if
-  // its final k is of class `cls`; the thread of class 0 also counts the escapes (z_ += log(2) each, :739)
-  void set_class(uint32_t s, uint32_t k, uint32_t c1, uint32_t c2, uint32_t cs, int cls);
+  // set() for ONE class of k on a scan_pack word (bce_core.h: the escape loop and the map key were worked out by the kernel
+  // that emitted it): the record is kept only if its k is of class `cls`; the thread of class 0 also adds up the escapes
+  // (z_ += log(2) each, :739)
+  void set_packed(uint32_t word, int cls);
   double base_cost(uint32_t k) const;                      // z_min before any j (:757)
   double trial_cost(uint32_t k, uint32_t j) const;         // z of context bits j (:759-785)
   uint64_t symbols(uint32_t k) const;                      // records kept for k (task weights)
@@ -52,7 +53,7 @@ struct ScanSpan { uint64_t start, count; };                // records [start, st
 class ScanSet {
  public:
   explicit ScanSet(unsigned threads = 0);                  // 0 = the CPUs this process may run on, at most 64
-  // records = 5 x u32 (s, k, c1, c2, cs); spans[p] = plane p's runs of this buffer in stream order
+  // records = one scan_pack word each; spans[p] = plane p's runs of this buffer in stream order
   void consume(const uint32_t *records, const std::vector<ScanSpan> spans[8]);
   void flush(uint8_t init[9][32], double result_bytes[9]);
   unsigned threads() const { return threads_; }

@@ -172,13 +172,13 @@ extern "C" int emul_scan(const uint32_t *syms6, size_t nsym, unsigned threads, u
     if (chunks == 0) chunks = 1;
     for (unsigned ch = 0; ch < chunks; ++ch) {
       const size_t lo = nsym * ch / chunks, hi = nsym * (ch + 1) / chunks;
-      std::vector<uint32_t> rec((hi - lo) * 5);
+      std::vector<uint32_t> rec(hi - lo);
       std::vector<ScanSpan> spans[8];
       // lay the chunk out plane by plane (any layout will do: the spans say where a plane's records are, in stream order)
       size_t w = 0;
       for (int p = 0; p < 8; ++p) {
         const size_t w0 = w;
-        for (size_t t = lo; t < hi; ++t) { const uint32_t *r = syms6 + 6 * t; if ((int)r[0] == p) { memcpy(&rec[w * 5], r + 1, 20); ++w; } }
+        for (size_t t = lo; t < hi; ++t) { const uint32_t *r = syms6 + 6 * t; if ((int)r[0] == p) { rec[w] = scan_pack(r[1], r[2], r[3], r[4], r[5]); ++w; } }
         if (w > w0) { const size_t mid = w0 + (w - w0) / 2; spans[p].push_back(ScanSpan{w0, mid - w0}); spans[p].push_back(ScanSpan{mid, w - mid}); }
       }
       const double t0 = emul_now();
