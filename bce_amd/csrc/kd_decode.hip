@@ -1467,6 +1467,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   // ... every LONG tail, that is: the copy and the threads cost ~0.1 s, which a tail of a few hundred rounds (text) does not have
   // to spare -- so the resident kernels always get the first kProbeRounds rounds.
   const bool host_has_ccx = std::thread::hardware_concurrency() >= 8u && !getenv("BCE_DEC_TAIL_SERIAL") && tail_cpus().size() == 8;
+  uint64_t wide_hist[32] = {0}, wide_nodes[32] = {0};
   uint64_t mbox_rounds = 0, launches_wave = 0, launches_wg = 0, rounds_wg = 0, nodes_wave = 0, nodes_wg = 0, rounds_wave = 0;
   double t_wave = 0, t_wg = 0;
   BCE_TRY(ensure(c, c->runs, 64));
@@ -1602,6 +1603,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
     a.res = Rsbuf.as<uint32_t>();
     uint64_t want = (cur_nodes + K3_TILE - 1) / K3_TILE + 8;
     const uint32_t grid = (uint32_t)(want < 2048 ? want : 2048);
+    if (timing) { uint32_t b = 0; while ((2ull << b) <= cur_nodes && b < 31) ++b; wide_hist[b]++; wide_nodes[b] += cur_nodes; }
     hipLaunchKernelGGL((dec_tiles_kernel<0>), dim3(grid), dim3(K3_T), 0, c->stream, a);
     hipLaunchKernelGGL((dec_scan_kernel<true>), dim3(8), dim3(1024), 0, c->stream, a);
     hipLaunchKernelGGL((dec_tiles_kernel<1>), dim3(grid), dim3(K3_T), 0, c->stream, a);
@@ -1652,6 +1654,11 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   if (timing) { fprintf(stderr, "gpu decode: %u rounds (%llu of them in the tail kernels, %llu query rounds answered through the mailbox), %llu nodes, %llu queries: %.3f s (query pass %.3f, copy out %.3f, host decoders %.3f, children pass %.3f)\n",
                         round, (unsigned long long)tail_rounds, (unsigned long long)mbox_rounds, (unsigned long long)nodes_total, (unsigned long long)queries_total, now_s() - tp0, t_q, t_copy, t_host, t_c); tp0 = now_s(); }
 
+  if (timing) {
+    fprintf(stderr, "gpu decode: six-launch rounds by node count:");
+    for (int b = 0; b < 32; ++b) if (wide_hist[b]) fprintf(stderr, " [2^%d) %llu rounds %.1f M nodes;", b, (unsigned long long)wide_hist[b], wide_nodes[b] * 1e-6);
+    fprintf(stderr, "\n");
+  }
   if (timing) fprintf(stderr, "gpu decode: tail kernels: wave %llu launches (%llu rounds, %llu nodes) %.3f s, workgroup %llu launches (%llu rounds, %llu nodes) %.3f s\n",
                       (unsigned long long)launches_wave, (unsigned long long)rounds_wave, (unsigned long long)nodes_wave, t_wave,
                       (unsigned long long)launches_wg, (unsigned long long)rounds_wg, (unsigned long long)nodes_wg, t_wg);
