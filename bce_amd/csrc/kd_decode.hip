@@ -77,6 +77,8 @@ struct DecArgs {
   //   [2] device -> host: set to 1 when the kernel has left
   uint32_t *mbox;
   uint32_t seq_base;         // number of the first query round of this launch (numbers never repeat within a decode)
+  unsigned long long *words; // dec_small_kernel: one tagged count word per tile
+  uint32_t round;            // ... and the round number the tags are made of
 };
 
 __device__ __forceinline__ Node *dec_nodes(const DecArgs &a, uint32_t par, uint32_t p) {
@@ -337,6 +339,190 @@ __global__ __launch_bounds__(1024) void dec_scan_kernel(DecArgs a) {
       ctl->cnt[a.par ^ 1u][qn][1] = pt[q][1];
       nextn += (uint64_t)pt[q][0] + pt[q][1];
       if ((uint64_t)pt[q][0] + pt[q][1] > a.capP) ovf = true;
+    }
+    if (ovf && !ctl->err) ctl->err = 2;
+    ctl->nodes_total += curn;
+    ctl->next_nodes = (uint32_t)nextn;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Rounds of up to ~2 M nodes in TWO launches instead of six (round 3).  Between the first wide rounds and the tail lie
+// thousands of rounds of 2 K .. 1 M nodes (natural corpus: 4 900, binary corpus: 4 100) in which count / scan / write
+// kernels of ~10 us each, three times per round, are pure launch overhead.  Here a pass is ONE kernel, as in
+// k3_small_kernel: block = tile, classified once; the tile's counts go out in a 64-bit word tagged with the pass number
+// (nothing to reset), the block waits for the words of the earlier tiles (all of them for the query offsets, those of
+// its plane for the children), sums them and writes; the block of the last tile folds the words into the control block
+// and the host's DecInfo.  A waiter only waits for smaller block indices (in-order dispatch, as k3_small_kernel); the
+// wait is bounded and ends in err = 4 instead of a hang.
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t DS_MAXTILES = 2048;
+constexpr uint32_t DS_MAXNODES = (DS_MAXTILES - 8u) * K3_TILE;
+__device__ __forceinline__ uint64_t ds_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t ds_wait(const unsigned long long *p, uint64_t epoch, uint64_t w, DecCtl *ctl) {
+  uint32_t spins = 0;
+  while ((w >> 33) != epoch) {
+    __builtin_amdgcn_s_sleep(1);
+    w = ds_ld(p);
+    if (++spins == (1u << 22)) { ctl->err = 4; return epoch << 33; }
+  }
+  return w;
+}
+template <bool QUERY>
+__global__ __launch_bounds__(K3_T) void dec_small_kernel(DecArgs a) {
+  __shared__ uint32_t tp[9];
+  __shared__ uint32_t lds_cnt[K3_NPT][4][3];
+  __shared__ unsigned long long s_acc[2];
+  __shared__ unsigned long long s_tot[8];
+  DecCtl *ctl = a.ctl;
+  if (ctl->err) return;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) dec_tile_prefix(a, tp);
+  if (tid < 2) s_acc[tid] = 0;
+  if (tid < 8) s_tot[tid] = 0;
+  __syncthreads();
+  const uint32_t T = tp[8], tile = blockIdx.x;
+  if (tile >= T) return;
+  const uint64_t epoch = ((uint64_t)a.round * 2u + (QUERY ? 1u : 2u)) & 0x7FFFFFFFull;
+  uint32_t p = 0;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) p += (tile >= tp[k]) ? 1u : 0u;
+  const uint32_t ti = tile - tp[p];
+  const uint32_t c0n = ctl->cnt[a.par][p][0], M = c0n + ctl->cnt[a.par][p][1];
+  const Node *src = dec_nodes(a, a.par, p);
+  uint32_t *R = a.R + (size_t)p * ((size_t)a.n + 1);
+  const uint32_t zi = a.zeros[p];
+  Node nd[K3_NPT];
+  DCls cl[K3_NPT];
+  uint32_t valid[K3_NPT], isq[K3_NPT], ise[K3_NPT], zero[K3_NPT];
+  uint32_t bad = 0;
+#pragma unroll
+  for (int it = 0; it < K3_NPT; ++it) {
+    const uint32_t q = ti * K3_TILE + (uint32_t)it * K3_T + tid;
+    valid[it] = q < M ? 1u : 0u;
+    const uint32_t qq = valid[it] ? q : ti * K3_TILE;
+    nd[it] = src[qq < c0n ? qq : (a.capP - 1u - (qq - c0n))];
+  }
+#pragma unroll
+  for (int it = 0; it < K3_NPT; ++it) {
+    cl[it] = dec_classify(nd[it], R, a.n);
+    bad |= cl[it].bad & valid[it];
+    isq[it] = (valid[it] && cl[it].kind == 3u) ? 1u : 0u;
+    ise[it] = (isq[it] && cl[it].mx - cl[it].mn + 1u > (uint32_t)kMaxK) ? 1u : 0u;
+    zero[it] = 0;
+  }
+  uint32_t qr[K3_NPT], er[K3_NPT], d2[K3_NPT], tot[3];
+  tile_ranks(isq, ise, zero, lds_cnt, qr, er, d2, tot);
+  uint32_t has0[K3_NPT], has1[K3_NPT], rval[K3_NPT], r0[K3_NPT], r1[K3_NPT];
+  Node c0[K3_NPT], c1[K3_NPT];
+  uint32_t qb = 0;
+  if (!QUERY) {
+    qb = a.tileoff[(size_t)tile * 4 + 2];                      // (left there by the query pass of this round)
+#pragma unroll
+    for (int it = 0; it < K3_NPT; ++it) {
+      uint32_t v = cl[it].mn;
+      if (isq[it]) v += a.res[qb + qr[it]];
+      if (valid[it] && cl[it].kind >= 2u && v > cl[it].mx) { bad = 1; v = cl[it].mn; }
+      rval[it] = dec_children(nd[it], cl[it], v, zi, has0[it], c0[it], has1[it], c1[it]);
+      has0[it] &= valid[it];
+      has1[it] &= valid[it];
+    }
+    tile_ranks(has0, has1, zero, lds_cnt, r0, r1, d2, tot);
+  }
+  if (bad) { ctl->err = 1; __threadfence(); }
+  // [10:0] first count, [21:11] second (queries / escapes, or child0 / child1: <= 1024 each), [63:33] pass tag
+  if (tid == 0)
+    __hip_atomic_store(&a.words[tile], (epoch << 33) | ((uint64_t)tot[1] << 11) | (uint64_t)tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // look back: the query pass needs every earlier tile (the query buffer runs through the planes), the children pass
+  // the earlier tiles of its own plane
+  {
+    constexpr int LB = (int)(DS_MAXTILES / K3_T);
+    const uint32_t first = QUERY ? 0u : tp[p];
+    uint64_t wv[LB], s0 = 0, s1 = 0;
+#pragma unroll
+    for (int q = 0; q < LB; ++q) { const uint32_t j = tid + (uint32_t)q * K3_T; wv[q] = (j >= first && j < tile) ? ds_ld(&a.words[j]) : 0ull; }
+#pragma unroll
+    for (int q = 0; q < LB; ++q) {
+      const uint32_t j = tid + (uint32_t)q * K3_T;
+      if (j >= first && j < tile) {
+        wv[q] = ds_wait(&a.words[j], epoch, wv[q], ctl);
+        s0 += wv[q] & 0x7FFu; s1 += (wv[q] >> 11) & 0x7FFu;
+      }
+    }
+    if (s0) atomicAdd(&s_acc[0], (unsigned long long)s0);
+    if (s1) atomicAdd(&s_acc[1], (unsigned long long)s1);
+  }
+  __syncthreads();
+  const uint32_t o0 = (uint32_t)s_acc[0], o1 = (uint32_t)s_acc[1];
+  if (QUERY) {
+    if (tid == 0) a.tileoff[(size_t)tile * 4 + 2] = o0;
+#pragma unroll
+    for (int it = 0; it < K3_NPT; ++it)
+      if (isq[it]) {
+        const uint32_t x = nd[it].x0 + nd[it].x1, k = cl[it].mx - cl[it].mn + 1u, cc1 = x - cl[it].n1x, cc2 = nd[it].x1;
+        if (k <= (uint32_t)kMaxK) {
+          const uint32_t b = a.cfg[p].bits[k];
+          a.Q[o0 + qr[it]] = k | (context_index(b, cc1, cc2, x) << 5);
+        } else {
+          a.Q[o0 + qr[it]] = kEscape;
+          a.E[o1 + er[it]] = make_uint4(k, cc1, cc2, x);
+        }
+      }
+  } else {
+    Node *dst = dec_nodes(a, a.par ^ 1u, (p + 1u) & 7u);
+#pragma unroll
+    for (int it = 0; it < K3_NPT; ++it) {
+      if (has0[it]) dst[o0 + r0[it]] = c0[it];
+      if (has1[it]) dst[a.capP - 1u - (o1 + r1[it])] = c1[it];
+      if (valid[it] && !cl[it].bad) R[nd[it].s + nd[it].x0] = rval[it];
+    }
+  }
+  // ---- the block of the last tile folds the pass into the control block (and the host's DecInfo) ----
+  if (tile != T - 1u) return;
+  {
+    constexpr int LB = (int)(DS_MAXTILES / K3_T);
+    uint64_t wv[LB];
+#pragma unroll
+    for (int q = 0; q < LB; ++q) { const uint32_t j = tid + (uint32_t)q * K3_T; wv[q] = j < T ? ds_ld(&a.words[j]) : 0ull; }
+#pragma unroll
+    for (int q = 0; q < LB; ++q) {
+      const uint32_t j = tid + (uint32_t)q * K3_T;
+      if (j < T) {
+        uint32_t pj = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) pj += (j >= tp[k]) ? 1u : 0u;
+        wv[q] = ds_wait(&a.words[j], epoch, wv[q], ctl);
+        atomicAdd(&s_tot[pj], (unsigned long long)((wv[q] & 0x7FFu) | (((wv[q] >> 11) & 0x7FFu) << 32)));
+      }
+    }
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  uint64_t curn = 0;
+  for (int q = 0; q < 8; ++q) curn += (uint64_t)ctl->cnt[a.par][q][0] + ctl->cnt[a.par][q][1];
+  if (QUERY) {
+    uint32_t acc = 0, eacc = 0;
+    for (int q = 0; q < 8; ++q) {
+      const uint32_t tq = (uint32_t)s_tot[q], te = (uint32_t)(s_tot[q] >> 32);
+      ctl->qbase[q] = acc; ctl->ebase[q] = eacc;
+      a.info->qbase[q] = acc; a.info->qtot[q] = tq;
+      a.info->ebase[q] = eacc; a.info->etot[q] = te;
+      acc += tq; eacc += te;
+    }
+    a.info->cur_nodes = (uint32_t)curn;
+    a.info->nodes_total = ctl->nodes_total;
+    __threadfence_system();
+    a.info->err = ctl->err;
+  } else {
+    uint64_t nextn = 0;
+    bool ovf = false;
+    for (uint32_t q = 0; q < 8; ++q) {
+      const uint32_t qn = (q + 1u) & 7u, t0 = (uint32_t)s_tot[q], t1 = (uint32_t)(s_tot[q] >> 32);
+      ctl->cnt[a.par ^ 1u][qn][0] = t0;
+      ctl->cnt[a.par ^ 1u][qn][1] = t1;
+      nextn += (uint64_t)t0 + t1;
+      if ((uint64_t)t0 + t1 > a.capP) ovf = true;
     }
     if (ovf && !ctl->err) ctl->err = 2;
     ctl->nodes_total += curn;
@@ -1467,7 +1653,12 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   // ... every LONG tail, that is: the copy and the threads cost ~0.1 s, which a tail of a few hundred rounds (text) does not have
   // to spare -- so the resident kernels always get the first kProbeRounds rounds.
   const bool host_has_ccx = std::thread::hardware_concurrency() >= 8u && !getenv("BCE_DEC_TAIL_SERIAL") && tail_cpus().size() == 8;
-  uint64_t wide_hist[32] = {0}, wide_nodes[32] = {0};
+  uint64_t wide_hist[32] = {0}, wide_nodes[32] = {0}, small_rounds = 0;
+  constexpr uint64_t kDirectNodes = 1u << 18;
+  const bool no_small = getenv("BCE_DEC_NO_SMALL") != nullptr;
+  BCE_TRY(ensure(c, c->smwords, (size_t)DS_MAXTILES * 8));
+  BCE_HIP_TRY(c, hipMemsetAsync(c->smwords.p, 0, (size_t)DS_MAXTILES * 8, c->stream));      // pass tags of an earlier decode
+  a.words = c->smwords.as<unsigned long long>();
   uint64_t mbox_rounds = 0, launches_wave = 0, launches_wg = 0, rounds_wg = 0, nodes_wave = 0, nodes_wg = 0, rounds_wave = 0;
   double t_wave = 0, t_wg = 0;
   BCE_TRY(ensure(c, c->runs, 64));
@@ -1595,18 +1786,38 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
       if (c->progress) c->progress(nodes_total, 8ull * n, c->progress_user);
       if (!cur_nodes) break;
     }
-    BCE_TRY(ensure(c, Qbuf, (size_t)(cur_nodes + 16) * 4));
-    BCE_TRY(ensure(c, Ebuf, (size_t)(cur_nodes + 16) * sizeof(uint4)));
-    BCE_TRY(ensure(c, Rsbuf, (size_t)(cur_nodes + 16) * 4));
-    a.Q = Qbuf.as<uint32_t>();
-    a.E = Ebuf.as<uint4>();
-    a.res = Rsbuf.as<uint32_t>();
+    // Rounds of up to kDirectNodes nodes exchange their queries and answers through pinned host memory (as the tail kernels do):
+    // the kernels write / read it over the bus, and the round is two launches and two syncs with no copy in between.
+    const bool small_round = cur_nodes <= DS_MAXNODES && !no_small;
+    const bool direct = small_round && cur_nodes <= kDirectNodes && !answered_pending;
+    if (direct) {
+      BCE_TRY(pin_q.ensure(c, (size_t)(cur_nodes + 16) * 4));
+      BCE_TRY(pin_e.ensure(c, (size_t)(cur_nodes + 16) * sizeof(uint4)));
+      BCE_TRY(pin_res.ensure(c, (size_t)(cur_nodes + 16) * 4));
+      a.Q = static_cast<uint32_t *>(pin_q.p);
+      a.E = static_cast<uint4 *>(pin_e.p);
+      a.res = static_cast<const uint32_t *>(pin_res.p);
+    } else {
+      BCE_TRY(ensure(c, Qbuf, (size_t)(cur_nodes + 16) * 4));
+      BCE_TRY(ensure(c, Ebuf, (size_t)(cur_nodes + 16) * sizeof(uint4)));
+      BCE_TRY(ensure(c, Rsbuf, (size_t)(cur_nodes + 16) * 4));
+      a.Q = Qbuf.as<uint32_t>();
+      a.E = Ebuf.as<uint4>();
+      a.res = Rsbuf.as<uint32_t>();
+    }
     uint64_t want = (cur_nodes + K3_TILE - 1) / K3_TILE + 8;
     const uint32_t grid = (uint32_t)(want < 2048 ? want : 2048);
     if (timing) { uint32_t b = 0; while ((2ull << b) <= cur_nodes && b < 31) ++b; wide_hist[b]++; wide_nodes[b] += cur_nodes; }
-    hipLaunchKernelGGL((dec_tiles_kernel<0>), dim3(grid), dim3(K3_T), 0, c->stream, a);
-    hipLaunchKernelGGL((dec_scan_kernel<true>), dim3(8), dim3(1024), 0, c->stream, a);
-    hipLaunchKernelGGL((dec_tiles_kernel<1>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+    const bool small = small_round;                                // one launch per pass (dec_small_kernel)
+    a.round = round;
+    if (small) {
+      hipLaunchKernelGGL((dec_small_kernel<true>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+      ++small_rounds;
+    } else {
+      hipLaunchKernelGGL((dec_tiles_kernel<0>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+      hipLaunchKernelGGL((dec_scan_kernel<true>), dim3(8), dim3(1024), 0, c->stream, a);
+      hipLaunchKernelGGL((dec_tiles_kernel<1>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+    }
     BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
     BCE_HIP_TRY(c, hipGetLastError());
     const DecInfo in = *info;
@@ -1617,6 +1828,12 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
     if (qtotal && answered_pending) {
       // the tail kernel emitted exactly these queries (same order) and the decoders answered them: do not ask twice
       BCE_HIP_TRY(c, hipMemcpyAsync(Rsbuf.p, pin_res.p, qtotal * 4, hipMemcpyHostToDevice, c->stream));
+    } else if (qtotal && direct) {
+      pool.Q = static_cast<const uint32_t *>(pin_q.p);
+      pool.E = static_cast<const uint4 *>(pin_e.p);
+      pool.res = static_cast<uint32_t *>(pin_res.p);
+      pool.run(in);
+      { const double t1 = now_s(); t_host += t1 - t0; t0 = t1; }
     } else if (qtotal) {
       BCE_TRY(pin_q.ensure(c, qtotal * 4));
       BCE_TRY(pin_e.ensure(c, (etotal + 1) * sizeof(uint4)));
@@ -1633,15 +1850,20 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
       BCE_HIP_TRY(c, hipMemcpyAsync(Rsbuf.p, pin_res.p, qtotal * 4, hipMemcpyHostToDevice, c->stream));
     }
     answered_pending = false;
-    hipLaunchKernelGGL((dec_tiles_kernel<2>), dim3(grid), dim3(K3_T), 0, c->stream, a);
-    hipLaunchKernelGGL((dec_scan_kernel<false>), dim3(8), dim3(1024), 0, c->stream, a);
-    hipLaunchKernelGGL((dec_tiles_kernel<3>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+    if (small) {
+      hipLaunchKernelGGL((dec_small_kernel<false>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+    } else {
+      hipLaunchKernelGGL((dec_tiles_kernel<2>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+      hipLaunchKernelGGL((dec_scan_kernel<false>), dim3(8), dim3(1024), 0, c->stream, a);
+      hipLaunchKernelGGL((dec_tiles_kernel<3>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+    }
     // the next round's size: read the control block (the query pass of the next round would tell, but its grid needs it)
     BCE_TRY(read_back(c, &ctl, c->ctl.p, sizeof ctl));
     BCE_HIP_TRY(c, hipGetLastError());
     if (ctl.err) {
-      snprintf(c->err, sizeof c->err, ctl.err == 2 ? "decode: node list overflow (capP=%u)" : "decode: inconsistent archive (round %u)",
-               ctl.err == 2 ? c->capP : round);
+      if (ctl.err == 4) snprintf(c->err, sizeof c->err, "decode: a two-launch round waited too long for a predecessor tile (round %u)", round);
+      else snprintf(c->err, sizeof c->err, ctl.err == 2 ? "decode: node list overflow (capP=%u)" : "decode: inconsistent archive (round %u)",
+                    ctl.err == 2 ? c->capP : round);
       return ctl.err == 2 ? BCE_HIP_E_OVERFLOW : BCE_HIP_E_INTERNAL;
     }
     t_c += now_s() - t0;
@@ -1655,7 +1877,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
                         round, (unsigned long long)tail_rounds, (unsigned long long)mbox_rounds, (unsigned long long)nodes_total, (unsigned long long)queries_total, now_s() - tp0, t_q, t_copy, t_host, t_c); tp0 = now_s(); }
 
   if (timing) {
-    fprintf(stderr, "gpu decode: six-launch rounds by node count:");
+    fprintf(stderr, "gpu decode: %llu rounds in two launches (dec_small_kernel); rounds outside the tail by node count:", (unsigned long long)small_rounds);
     for (int b = 0; b < 32; ++b) if (wide_hist[b]) fprintf(stderr, " [2^%d) %llu rounds %.1f M nodes;", b, (unsigned long long)wide_hist[b], wide_nodes[b] * 1e-6);
     fprintf(stderr, "\n");
   }
