@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise tools/profile.sh output: per-kernel FETCH_SIZE / WRITE_SIZE sums (one compression) and K3's HBM
-traffic with the gfx950 read correction of MI355X_MICROARCH.md.   python tools/pmc_summary.py OUTDIR TAG"""
+traffic with the gfx950 read correction of MI355X_MICROARCH.md.   python tools/pmc_summary.py OUTDIR TAG [SUFFIX]"""
 import csv
 import glob
 import json
@@ -30,10 +30,11 @@ def sums(outdir, sub, counter):
 
 def main():
     outdir, tag = sys.argv[1], sys.argv[2]
-    fetch, calls = sums(outdir, "fetch", "FETCH_SIZE")
-    write, _ = sums(outdir, "write", "WRITE_SIZE")
+    sfx = sys.argv[3] if len(sys.argv) > 3 else ""          # e.g. "_1e9": passes in fetch_1e9/ write_1e9/, log fetch_1e9.log
+    fetch, calls = sums(outdir, "fetch" + sfx, "FETCH_SIZE")
+    write, _ = sums(outdir, "write" + sfx, "WRITE_SIZE")
     rows = sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) + write.get(k, 0)))
-    with open(os.path.join(outdir, "%s_pmc_fetch_write.csv" % tag), "w") as f:
+    with open(os.path.join(outdir, "%s_pmc_fetch_write%s.csv" % (tag, sfx)), "w") as f:
         f.write("kernel,dispatches,FETCH_SIZE_KB_sum,WRITE_SIZE_KB_sum\n")
         for k in rows:
             f.write("%s,%d,%.1f,%.1f\n" % (k, calls.get(k, 0), fetch.get(k, 0.0), write.get(k, 0.0)))
@@ -42,7 +43,7 @@ def main():
     wr = sum(write.get(k, 0.0) for k in k3) * 1024.0
     line = {}
     try:
-        with open(os.path.join(outdir, "fetch.log")) as f:
+        with open(os.path.join(outdir, "fetch%s.log" % sfx)) as f:
             line = json.loads([l for l in f if l.startswith("{")][-1])
     except Exception:
         pass
@@ -61,7 +62,7 @@ def main():
         "collected": "tools/profile.sh: rocprofv3 --pmc FETCH_SIZE --kernel-trace / --pmc WRITE_SIZE --kernel-trace, separate "
                      "passes, bench.py --steps 1 --warmup 0 --no-cpu --no-decode --no-workloads",
     }
-    with open(os.path.join(outdir, "%s_k3_traffic.json" % tag), "w") as f:
+    with open(os.path.join(outdir, "%s_k3_traffic%s.json" % (tag, sfx)), "w") as f:
         json.dump(tj, f, indent=1)
     print(json.dumps({k: tj[k] for k in ("traffic_bytes_raw", "traffic_bytes_corrected", "algorithmic_bytes")}))
 

@@ -29,6 +29,9 @@ run synthtext_1e8
 run natural_1e8 --file /tmp/bce_natural_100000000.bin
 run binary_1e8 --file /tmp/bce_binary_100000000.bin
 run synthrand_32Mi --workload synth-rand --size 33554432
+# BASELINE configs[2] (enwik9-sized): 2 compressions of 10^9 bytes (--steps 1 --warmup 1 replaces $B's counts)
+B="--steps 1 --warmup 1 --no-cpu --no-decode --no-workloads --no-e2e --no-stream"
+run synthtext_1e9 --size 1000000000
 P="--steps 1 --warmup 0 --no-cpu --no-decode --no-workloads --no-e2e --no-stream"   # ONE compression
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o run -- \
   python3 "$ROOT/bench.py" $P > "$OUT/fetch.log" 2>&1
@@ -36,3 +39,10 @@ timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
   python3 "$ROOT/bench.py" $P > "$OUT/write.log" 2>&1
 python3 "$ROOT/tools/pmc_summary.py" "$OUT" "$TAG"
 rm -rf "$OUT/fetch" "$OUT/write"
+# the same two passes at 10^9 bytes (config 3 asks for the HBM figure at that size)
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch_1e9" -o run -- \
+  python3 "$ROOT/bench.py" $P --size 1000000000 > "$OUT/fetch_1e9.log" 2>&1
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write_1e9" -o run -- \
+  python3 "$ROOT/bench.py" $P --size 1000000000 > "$OUT/write_1e9.log" 2>&1
+python3 "$ROOT/tools/pmc_summary.py" "$OUT" "$TAG" _1e9
+rm -rf "$OUT/fetch_1e9" "$OUT/write_1e9"
