@@ -94,3 +94,66 @@ def test_cli_container_with_hostile_size_table(tmp_path):
         r = subprocess.run([exe, "-ds", str(out), str(bad)], capture_output=True, text=True)
         assert r.returncode == 254 and "Could not read Archive." in r.stdout, (t, r.returncode, r.stdout, r.stderr)
         assert not out.exists()
+
+
+@pytest.fixture(scope="module")
+def asan_cli():
+    """The CLI + host decoder + host coder as a CPU-only binary under AddressSanitizer and UBSan (the GPU entry points are
+    "no device" stubs, tests/asan_stubs.cpp): what `bce -ds` does with untrusted bytes, with every heap access checked."""
+    out = os.path.join(ROOT, "tests", "_build", "bce_asan")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    src = [os.path.join(ROOT, "bce_amd", "csrc", f) for f in ("main.cpp", "decoder.cpp", "host_coder.cpp")] + [os.path.join(ROOT, "tests", "asan_stubs.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-o", out] + src + ["-lpthread"])
+    return out
+
+
+def test_sanitized_ds_on_hostile_containers_and_corrupt_archives(asan_cli, tmp_path):
+    """Wrapping / oversized / lying container tables (a table of 2^64 - 100 and 200 bytes made the old code write a
+    block into a 100-byte buffer) and bit-flipped or truncated archives through `bce -ds` under ASan + UBSan: a clean exit
+    code every time, the right bytes when the archive is intact, no sanitizer report."""
+    import struct
+    from bce_amd import container
+    env = dict(os.environ, ASAN_OPTIONS="abort_on_error=0:detect_leaks=0:exitcode=99", UBSAN_OPTIONS="halt_on_error=1:exitcode=98")
+    parts = [oracle.synth_text(31, 4000), oracle.synth_text(32, 300), b"a" * 50]
+    archives = [oracle.compress(p) for p in parts]
+    out = tmp_path / "o"
+
+    def run(path):
+        out.unlink(missing_ok=True)
+        r = subprocess.run([asan_cli, "-ds", str(out), str(path)], capture_output=True, text=True, env=env)
+        assert r.returncode not in (98, 99) and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+        return r
+
+    good = tmp_path / "good.bcem"
+    good.write_bytes(container.pack_blocks(archives, [len(p) for p in parts]))
+    r = run(good)
+    assert r.returncode == 0 and out.read_bytes() == b"".join(parts)
+    sizes = [len(p) for p in parts]
+    for t in ([2**64 - 100, 200, 50], [4000, 2**64 - 4000, 50], [2**31, 300, 50], [2**40, 300, 50], [0, 300, 50], [4001, 300, 50],
+              [4000, 300, 2**63]):
+        bad = tmp_path / "bad.bcem"
+        bad.write_bytes(container.pack_blocks(archives, t))
+        r = run(bad)
+        assert r.returncode == 254 and "Could not read Archive." in r.stdout and not out.exists(), (t, r.returncode, r.stdout)
+    # a table whose ARCHIVE sizes lie (beyond the file, wrapping)
+    blob = bytearray(container.pack_blocks(archives, sizes))
+    for alen in (2**64 - 1, len(blob), 2**40):
+        b2 = bytearray(blob)
+        b2[12 + 8:12 + 16] = struct.pack("<Q", alen)
+        bad = tmp_path / "bad2.bcem"
+        bad.write_bytes(bytes(b2))
+        r = run(bad)
+        assert r.returncode != 0 and not out.exists()
+    # single archives: truncated and bit-flipped -- any exit code, never a sanitizer report
+    rs = np.random.RandomState(5)
+    single = archives[0]
+    arc = tmp_path / "a.bce"
+    arc.write_bytes(single)
+    r = run(arc)
+    assert r.returncode == 0 and out.read_bytes() == parts[0]
+    for _ in range(40):
+        b = bytearray(single)
+        for _k in range(int(rs.randint(1, 4))):
+            b[rs.randint(len(b))] ^= 1 << rs.randint(8)
+        arc.write_bytes(bytes(b[: len(b) - 2 * int(rs.randint(0, 5))]))
+        run(arc)
