@@ -115,3 +115,20 @@ def test_cli_many_blocks_on_few_gpus(tmp_path):
         bad.write_bytes(bytes(blob))
         r = subprocess.run([EXE, "-d", str(out), str(bad)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 254 and "Could not read Archive." in r.stdout, (raw0, r.stdout, r.stderr)
+
+
+def test_two_bce_processes_on_one_gpu_take_turns(tmp_path):
+    """Two `bce -c` PROCESSES on the same device at the same time: their enumerations are kept apart by the advisory file lock
+    behind the device gate (api.hip gate_file: /dev/shm/bce_hip_gate_<PCI address>), everything else overlaps.  Both archives
+    must be the oracle's; nothing may hang (the single-launch rounds of two ungated processes could starve each other)."""
+    datas = [oracle.synth_text(61, 6_000_000), oracle.synth_text(62, 5_000_000), oracle.synth_rand(63, 1_500_000)]
+    procs = []
+    for i, d in enumerate(datas):
+        (tmp_path / ("in%d" % i)).write_bytes(d)
+        procs.append(subprocess.Popen([EXE, "-c", str(tmp_path / ("a%d.bce" % i)), str(tmp_path / ("in%d" % i))], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, out + err
+    for i, d in enumerate(datas):
+        assert (tmp_path / ("a%d.bce" % i)).read_bytes() == oracle.compress(d)
