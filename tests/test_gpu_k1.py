@@ -1,0 +1,97 @@
+"""GPU: K1 (rotation sort + BWT, k1_bwt.hip) on inputs aimed at its round-3 machinery: the compacted alphabet and the
+64-bit first key, groups around the 2048-element limit of the in-LDS sort (2047 / 2048 / 2049 / larger: the deferred
+path), list lengths around the 2048-element chunks a workgroup owns, periodic inputs that never separate, and the old
+sorter (BCE_K1_V1) as a second opinion.  Everything against File::rotate + File::bwt of the oracle (bce.cpp:858-910)."""
+import os
+
+import numpy as np
+import pytest
+
+import bce_amd
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def k1(data):
+    rf = bce_amd.RankFile(data, build=False)
+    try:
+        return bytes(rf.bwt()), rf.offset()
+    finally:
+        rf.close()
+
+
+def check(data):
+    data = bytes(data)
+    bwt, off = oracle.bwt_stage(data)
+    got, goff = k1(data)
+    assert goff == off
+    assert got == bytes(bwt)
+
+
+def repeats(unit, count, rng, sep=True):
+    """`count` copies of `unit`, each followed by a distinct tail: one group of `count` rotations per position of the unit."""
+    out = []
+    for i in range(count):
+        out.append(unit)
+        if sep:
+            out.append(b"\xff" + int(i).to_bytes(3, "big") + rng.bytes(3))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("sigma", [1, 2, 3, 4, 5, 16, 17, 127, 128, 129, 255, 256])
+def test_alphabet_sizes(sigma):
+    """sigma distinct bytes -> ceil(log2 sigma) bits per symbol, 64 / bits symbols per key (16 at most); sigma = 1 never separates."""
+    rng = np.random.RandomState(sigma)
+    vals = rng.permutation(256)[:sigma].astype(np.uint8)
+    for n in (1, 2, 3, 17, 300, 5000, 70001):
+        data = vals[rng.randint(0, sigma, n)]
+        if sigma > 1 and n >= sigma:
+            data[:sigma] = vals                      # every symbol occurs
+        check(data)
+
+
+@pytest.mark.parametrize("count", [2, 63, 64, 65, 1023, 1024, 1025, 2047, 2048, 2049, 2050, 4095, 4096, 4097, 9000])
+def test_group_sizes_around_the_lds_limit(count):
+    """Groups of exactly `count` rotations that share 40 bytes (then differ): sorted in LDS up to 2048, deferred to the wide
+    sort above; 2047 / 2048 / 2049 sit on the boundary of both rules (group <= SEG_CAP, group starts in the chunk)."""
+    rng = np.random.RandomState(count)
+    unit = rng.bytes(40)
+    check(repeats(unit, count, rng))
+
+
+def test_many_groups_of_mixed_sizes_and_chunk_boundaries():
+    """Groups of 2 .. 5000 members in one input, and list lengths of 2048 k - 1, 2048 k, 2048 k + 1 active elements (a
+    workgroup owns the groups that START in its 2048-element chunk; the last chunk is ragged)."""
+    rng = np.random.RandomState(7)
+    parts = []
+    for g in (2, 3, 7, 64, 100, 511, 2048, 2049, 3000, 5000, 2, 2047):
+        parts.append(repeats(rng.bytes(int(rng.randint(12, 60))), g, rng))
+    check(b"".join(parts))
+    for total in (2047, 2048, 2049, 4095, 4096, 4097, 6143, 6145):
+        # `total` rotations in non-singleton groups: pairs of equal 24-byte units
+        units = [rng.bytes(24) for _ in range(total // 2)]
+        body = b"".join(u + b"\xfe" + rng.bytes(4) + u + b"\xfd" + rng.bytes(4) for u in units)
+        check(body)
+
+
+def test_long_runs_and_periodic_inputs():
+    """Runs (one giant group that shrinks by one per byte: deferred in every round), period-p inputs (rotations p apart are EQUAL:
+    h reaches n with groups left), and the mixture an executable is made of."""
+    rng = np.random.RandomState(3)
+    check(bytes(100000))
+    check(b"ab" * 30000)
+    check(b"abcabcabd" * 9000)
+    check(bytes(70000) + b"\x01" + bytes(50000) + rng.bytes(1000) + bytes(6000))
+    check(b"".join(bytes(int(rng.randint(1, 6000))) + rng.bytes(int(rng.randint(1, 40))) for _ in range(300)))
+    check((rng.bytes(4099) * 50)[:200001])
+
+
+def test_old_sorter_agrees(monkeypatch):
+    """BCE_K1_V1=1 (the sorter of rounds 1-2) and the new one on the same inputs: the same BWT and offset."""
+    rng = np.random.RandomState(11)
+    inputs = [oracle.synth_text(5, 1 << 20), repeats(rng.bytes(50), 3000, rng), bytes(50000) + rng.bytes(50000)]
+    new = [k1(d) for d in inputs]
+    monkeypatch.setenv("BCE_K1_V1", "1")
+    old = [k1(d) for d in inputs]
+    assert new == old
