@@ -669,6 +669,7 @@ int bce_hip_scan(bce_hip_ctx *c, uint8_t config288[BCE_HIP_CONFIG_BYTES], double
 static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes) {
   BCE_TRY(check_stage(c, 3));
   if (!config288) return BCE_HIP_E_ARG;
+  const double t_begin = now_s();
   gate_acquire(c);
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   c->coder->drain();
@@ -690,11 +691,13 @@ static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes) {
       return 0;
     }
   } host;
-  double t_copy = 0, t_record = 0;
+  double t_copy = 0, t_record = 0, t_pin = 0;
   auto consume = [&](uint64_t nsym) -> int {
     if (nsym) {
-      const double tc0 = now_s();
+      const double tp0 = now_s();
       if (host.ensure((size_t)nsym > (size_t)c->sym_cap ? (size_t)nsym : (size_t)c->sym_cap)) return BCE_HIP_E_NOMEM;
+      const double tc0 = now_s();
+      t_pin += tc0 - tp0;
       BCE_HIP_TRY(c, hipMemcpyAsync(host.p, c->scanrec.p, (size_t)nsym * 4, hipMemcpyDeviceToHost, c->stream));
       BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
       t_copy += now_s() - tc0;
@@ -721,10 +724,17 @@ static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes) {
   coders.flush(init, res);                                 // coder_[i].flush() :1135-1138, then main(-1).flush() :1141-1149
   c->stats.t_coder += now_s() - tf0;
   if (getenv("BCE_HIP_SCAN_DEBUG"))
-    fprintf(stderr, "scan: %llu symbols in %llu batches: device-to-host copies %.3f s, recording %.3f s, optimisation %.3f s on %u host threads; K3 %.1f ms\n",
-            (unsigned long long)c->stats.symbols, (unsigned long long)c->stats.flushes, t_copy, t_record, now_s() - tf0, coders.threads(), c->stats.k3_ms);
+    fprintf(stderr, "scan: %llu symbols in %llu batches: pinned buffer %.3f s, device-to-host copies %.3f s, recording %.3f s, optimisation %.3f s on %u host threads; K3 %.1f ms; %.3f s since entry\n",
+            (unsigned long long)c->stats.symbols, (unsigned long long)c->stats.flushes, t_pin, t_copy, t_record, now_s() - tf0, coders.threads(), c->stats.k3_ms, now_s() - t_begin);
   if (result_bytes) memcpy(result_bytes, res, sizeof res);
   memcpy(config288, init, BCE_HIP_CONFIG_BYTES);
+  if (getenv("BCE_HIP_SCAN_DEBUG")) {
+    const double t0 = now_s();
+    coders.release();
+    const double t1 = now_s();
+    host.ensure(0); if (host.p) { (void)hipHostFree(host.p); host.p = nullptr; host.cap = 0; }
+    fprintf(stderr, "scan: giving back the recorded streams %.3f s, the pinned buffer %.3f s\n", t1 - t0, now_s() - t1);
+  }
   return BCE_HIP_OK;
 }
 

@@ -2,10 +2,13 @@
 #include "scan_coder.h"
 
 #include <sched.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <thread>
 
@@ -26,6 +29,20 @@ template <class F> void run_tasks(unsigned threads, size_t ntasks, F &&fn) {
 }
 }  // namespace
 
+void ScanCoder::put(uint32_t k, uint32_t q1, uint32_t q2, uint32_t sym) {
+  PerK &t = stat_[k];
+  if (t.group_of.empty()) t.group_of.assign(65536, 0u);
+  uint32_t &g = t.group_of[(q2 << 8) | q1];
+  if (!g) {                                                   // first symbol of this key: the map learns it NOW, as stat_[k][key] would
+    const uint32_t id = (uint32_t)t.order.size();
+    t.order.emplace((q2 << 16) | q1, id);                     // the reference's key: (c2 << 8) / cs << 16 | (c1 << 8) / cs  (:743)
+    g = id + 1;
+  }
+  t.sym.push_back((uint8_t)sym);
+  t.grp.push_back((uint16_t)(g - 1));
+  t.ready = false;
+}
+
 void ScanCoder::set(uint32_t s, uint32_t k, uint32_t c1, uint32_t c2, uint32_t cs) {
   // k > 31: one uniform bit is charged and the range halves -- with ScanCoder's OWN formula
   // (k >> 1) + (~s & 1), which differs from AdaptiveCoder's (k + (~s & 1)) >> 1 for even k (quirk Q2)
@@ -35,36 +52,48 @@ void ScanCoder::set(uint32_t s, uint32_t k, uint32_t c1, uint32_t c2, uint32_t c
     s = s0 >> 1;
     k = (k >> 1) + ((~s0) & 1u);
   }
-  stat_[k][scan_key(c1, c2, cs)].push_back((uint8_t)s);
+  const uint32_t key = scan_key(c1, c2, cs);                  // both quotients < 256 (c < cs)
+  put(k, key & 0xFFFFu, key >> 16, s);
 }
 
 void ScanCoder::set_packed(uint32_t word, int cls) {
   const uint32_t k = (word >> 5) & 31u;
   if (cls == 0) nesc_ += word >> 26;
   if (class_of(k) != cls) return;
-  // the map decides the ORDER (of its iteration, later); finding a key's vector again goes through a flat table of the
-  // 2^16 possible keys (both quotients are < 256)
-  const uint32_t q1 = (word >> 10) & 0xFFu, q2 = (word >> 18) & 0xFFu;
-  std::vector<std::vector<uint8_t> *> &fast = fast_[k];
-  if (fast.empty()) fast.assign(65536, nullptr);
-  std::vector<uint8_t> *&v = fast[(q2 << 8) | q1];
-  if (!v) v = &stat_[k][(q2 << 16) | q1];                     // the reference's key: (c2 << 8) / cs << 16 | (c1 << 8) / cs  (:743)
-  v->push_back((uint8_t)(word & 31u));
+  put(k, (word >> 10) & 0xFFu, (word >> 18) & 0xFFu, word & 31u);
 }
 
-uint64_t ScanCoder::symbols(uint32_t k) const {
-  uint64_t t = 0;
-  for (auto &g : stat_[k]) t += g.second.size();
-  return t;
+uint64_t ScanCoder::symbols(uint32_t k) const { return stat_[k].sym.size(); }
+
+void ScanCoder::prepare(uint32_t k) const {
+  PerK &t = stat_[k];
+  if (t.ready) return;
+  const size_t ng = t.order.size(), n = t.sym.size();
+  std::vector<uint32_t> pos_of(ng);                           // group number -> place in the iteration order
+  t.gkey.resize(ng);
+  size_t at = 0;
+  for (auto &g : t.order) { t.gkey[at] = g.first; pos_of[g.second] = (uint32_t)at; ++at; }
+  std::vector<uint64_t> cnt(ng + 1, 0);
+  for (size_t i = 0; i < n; ++i) ++cnt[pos_of[t.grp[i]] + 1];
+  for (size_t g = 0; g < ng; ++g) cnt[g + 1] += cnt[g];      // cnt[g] = where group g (in iteration order) starts
+  t.gend.assign(cnt.begin() + 1, cnt.end());
+  t.sorted.resize(n);
+  for (size_t i = 0; i < n; ++i) t.sorted[cnt[pos_of[t.grp[i]]]++] = t.sym[i];
+  t.ready = true;
 }
 
 double ScanCoder::base_cost(uint32_t k) const {
+  prepare(k);
+  const PerK &t = stat_[k];
   double z_min = 0;
-  for (auto &g : stat_[k]) z_min += std::log(k) * g.second.size();            // cost with no model at all
+  uint64_t lo = 0;
+  for (size_t g = 0; g < t.gkey.size(); ++g) { z_min += std::log(k) * (t.gend[g] - lo); lo = t.gend[g]; }   // cost with no model at all
   return z_min;
 }
 
 double ScanCoder::trial_cost(uint32_t k, uint32_t j) const {
+  prepare(k);
+  const PerK &t = stat_[k];
   std::vector<uint16_t> ctr((size_t)k << (2 * j), 0);
   // log(l / c) has few distinct arguments: l = k + sum of k counters <= 255 k, c = 1 + counter <= 255.  For small k (where
   // nearly all symbols are) the values are kept in a table filled on first use with the very expression the reference
@@ -78,18 +107,20 @@ double ScanCoder::trial_cost(uint32_t k, uint32_t j) const {
   std::vector<Ent> cache;
   if (!tabled) cache.assign(1u << 15, Ent{0u, 0.0});
   double z = 0;
-  for (auto &g : stat_[k]) {
-    uint16_t q1 = (uint16_t)(g.first >> 0), q2 = (uint16_t)(g.first >> 16);   // 8-bit quantised c1, c2
+  uint64_t at = 0;
+  for (size_t g = 0; g < t.gkey.size(); ++g) {
+    uint16_t q1 = (uint16_t)(t.gkey[g] >> 0), q2 = (uint16_t)(t.gkey[g] >> 16);   // 8-bit quantised c1, c2
     q1 >>= 8 - j;
     q2 >>= 8 - j;
     uint16_t *ctx = &ctr[(size_t)((q1 << j) | q2) * k];
-    for (uint8_t sym : g.second) {
+    for (; at < t.gend[g]; ++at) {
+      const uint8_t sym = t.sorted[at];
       uint32_t l = k;
       for (uint32_t i = 0; i < k; ++i) l += ctx[i];
       if (tabled) {
-        double &t = tab[(size_t)l * 256 + (1u + ctx[sym])];
-        if (t < 0) t = std::log(static_cast<double>(l) / (1 + ctx[sym]));
-        z += t;
+        double &e = tab[(size_t)l * 256 + (1u + ctx[sym])];
+        if (e < 0) e = std::log(static_cast<double>(l) / (1 + ctx[sym]));
+        z += e;
       } else {
         const uint32_t cc = 1u + ctx[sym], key = (l << 8) | cc;      // (l <= 255 k < 2^13, c <= 255: never 0)
         Ent &e = cache[(key * 2654435761u) >> 17];
@@ -103,8 +134,85 @@ double ScanCoder::trial_cost(uint32_t k, uint32_t j) const {
   return z;
 }
 
+// The six trials of one k in ONE pass over the recorded symbols: six counter tables, six accumulators -- each z_j adds up the
+// very terms trial_cost(k, j) adds, in the same order (a symbol's term for j depends on table j alone), so the doubles
+// are the same; the symbols, the map and the log table are walked once instead of six times.
+void ScanCoder::trial_costs(uint32_t k, double out[6]) const {
+  prepare(k);
+  const PerK &t = stat_[k];
+  std::vector<uint16_t> ctr[6];
+  for (uint32_t j = 0; j <= 5; ++j) ctr[j].assign((size_t)k << (2 * j), 0);
+  const bool tabled = k <= 4;
+  std::vector<double> tab;
+  if (tabled) tab.assign((size_t)(255 * k + 1) * 256, -1.0);
+  struct Ent { uint32_t key; double v; };
+  std::vector<Ent> cache;
+  if (!tabled) cache.assign(1u << 15, Ent{0u, 0.0});
+  auto lg = [&](uint32_t l, uint32_t c) -> double {           // log(l / c) as the reference evaluates it, remembered
+    if (tabled) {
+      double &t = tab[(size_t)l * 256 + c];
+      if (t < 0) t = std::log(static_cast<double>(l) / c);
+      return t;
+    }
+    const uint32_t key = (l << 8) | c;
+    Ent &e = cache[(key * 2654435761u) >> 17];
+    if (e.key != key) { e.key = key; e.v = std::log(static_cast<double>(l) / c); }
+    return e.v;
+  };
+  double z[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t at = 0;
+  for (size_t g = 0; g < t.gkey.size(); ++g) {
+    uint16_t *ctx[6];
+    for (uint32_t j = 0; j <= 5; ++j) {
+      uint16_t q1 = (uint16_t)(t.gkey[g] >> 0), q2 = (uint16_t)(t.gkey[g] >> 16);
+      q1 >>= 8 - j;
+      q2 >>= 8 - j;
+      ctx[j] = &ctr[j][(size_t)((q1 << j) | q2) * k];
+    }
+    for (; at < t.gend[g]; ++at) {
+      const uint8_t sym = t.sorted[at];
+#pragma GCC unroll 6
+      for (uint32_t j = 0; j <= 5; ++j) {
+        uint16_t *c = ctx[j];
+        uint32_t l = k;
+        for (uint32_t i = 0; i < k; ++i) l += c[i];
+        z[j] += lg(l, 1u + c[sym]);
+        if (++c[sym] == 0xFF)
+          for (uint32_t i = 0; i < k; ++i) c[i] >>= 1;
+      }
+    }
+  }
+  for (uint32_t j = 0; j <= 5; ++j) out[j] = z[j];
+}
+
+// z after `z += c` executed m times (c > 0, z >= 0), the same double the loop gives, in ~one step per binade instead of m.
+// While z and z + c stay in one binade [2^(e-1), 2^e) every z is a multiple of that binade's ulp, so fl(z + c) - z is one
+// fixed multiple d of the ulp (c rounded to the ulp: the rounding sees only c's remainder, the same at every step) -- unless
+// c lies exactly half way between two multiples (ties go by the parity of z: those steps are taken one by one).  The steps
+// that stay below 2^e are therefore one exact multiplication; the step that crosses into the next binade is a real addition.
+double scan_add_repeated(double z, double c, uint64_t m) {
+  while (m) {
+    const double z1 = z + c;
+    int e0 = 0, e1 = 0;
+    (void)std::frexp(z, &e0);
+    (void)std::frexp(z1, &e1);
+    if (!(z > 0) || e0 != e1) { z = z1; --m; continue; }
+    const double d = z1 - z;                                  // exact (same binade)
+    const double ulp = std::ldexp(1.0, e0 - 53);
+    if (!(d > 0) || std::fabs(c - d) * 2 >= ulp) { z = z1; --m; continue; }   // a tie (or c below half an ulp): single steps
+    const double top = std::ldexp(1.0, e0);
+    const uint64_t Z = (uint64_t)((top - z) / ulp), D = (uint64_t)(d / ulp);  // exact integers < 2^53
+    uint64_t s = D ? (Z - 1) / D : 0;                         // the most steps with z + s d < top
+    if (s == 0) { z = z1; --m; continue; }
+    if (s > m) s = m;
+    z += (double)s * d;                                       // exact: s D < 2^53, the sum a multiple of ulp below top
+    m -= s;
+  }
+  return z;
+}
+
 double ScanCoder::finish(uint8_t init[9][32], const double base[32], const double trial[32][6]) {
-  for (uint64_t e = 0; e < nesc_; ++e) z_ += std::log(2);    // the escapes of set_class, added one by one as set() does
+  z_ = scan_add_repeated(z_, std::log(2), nesc_);            // the escapes of set_packed, `z_ += log(2)` each (:739), in order
   nesc_ = 0;
   for (uint32_t k = 2; k < 31u; ++k) {                       // k = 31 is never optimised (:754)
     double z_min = base[k];
@@ -133,6 +241,14 @@ ScanSet::ScanSet(unsigned threads) : threads_(threads) {
     CPU_ZERO(&set);
     threads_ = sched_getaffinity(0, sizeof set, &set) == 0 ? (unsigned)CPU_COUNT(&set) : std::thread::hardware_concurrency();
     threads_ = std::max(1u, std::min(threads_, 64u));
+    // a container's CPU quota (cgroup v2 cpu.max "quota period"): more runnable threads than the quota pays for are frozen
+    // together for the rest of each period -- the thread feeding the GPU with them -- so the pool stays within it
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      long long quota = 0, period = 0;
+      if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+        threads_ = std::max(1u, std::min(threads_, (unsigned)((quota + period - 1) / period)));
+      fclose(f);
+    }
   }
 }
 
@@ -146,25 +262,47 @@ void ScanSet::consume(const uint32_t *records, const std::vector<ScanSpan> spans
   });
 }
 
+void ScanSet::release() {
+  run_tasks(threads_, 9 * 32, [&](size_t t) { coders_[t / 32].stat_[t % 32] = ScanCoder::PerK(); });
+}
+
 void ScanSet::flush(uint8_t init[9][32], double result_bytes[9]) {
-  struct Task { uint8_t i, k, j; uint64_t w; };             // j = 6: the base cost
+  struct Task { uint8_t i, k; uint64_t w; };                // one task per (coder, k): group the stream, base cost, the six trials
   std::vector<Task> tasks;
   for (int i = 0; i < 9; ++i)
     for (uint32_t k = 2; k < 31u; ++k) {
       const uint64_t w = coders_[i].symbols(k);
       if (!w) continue;                                       // (all costs of an empty k are 0.0, as in the reference)
-      for (uint32_t j = 0; j <= 6; ++j) tasks.push_back(Task{(uint8_t)i, (uint8_t)k, (uint8_t)j, j == 6 ? w / 16 + 1 : w * (k + 8)});
+      tasks.push_back(Task{(uint8_t)i, (uint8_t)k, w * (k + 8)});
     }
   std::stable_sort(tasks.begin(), tasks.end(), [](const Task &a, const Task &b) { return a.w > b.w; });   // longest first
   std::vector<std::array<double, 32>> vb(9);
   std::vector<std::array<std::array<double, 6>, 32>> vt(9);
   for (auto &a : vb) a.fill(0.0);
   for (auto &a : vt) for (auto &b : a) b.fill(0.0);
+  std::vector<double> took(tasks.size(), 0.0), cpu(tasks.size(), 0.0);
+  const bool dbg = getenv("BCE_HIP_SCAN_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  auto tcpu = [] { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+  const double t_start = dbg ? now() : 0.0;
   run_tasks(threads_, tasks.size(), [&](size_t t) {
     const Task &q = tasks[t];
-    if (q.j == 6) vb[q.i][q.k] = coders_[q.i].base_cost(q.k);
-    else vt[q.i][q.k][q.j] = coders_[q.i].trial_cost(q.k, q.j);
+    const double t0 = dbg ? now() : 0.0, c0 = dbg ? tcpu() : 0.0;
+    vb[q.i][q.k] = coders_[q.i].base_cost(q.k);
+    coders_[q.i].trial_costs(q.k, vt[q.i][q.k].data());
+    if (dbg) { took[t] = now() - t0; cpu[t] = tcpu() - c0; }
   });
+  const double t_tasks = dbg ? now() : 0.0;
+  if (dbg) {
+    double sum = 0, csum = 0;
+    for (double d : took) sum += d;
+    for (double d : cpu) csum += d;
+    fprintf(stderr, "scan flush: %zu tasks ran %.3f s wall, %.3f s summed wall, %.3f s of thread CPU; longest:", tasks.size(), t_tasks - t_start, sum, csum);
+    for (size_t t = 0; t < tasks.size() && t < 6; ++t)
+      fprintf(stderr, " (plane %d k %d: %llu symbols) %.3f s", tasks[t].i, tasks[t].k,
+              (unsigned long long)coders_[tasks[t].i].symbols(tasks[t].k), took[t]);
+    fprintf(stderr, "\n");
+  }
   for (int i = 0; i < 9; ++i) {                               // coder_[i].flush() in order, then main(-1): :1135-1149
     double b[32], tr[32][6];
     for (int k = 0; k < 32; ++k) { b[k] = vb[i][k]; for (int j = 0; j < 6; ++j) tr[k][j] = vt[i][k][j]; }

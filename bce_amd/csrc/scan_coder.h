@@ -20,6 +20,8 @@
 
 namespace bce {
 
+double scan_add_repeated(double z, double c, uint64_t m);  // `z += c` m times, the loop's own double (scan_coder.cpp)
+
 class ScanCoder {
  public:
   explicit ScanCoder(int i) : nesc_(0), z_(0), i_(i < 0 || i > 7 ? 8 : i) {}    // :733
@@ -34,18 +36,38 @@ class ScanCoder {
   // that emitted it): the record is kept only if its k is of class `cls`; the thread of class 0 also adds up the escapes
   // (z_ += log(2) each, :739)
   void set_packed(uint32_t word, int cls);
+  void prepare_k(uint32_t k) const { prepare(k); }         // group the recorded stream of k (needed before the costs)
   double base_cost(uint32_t k) const;                      // z_min before any j (:757)
   double trial_cost(uint32_t k, uint32_t j) const;         // z of context bits j (:759-785)
+  void trial_costs(uint32_t k, double out[6]) const;       // ... all six j in one pass over the symbols (the same doubles)
   uint64_t symbols(uint32_t k) const;                      // records kept for k (task weights)
   // the ordered part of flush (:786-797) from the costs computed above
   double finish(uint8_t init[9][32], const double base[32], const double trial[32][6]);
 
  private:
-  std::array<std::unordered_map<uint32_t, std::vector<uint8_t>>, 32> stat_;
-  std::array<std::vector<std::vector<uint8_t> *>, 32> fast_;   // set_class: key -> its vector in stat_[k]
-  uint64_t nesc_;          // escapes seen by set_class (each is one `z_ += log(2)`, added in order by finish)
+  // What stat_[k] of the reference holds (unordered_map<uint32_t, vector<uint8_t>>, :731), kept as the two things it is
+  // used for: `order` is that very map with the vector replaced by a group number -- same keys inserted in the same
+  // sequence, hence the same iteration order (Q11: it decides the order of the double additions) -- and the symbols go to
+  // one append-only stream per k with their group number beside them.  prepare() sorts a stream by group (a stable
+  // counting sort: stream order within a group, as push_back gave) in the map's iteration order, so that base and trial
+  // costs walk contiguous bytes instead of 10^5 heap vectors per k -- whose filling, walking and freeing was most of the time.
+  struct PerK {
+    std::unordered_map<uint32_t, uint32_t> order;          // key (:743) -> group number
+    std::vector<uint32_t> group_of;                        // [q2 << 8 | q1] -> group number + 1 (0: not seen); sized on first use
+    std::vector<uint8_t> sym;                              // the stream
+    std::vector<uint16_t> grp;                             // ... and each symbol's group (at most 2^16 keys: both quotients < 256)
+    std::vector<uint32_t> gkey;                            // prepare(): keys in iteration order,
+    std::vector<uint64_t> gend;                            //   where each group ends in `sorted`,
+    std::vector<uint8_t> sorted;                           //   the symbols group by group
+    bool ready = false;
+  };
+  void put(uint32_t k, uint32_t q1, uint32_t q2, uint32_t sym);
+  mutable std::array<PerK, 32> stat_;
+  void prepare(uint32_t k) const;                          // idempotent; one thread per k at a time
+  uint64_t nesc_;          // escapes seen by set_packed (each is one `z_ += log(2)`, added in order by finish)
   double z_;
   int i_;
+  friend class ScanSet;
 };
 
 // The nine coders of one `bce -s` run (planes 0-7 and the header coder, whose set(s, k) is a no-op: bce.cpp:745-749).
@@ -57,6 +79,7 @@ class ScanSet {
   void consume(const uint32_t *records, const std::vector<ScanSpan> spans[8]);
   void flush(uint8_t init[9][32], double result_bytes[9]);
   unsigned threads() const { return threads_; }
+  void release();                                          // drop everything recorded (on the pool: the streams are ~4 B per symbol)
 
  private:
   std::vector<ScanCoder> coders_;

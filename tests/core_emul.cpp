@@ -192,3 +192,12 @@ extern "C" int emul_scan(const uint32_t *syms6, size_t nsym, unsigned threads, u
   memcpy(config288, init, 288);
   return 0;
 }
+
+// scan_add_repeated against the loop it replaces
+extern "C" int emul_add_repeated(double z, double c, uint64_t m, double *fast, double *slow) {
+  *fast = bce::scan_add_repeated(z, c, m);
+  double t = z;
+  for (uint64_t i = 0; i < m; ++i) t += c;
+  *slow = t;
+  return *fast == *slow;
+}

@@ -150,3 +150,23 @@ def test_scan_coder_sequential_and_threaded_equal_the_oracle(emul, gen, seed, n)
         emul.emul_scan(syms.ctypes.data, len(syms), threads, chunks, out.ctypes.data, r9.ctypes.data)
         assert out.tobytes() == cfg, (threads, chunks)
         assert list(r9) == res, (threads, chunks)
+
+
+def test_repeated_addition_equals_the_loop(emul):
+    """finish() adds log(2) once per escape (bce.cpp:739) -- several 10^8 times on binary data.  scan_add_repeated takes
+    the additions a binade at a time; the double must be the loop's, for any start, addend and count."""
+    import math
+    import random
+    emul.emul_add_repeated.argtypes = [C.c_double, C.c_double, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rng = random.Random(7)
+    cases = [(0.0, math.log(2), m) for m in (0, 1, 2, 3, 100, 12345, 1 << 20, 3_000_001, 40_000_000, 600_000_000)]
+    cases += [(0.0, 0.5, 1 << 22), (0.0, 0.75, 3_000_000), (1.0, 2.0 ** -53, 5000), (1.0, 2.0 ** -54, 5000),
+              (1.0, 3 * 2.0 ** -54, 100_000), (0.0, 1.5 * 2.0 ** -30, 1 << 22), (123.456, 1e-3, 2_000_000)]
+    for _ in range(60):
+        c = rng.choice([math.log(2), rng.random(), rng.random() * 1e-6, rng.uniform(1, 1e6), math.ldexp(rng.randrange(1, 1 << 53), -rng.randrange(40, 70))])
+        z = rng.choice([0.0, rng.random(), rng.uniform(0, 1e9), math.ldexp(1.0, rng.randrange(-3, 30))])
+        cases.append((z, c, rng.randrange(0, 2_000_000)))
+    for z, c, m in cases:
+        f, s = C.c_double(), C.c_double()
+        ok = emul.emul_add_repeated(z, c, m, C.byref(f), C.byref(s))
+        assert ok and f.value == s.value, (z, c, m, f.value, s.value)
