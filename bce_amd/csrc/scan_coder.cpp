@@ -2,6 +2,7 @@
 #include "scan_coder.h"
 
 #include <sched.h>
+#include <sys/mman.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <time.h>
@@ -10,6 +11,9 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <exception>
+#include <mutex>
+#include <new>
 #include <thread>
 
 namespace bce {
@@ -20,26 +24,73 @@ inline uint32_t scan_key(uint32_t c1, uint32_t c2, uint32_t cs) { return (((uint
 
 template <class F> void run_tasks(unsigned threads, size_t ntasks, F &&fn) {
   std::atomic<size_t> next{0};
-  auto work = [&] { for (size_t t; (t = next.fetch_add(1)) < ntasks;) fn(t); };
+  std::exception_ptr failed;                                  // the first exception of any worker (std::bad_alloc), rethrown by the caller
+  std::mutex mu;
+  auto work = [&] {
+    try {
+      for (size_t t; (t = next.fetch_add(1)) < ntasks;) fn(t);
+    } catch (...) {
+      next.store(ntasks);
+      std::lock_guard<std::mutex> lk(mu);
+      if (!failed) failed = std::current_exception();
+    }
+  };
   std::vector<std::thread> th;
   const unsigned extra = (unsigned)std::min<size_t>(threads > 0 ? threads - 1 : 0, ntasks > 0 ? ntasks - 1 : 0);
   for (unsigned i = 0; i < extra; ++i) th.emplace_back(work);
   work();
   for (auto &t : th) t.join();
+  if (failed) std::rethrow_exception(failed);
 }
 }  // namespace
 
+uint8_t *ScanArena::take(size_t bytes) {
+  bytes = (bytes + 63) & ~(size_t)63;
+  std::lock_guard<std::mutex> lk(mu_);
+  if (regions_.empty() || regions_.back().used + bytes > regions_.back().cap) {
+    constexpr size_t kRegion = (size_t)256 << 20;             // address space only: pages come when touched
+    const size_t cap = std::max(kRegion, (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1));
+    void *p = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) throw std::bad_alloc();
+    (void)madvise(p, cap, MADV_HUGEPAGE);                     // 2 MB pages where the kernel allows: 512 x fewer faults
+    regions_.push_back(Region{static_cast<uint8_t *>(p), cap, 0});
+  }
+  Region &r = regions_.back();
+  uint8_t *out = r.p + r.used;
+  r.used += bytes;
+  return out;
+}
+
+void ScanArena::release() {
+  std::lock_guard<std::mutex> lk(mu_);
+  for (Region &r : regions_) (void)munmap(r.p, r.cap);
+  regions_.clear();
+}
+
+void ScanCoder::learn(PerK &t, uint32_t key16) {
+  if (!t.seen) {
+    t.seen = arena_->take(65536);                             // (zero pages)
+    ScanBump *bump = new (arena_->take(sizeof(ScanBump))) ScanBump{arena_.get()};
+    t.order = new (arena_->take(sizeof(PerK::Order))) PerK::Order(ScanBumpAlloc<std::pair<const uint32_t, uint32_t>>(bump));
+  }
+  if (t.seen[key16]) return;
+  t.seen[key16] = 1;
+  // the reference's key: (c2 << 8) / cs << 16 | (c1 << 8) / cs  (:743)
+  t.order->emplace(((key16 >> 8) << 16) | (key16 & 0xFFu), 0u);
+}
+
 void ScanCoder::put(uint32_t k, uint32_t q1, uint32_t q2, uint32_t sym) {
   PerK &t = stat_[k];
-  if (t.group_of.empty()) t.group_of.assign(65536, 0u);
-  uint32_t &g = t.group_of[(q2 << 8) | q1];
-  if (!g) {                                                   // first symbol of this key: the map learns it NOW, as stat_[k][key] would
-    const uint32_t id = (uint32_t)t.order.size();
-    t.order.emplace((q2 << 16) | q1, id);                     // the reference's key: (c2 << 8) / cs << 16 | (c1 << 8) / cs  (:743)
-    g = id + 1;
-  }
-  t.sym.push_back((uint8_t)sym);
-  t.grp.push_back((uint16_t)(g - 1));
+  const uint32_t key16 = (q2 << 8) | q1;
+  learn(t, key16);
+  Open &o = t.own;
+  if (o.fill == kChunk) { o.chunk = arena_->take((size_t)kChunk * 3); o.fill = 0; }
+  reinterpret_cast<uint16_t *>(o.chunk)[o.fill] = (uint16_t)key16;
+  o.chunk[2 * (size_t)kChunk + o.fill] = (uint8_t)sym;
+  if (!t.segs.empty() && t.segs.back().chunk == o.chunk && t.segs.back().off + t.segs.back().count == o.fill) ++t.segs.back().count;
+  else t.segs.push_back(Seg{o.chunk, o.fill, 1});
+  ++o.fill;
+  ++t.n;
   t.ready = false;
 }
 
@@ -56,29 +107,30 @@ void ScanCoder::set(uint32_t s, uint32_t k, uint32_t c1, uint32_t c2, uint32_t c
   put(k, key & 0xFFFFu, key >> 16, s);
 }
 
-void ScanCoder::set_packed(uint32_t word, int cls) {
-  const uint32_t k = (word >> 5) & 31u;
-  if (cls == 0) nesc_ += word >> 26;
-  if (class_of(k) != cls) return;
-  put(k, (word >> 10) & 0xFFu, (word >> 18) & 0xFFu, word & 31u);
-}
-
-uint64_t ScanCoder::symbols(uint32_t k) const { return stat_[k].sym.size(); }
+uint64_t ScanCoder::symbols(uint32_t k) const { return stat_[k].n; }
 
 void ScanCoder::prepare(uint32_t k) const {
   PerK &t = stat_[k];
   if (t.ready) return;
-  const size_t ng = t.order.size(), n = t.sym.size();
-  std::vector<uint32_t> pos_of(ng);                           // group number -> place in the iteration order
+  const size_t ng = t.order ? t.order->size() : 0, n = t.n;
+  std::vector<uint32_t> pos_of(65536, 0);                     // key16 -> place in the iteration order
   t.gkey.resize(ng);
   size_t at = 0;
-  for (auto &g : t.order) { t.gkey[at] = g.first; pos_of[g.second] = (uint32_t)at; ++at; }
+  if (t.order)
+    for (auto &g : *t.order) { t.gkey[at] = g.first; pos_of[((g.first >> 16) << 8) | (g.first & 0xFFu)] = (uint32_t)at; ++at; }
   std::vector<uint64_t> cnt(ng + 1, 0);
-  for (size_t i = 0; i < n; ++i) ++cnt[pos_of[t.grp[i]] + 1];
-  for (size_t g = 0; g < ng; ++g) cnt[g + 1] += cnt[g];      // cnt[g] = where group g (in iteration order) starts
+  auto each = [&](auto &&fn) {                                 // fn(key16, symbol) over the stream, in order
+    for (const Seg &sg : t.segs) {
+      const uint16_t *key = reinterpret_cast<const uint16_t *>(sg.chunk) + sg.off;
+      const uint8_t *sym = sg.chunk + 2 * (size_t)kChunk + sg.off;
+      for (uint32_t i = 0; i < sg.count; ++i) fn(key[i], sym[i]);
+    }
+  };
+  each([&](uint16_t g, uint8_t) { ++cnt[pos_of[g] + 1]; });
+  for (size_t g = 0; g < ng; ++g) cnt[g + 1] += cnt[g];      // cnt[g] = where key g (in iteration order) starts
   t.gend.assign(cnt.begin() + 1, cnt.end());
-  t.sorted.resize(n);
-  for (size_t i = 0; i < n; ++i) t.sorted[cnt[pos_of[t.grp[i]]]++] = t.sym[i];
+  t.sorted = n ? arena_->take(n) : nullptr;
+  each([&](uint16_t g, uint8_t s) { t.sorted[cnt[pos_of[g]]++] = s; });
   t.ready = true;
 }
 
@@ -232,10 +284,11 @@ double ScanCoder::flush(uint8_t init[9][32]) {
   return finish(init, base, trial);
 }
 
-ScanSet::ScanSet(unsigned threads) : threads_(threads) {
-  for (int i = 0; i < 8; ++i) coders_.emplace_back(i);
-  coders_.emplace_back(-1);
+ScanSet::ScanSet(unsigned threads) : arena_(std::make_shared<ScanArena>()), threads_(threads) {
+  for (int i = 0; i < 8; ++i) coders_.emplace_back(i, arena_);
+  coders_.emplace_back(-1, arena_);
   if (const char *e = getenv("BCE_HIP_SCAN_THREADS")) threads_ = (unsigned)atoi(e);
+  if (const char *e = getenv("BCE_HIP_SCAN_MIN_RANGE")) min_range_ = std::max(1, atoi(e));   // (tests: many ranges on small inputs)
   if (threads_ == 0) {
     cpu_set_t set;
     CPU_ZERO(&set);
@@ -253,17 +306,80 @@ ScanSet::ScanSet(unsigned threads) : threads_(threads) {
 }
 
 void ScanSet::consume(const uint32_t *records, const std::vector<ScanSpan> spans[8]) {
-  // task = (plane, class of k): every map stat_[k] is filled by exactly one thread, in stream order
-  run_tasks(threads_, 8 * ScanCoder::kClasses, [&](size_t t) {
-    const int p = (int)(t / ScanCoder::kClasses), cls = (int)(t % ScanCoder::kClasses);
-    ScanCoder &c = coders_[p];
-    for (const ScanSpan &e : spans[p])
-      for (uint64_t i = e.start; i < e.start + e.count; ++i) c.set_packed(records[i], cls);
+  // 1. Every plane's records are cut into ranges of about equal length; a task records one range, all k at once, into the
+  //    chunks of its slot.  What must happen in stream order -- a key entering the map -- is only noted (the slot's
+  //    `fresh` list: keys this slot meets for the first time).
+  constexpr uint32_t kChunk = ScanCoder::kChunk;
+  uint64_t total = 0, np[8];
+  for (int p = 0; p < 8; ++p) { np[p] = 0; for (const ScanSpan &e : spans[p]) np[p] += e.count; total += np[p]; }
+  if (!total) return;
+  const uint64_t target = std::max<uint64_t>(min_range_, (total + 3 * threads_ - 1) / (3 * threads_));
+  struct Task { uint8_t p, s; uint64_t lo, hi; };              // records [lo, hi) of plane p's spans laid end to end
+  std::vector<Task> tasks;
+  unsigned pieces[8];
+  for (int p = 0; p < 8; ++p) {
+    pieces[p] = np[p] ? (unsigned)std::min<uint64_t>(kSlots, (np[p] + target - 1) / target) : 0;
+    for (unsigned s = 0; s < pieces[p]; ++s) tasks.push_back(Task{(uint8_t)p, (uint8_t)s, np[p] * s / pieces[p], np[p] * (s + 1) / pieces[p]});
+  }
+  if (slots_.empty()) slots_.resize(8 * kSlots);
+  for (const Task &q : tasks)
+    if (!slots_[q.p * kSlots + q.s]) slots_[q.p * kSlots + q.s].reset(new Slot());
+  run_tasks(threads_, tasks.size(), [&](size_t ti) {
+    const Task &q = tasks[ti];
+    Slot &sl = *slots_[q.p * kSlots + q.s];
+    uint32_t start[32];
+    for (int k = 0; k < 32; ++k) start[k] = sl.open[k].fill;
+    uint64_t nesc = 0, at = 0;
+    for (const ScanSpan &e : spans[q.p]) {
+      const uint64_t lo = std::max(at, q.lo), hi = std::min(at + e.count, q.hi);
+      for (uint64_t i = lo; i < hi; ++i) {
+        const uint32_t w = records[e.start + (i - at)];
+        const uint32_t k = (w >> 5) & 31u, key16 = (w >> 10) & 0xFFFFu;     // [17:10] q1, [25:18] q2: q2 << 8 | q1
+        nesc += w >> 26;
+        ScanCoder::Open &o = sl.open[k];
+        if (o.fill == kChunk) {
+          if (o.chunk && start[k] < kChunk) sl.segs[k].push_back(ScanCoder::Seg{o.chunk, start[k], kChunk - start[k]});
+          o.chunk = arena_->take((size_t)kChunk * 3);
+          o.fill = 0;
+          start[k] = 0;
+        }
+        reinterpret_cast<uint16_t *>(o.chunk)[o.fill] = (uint16_t)key16;
+        o.chunk[2 * (size_t)kChunk + o.fill] = (uint8_t)(w & 31u);
+        ++o.fill;
+        uint8_t *&seen = sl.seen[k];
+        if (!seen) seen = arena_->take(8192);
+        if (!((seen[key16 >> 3] >> (key16 & 7u)) & 1u)) { seen[key16 >> 3] |= (uint8_t)(1u << (key16 & 7u)); sl.fresh[k].push_back((uint16_t)key16); }
+      }
+      at += e.count;
+      if (at >= q.hi) break;
+    }
+    for (int k = 0; k < 32; ++k)
+      if (sl.open[k].chunk && sl.open[k].fill > start[k] && start[k] < kChunk)
+        sl.segs[k].push_back(ScanCoder::Seg{sl.open[k].chunk, start[k], sl.open[k].fill - start[k]});
+    sl.nesc += nesc;
   });
+  // 2. Per (plane, k), the slots in range order: their pieces join the stream, their fresh keys enter the map -- a key
+  //    more than one slot met enters where the first of them met it, which is where the sequential set() would have.
+  run_tasks(threads_, 8 * 32, [&](size_t ti) {
+    const unsigned p = (unsigned)(ti / 32), k = (unsigned)(ti % 32);
+    ScanCoder &c = coders_[p];
+    ScanCoder::PerK &t = c.stat_[k];
+    for (unsigned s = 0; s < pieces[p]; ++s) {
+      Slot &sl = *slots_[p * kSlots + s];
+      for (const ScanCoder::Seg &sg : sl.segs[k]) { t.segs.push_back(sg); t.n += sg.count; t.ready = false; }
+      sl.segs[k].clear();
+      for (uint16_t key16 : sl.fresh[k]) c.learn(t, key16);
+      sl.fresh[k].clear();
+    }
+  });
+  for (int p = 0; p < 8; ++p)
+    for (unsigned s = 0; s < pieces[p]; ++s) { Slot &sl = *slots_[p * kSlots + s]; coders_[p].nesc_ += sl.nesc; sl.nesc = 0; }
 }
 
 void ScanSet::release() {
-  run_tasks(threads_, 9 * 32, [&](size_t t) { coders_[t / 32].stat_[t % 32] = ScanCoder::PerK(); });
+  for (ScanCoder &c : coders_) for (auto &t : c.stat_) t = ScanCoder::PerK();
+  slots_.clear();
+  arena_->release();
 }
 
 void ScanSet::flush(uint8_t init[9][32], double result_bytes[9]) {

@@ -132,8 +132,8 @@ def test_context_index_u32_wrap_matches_reference(emul):
 
 @pytest.mark.parametrize("gen,seed,n", [("synth_text", 1, 1 << 20), ("synth_rand", 5, 150000), ("synth_text", 9, 70000)])
 def test_scan_coder_sequential_and_threaded_equal_the_oracle(emul, gen, seed, n):
-    """`bce -s` host part (scan_coder.cpp): ScanCoder::set / flush and the threaded ScanSet (recording split by plane and
-    class of k, optimisation by (coder, k, j)) give the oracle's 288-byte table and the SAME doubles for the nine
+    """`bce -s` host part (scan_coder.cpp): ScanCoder::set / flush and the threaded ScanSet (recording split by ranges of a
+    plane's records, optimisation by (coder, k)) give the oracle's 288-byte table and the SAME doubles for the nine
     "Result size" lines -- the order of every floating-point sum is kept.  synth-text 1 MiB is the
     vector whose .bcc hash SURVEY 8c records."""
     import hashlib
@@ -144,12 +144,19 @@ def test_scan_coder_sequential_and_threaded_equal_the_oracle(emul, gen, seed, n)
     if gen == "synth_text" and n == 1 << 20:
         h = hashlib.sha256(cfg).hexdigest()
         assert h.startswith("7f7c243b") and h.endswith("4cea2f")
-    for threads, chunks in ((0, 1), (1, 1), (5, 3), (16, 7)):
+    # (threads, buffers, shortest range): the last makes consume() cut each plane's records into up to 16 ranges recorded
+    # by different threads even on these small inputs (by default a range has at least 32768 records)
+    for threads, chunks, min_range in ((0, 1, None), (1, 1, None), (5, 3, None), (16, 7, None), (16, 1, 50), (7, 5, 300), (3, 2, 1)):
         out = np.zeros(288, dtype=np.uint8)
         r9 = np.zeros(9, dtype=np.float64)
-        emul.emul_scan(syms.ctypes.data, len(syms), threads, chunks, out.ctypes.data, r9.ctypes.data)
-        assert out.tobytes() == cfg, (threads, chunks)
-        assert list(r9) == res, (threads, chunks)
+        if min_range is not None:
+            os.environ["BCE_HIP_SCAN_MIN_RANGE"] = str(min_range)
+        try:
+            emul.emul_scan(syms.ctypes.data, len(syms), threads, chunks, out.ctypes.data, r9.ctypes.data)
+        finally:
+            os.environ.pop("BCE_HIP_SCAN_MIN_RANGE", None)
+        assert out.tobytes() == cfg, (threads, chunks, min_range)
+        assert list(r9) == res, (threads, chunks, min_range)
 
 
 def test_repeated_addition_equals_the_loop(emul):

@@ -79,4 +79,4 @@ def test_scan_of_1e8_bytes_stays_under_seconds():
     cfg, sizes = bce_amd.scan(data)
     dt = time.time() - t0
     print("bce -s of 1e8 B: %.2f s" % dt)
-    assert len(cfg) == 288 and dt < 8.0, "scan took %.1f s" % dt
+    assert len(cfg) == 288 and dt < 4.0, "scan took %.1f s" % dt
