@@ -1328,6 +1328,41 @@ static std::vector<int> tail_cpus() {
   return ccx;
 }
 
+// The host tail's pinned copy of the boundary ranks is 32 (n + 1) bytes; pinning them takes ~0.15 s per GB the first time a
+// context needs them (3.2 GB at 10^8 bytes: 0.5 s, a third of a whole decode).  Once a decode looks like it will end in
+// a long tail (see the caller) the allocation is started on a thread of its own, beside the GPU's rounds.
+struct BigPin {
+  bce_hip_ctx *c = nullptr;
+  std::thread th;
+  void *p = nullptr;
+  size_t bytes = 0;
+  hipError_t err = hipSuccess;
+  bool running = false;
+  double t_start = 0, t_done = 0;
+  void start(bce_hip_ctx *ctx, size_t want) {
+    if (running || ctx->h_big_cap >= want) return;
+    c = ctx; bytes = want;
+    const int dev = ctx->device;
+    try {
+      t_start = now_s();
+      th = std::thread([this, dev] { err = hipSetDevice(dev); if (err == hipSuccess) err = hipHostMalloc(&p, bytes, hipHostMallocDefault); t_done = now_s(); });
+      running = true;
+    } catch (...) { running = false; }                        // (no thread: dec_host_tail allocates as before)
+  }
+  void settle() {                                              // the buffer, if it came, becomes the context's
+    if (!running) return;
+    const double t0 = now_s();
+    th.join();
+    running = false;
+    if (getenv("BCE_DEC_TIMING")) fprintf(stderr, "gpu decode: pinned %.1f GB beside the rounds: %.3f s, the tail waited %.3f s of them\n", bytes / 1e9, t_done - t_start, now_s() - t0);
+    if (err == hipSuccess && p) {
+      if (c->h_big) (void)hipHostFree(c->h_big);
+      c->h_big = p; c->h_big_cap = bytes; p = nullptr;
+    }
+  }
+  ~BigPin() { settle(); }
+};
+
 constexpr uint32_t kHostTailMin = 20000;                    // ... rounds, or n / 1000 if that is more (the copies cost ~n)
 
 int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vector<Decoder> &dec, uint32_t n, uint32_t *round,
@@ -1369,7 +1404,10 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
     uint64_t nodes = 0, queries = 0;
   };
   std::unique_ptr<PlaneOut[]> po(new PlaneOut[8]);
-  const size_t pairs_max = stride / 8 + 1;                                 // beyond that (per plane) the whole array goes back
+  // beyond that many pairs (per plane) the whole array goes back: the pinned copy runs at the bus' rate (3.2 GB in 56 ms),
+  // while a pair costs two appends here, a place in two pageable arrays and a scattered store there (~7 ns: 18 M pairs of
+  // the natural corpus took longer than the whole array)
+  const size_t pairs_max = std::min<size_t>(stride / 8 + 1, (size_t)1 << 18);
   std::atomic<bool> bad_flag{false};
   // One plane of one round (BCE::code mode 0, bce.cpp:1261-1351): reads and writes plane i's boundary ranks only, appends to the
   // lists of plane i + 1 only -- the planes of a round are independent, which is the reference's own OpenMP split (:1250-1252).
@@ -1377,6 +1415,15 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
     uint32_t *R = Rh + (size_t)i * stride;
     const uint32_t zi = a.zeros[i];
     PlaneOut &P = po[i];
+    // a child is plane i + 1's node in the NEXT round: its three boundary ranks are asked for now (two random lines of a
+    // 4(n + 1)-byte array: DRAM), so that they are in the cache (this core's, or the L3 it shares with the plane's thread)
+    // by the time the round gets there -- in the chains a round is ~10 nodes and was mostly waiting for these lines
+    const uint32_t *Rn = Rh + (size_t)((i + 1u) & 7u) * stride;
+    auto ask = [&](uint32_t cs, uint32_t cx0, uint32_t cx1) {
+      __builtin_prefetch(Rn + cs, 0, 3);
+      __builtin_prefetch(Rn + cs + cx0 + cx1, 0, 3);
+      __builtin_prefetch(Rn + cs + cx0, 1, 3);
+    };
     std::vector<Node> &o0 = P.o0, &o1 = P.o1;
     std::vector<uint64_t> &wi = P.wi;
     std::vector<uint32_t> &wv = P.wv;
@@ -1388,8 +1435,8 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
         const uint32_t s1 = R[s], n1x = R[s + x] - s1, s0 = s - s1;
         if (n1x > x) { bad_flag.store(true); return; }
         uint32_t n1x0;
-        if (!n1x) { o0.push_back(Node{s0, x0, x1}); n1x0 = 0; }
-        else if (n1x == x) { o1.push_back(Node{zi + s1, x0, x1}); n1x0 = x0; }
+        if (!n1x) { o0.push_back(Node{s0, x0, x1}); ask(s0, x0, x1); n1x0 = 0; }
+        else if (n1x == x) { o1.push_back(Node{zi + s1, x0, x1}); ask(zi + s1, x0, x1); n1x0 = x0; }
         else {
           const uint32_t n0x = x - n1x;
           uint32_t mn = x0 - n1x, mx = n1x - x1;
@@ -1400,10 +1447,10 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
           if (mx != mn) { n0x0 = mn + dec[i].get_adaptive(mx - mn + 1, n0x, x1, x); ++qq; }
           if (n0x0 > mx) { bad_flag.store(true); return; }
           const uint32_t n0x1 = n0x - n0x0;
-          if (n0x0 && n0x1) o0.push_back(Node{s0, n0x0, n0x1});
+          if (n0x0 && n0x1) { o0.push_back(Node{s0, n0x0, n0x1}); ask(s0, n0x0, n0x1); }
           const uint32_t n1x1 = x1 - n0x1;
           n1x0 = n1x - n1x1;
-          if (n1x0 && n1x1) o1.push_back(Node{zi + s1, n1x0, n1x1});
+          if (n1x0 && n1x1) { o1.push_back(Node{zi + s1, n1x0, n1x1}); ask(zi + s1, n1x0, n1x1); }
         }
         R[s + x0] = s1 + n1x0;
         if (wi.size() <= pairs_max) { wi.push_back((uint64_t)i * stride + s + x0); wv.push_back(s1 + n1x0); }
@@ -1472,13 +1519,17 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
     pool.th.clear();
     threaded = false;
   }
-  uint64_t par_rounds = 0;
+  uint64_t par_rounds = 0, par_nodes = 0, ser_nodes = 0;
+  double par_time = 0, ser_time = 0;
+  const bool tail_timing = getenv("BCE_DEC_TIMING") != nullptr;
   uint32_t rounds = 0, serial_run = 0;
   auto unpark = [&] { { std::lock_guard<std::mutex> lk(pool.mu); pool.parked.store(false); } pool.cv.notify_all(); };
   for (bool again = true; again && !bad_flag.load();) {
     size_t tot = 0;
     for (int i = 0; i < 8; ++i) tot += cur[i][0].size() + cur[i][1].size();
-    if (threaded && tot >= kParMin) {
+    const double tr0 = tail_timing ? now_s() : 0.0;
+    const bool par_round = threaded && tot >= kParMin;
+    if (par_round) {
       if (pool.parked.load(std::memory_order_relaxed)) unpark();
       serial_run = 0;
       pool.done.store(0, std::memory_order_relaxed);
@@ -1490,6 +1541,7 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
       for (uint32_t i = 0; i < 8 && !bad_flag.load(std::memory_order_relaxed); ++i) do_plane(i);
       if (threaded && ++serial_run == kParkAfter) pool.parked.store(true, std::memory_order_release);
     }
+    if (tail_timing) { const double d = now_s() - tr0; if (par_round) { par_time += d; par_nodes += tot; } else { ser_time += d; ser_nodes += tot; } }
     ++rounds;
     again = false;
     for (int i = 0; i < 8; ++i) {                                          // plane i's children are plane i + 1's nodes
@@ -1513,7 +1565,8 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
   }
   if (!whole)
     for (int i = 0; i < 8; ++i) { widx.insert(widx.end(), po[i].wi.begin(), po[i].wi.end()); wval.insert(wval.end(), po[i].wv.begin(), po[i].wv.end()); }
-  if (getenv("BCE_DEC_TIMING")) fprintf(stderr, "gpu decode: host tail: %llu of %u rounds on eight threads\n", (unsigned long long)par_rounds, rounds);
+  if (tail_timing) fprintf(stderr, "gpu decode: host tail: %llu of %u rounds on eight threads (%llu nodes, %.3f s), the others on one (%llu nodes, %.3f s)\n",
+                           (unsigned long long)par_rounds, rounds, (unsigned long long)par_nodes, par_time, (unsigned long long)ser_nodes, ser_time);
   *bad_out = bad;
   if (bad) return BCE_HIP_OK;
   const double tcp2 = now_s();
@@ -1654,6 +1707,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   // to spare -- so the resident kernels always get the first kProbeRounds rounds.
   const bool host_has_ccx = std::thread::hardware_concurrency() >= 8u && !getenv("BCE_DEC_TAIL_SERIAL") && tail_cpus().size() == 8;
   uint64_t wide_hist[32] = {0}, wide_nodes[32] = {0}, small_rounds = 0;
+  double wide_time[32] = {0};
   constexpr uint64_t kDirectNodes = 1u << 18;
   const bool no_small = getenv("BCE_DEC_NO_SMALL") != nullptr;
   BCE_TRY(ensure(c, c->smwords, (size_t)DS_MAXTILES * 8));
@@ -1663,9 +1717,37 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   double t_wave = 0, t_wg = 0;
   BCE_TRY(ensure(c, c->runs, 64));
   uint32_t *d_rounds = c->runs.as<uint32_t>();
+  // Rounds of a few thousand nodes cost the GPU ~40 us each (two launches, two syncs) whatever they hold; eight host threads
+  // do 8192 nodes in about that time and 1024 in a tenth of it.  Where the host takes the tail anyway (a CCX for its
+  // threads) it takes it from here on, provided the tail is LONG -- at least 512 more rounds at the present width, and worth
+  // the copy of the ranks: text's few hundred tail rounds stay on the device.
+  BigPin big_pin;
+  uint32_t host_enter = 8192;
+  if (const char *e = getenv("BCE_DEC_HOST_ENTER")) host_enter = (uint32_t)strtoul(e, nullptr, 10);
   while (cur_nodes) {
     double t0 = now_s();
     a.par = round & 1u;
+    {
+      const uint64_t left = 8ull * (n - 1u) - nodes_total;
+      // past the half-way mark with 64 rounds' worth of the present width still to come: the widths of text fall
+      // geometrically from their peak (the ratio stays under ~50 until next to nothing is left), a long tail does not
+      if (host_tail_ok && host_has_ccx && !big_pin.running && left <= 4ull * (n - 1u) && left >= (n >> 6) + (1u << 18) &&
+          left >= 64ull * cur_nodes && !getenv("BCE_DEC_NO_EARLY_PIN"))
+        big_pin.start(c, 8 * ((size_t)n + 1) * 4);
+      if (host_tail_ok && host_has_ccx && !answered_pending && !getenv("BCE_DEC_NO_TAIL") && cur_nodes <= host_enter &&
+          left >= (n >> 6) + (1u << 18) && left >= 512ull * cur_nodes && left <= 8ull * (n - 1u) / 8u) {
+        bool bad = false;
+        const double th = now_s();
+        const uint32_t r0 = round;
+        big_pin.settle();
+        BCE_TRY(dec_host_tail(c, a, ctl, hd.dec, n, &round, &nodes_total, &queries_total, &bad));
+        if (bad) { snprintf(c->err, sizeof c->err, "decode: inconsistent archive (round %u)", round); return BCE_HIP_E_INTERNAL; }
+        if (timing) fprintf(stderr, "gpu decode: %u rounds of the tail on the host from %llu nodes a round on, %.3f s with the copies\n", round - r0, (unsigned long long)cur_nodes, now_s() - th);
+        t_c += now_s() - t0;
+        cur_nodes = 0;
+        break;
+      }
+    }
     if (cur_nodes <= DT_ENTER && !getenv("BCE_DEC_NO_TAIL")) {
       // Few nodes: the tail kernels run the forced rounds on the device; at a round with queries the workgroup kernel
       // emits them straight into pinned memory, the host answers (inline: they are few) and the kernel resumes with
@@ -1696,7 +1778,8 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
           bool bad = false;
           const double th = now_s();
           const uint32_t r0 = round;
-          BCE_TRY(dec_host_tail(c, a, ctl, hd.dec, n, &round, &nodes_total, &queries_total, &bad));
+          big_pin.settle();
+        BCE_TRY(dec_host_tail(c, a, ctl, hd.dec, n, &round, &nodes_total, &queries_total, &bad));
           if (bad) { snprintf(c->err, sizeof c->err, "decode: inconsistent archive (round %u)", round); return BCE_HIP_E_INTERNAL; }
           if (timing) fprintf(stderr, "gpu decode: %u rounds of the tail on the host, %.3f s with the copies\n", round - r0, now_s() - th);
           cur_nodes = 0;
@@ -1771,7 +1854,8 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
           bool bad = false;
           const double th = now_s();
           const uint32_t r0 = round;
-          BCE_TRY(dec_host_tail(c, a, ctl, hd.dec, n, &round, &nodes_total, &queries_total, &bad));
+          big_pin.settle();
+        BCE_TRY(dec_host_tail(c, a, ctl, hd.dec, n, &round, &nodes_total, &queries_total, &bad));
           if (bad) { snprintf(c->err, sizeof c->err, "decode: inconsistent archive (round %u)", round); return BCE_HIP_E_INTERNAL; }
           if (timing) fprintf(stderr, "gpu decode: %u rounds of the deep tail on the host, %.3f s with the copies\n", round - r0, now_s() - th);
           cur_nodes = 0;
@@ -1807,7 +1891,9 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
     }
     uint64_t want = (cur_nodes + K3_TILE - 1) / K3_TILE + 8;
     const uint32_t grid = (uint32_t)(want < 2048 ? want : 2048);
-    if (timing) { uint32_t b = 0; while ((2ull << b) <= cur_nodes && b < 31) ++b; wide_hist[b]++; wide_nodes[b] += cur_nodes; }
+    uint32_t hb = 0;
+    const double t_round0 = timing ? now_s() : 0.0;
+    if (timing) { while ((2ull << hb) <= cur_nodes && hb < 31) ++hb; wide_hist[hb]++; wide_nodes[hb] += cur_nodes; }
     const bool small = small_round;                                // one launch per pass (dec_small_kernel)
     a.round = round;
     if (small) {
@@ -1867,6 +1953,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
       return ctl.err == 2 ? BCE_HIP_E_OVERFLOW : BCE_HIP_E_INTERNAL;
     }
     t_c += now_s() - t0;
+    if (timing) wide_time[hb] += now_s() - t_round0;
     cur_nodes = ctl.next_nodes;
     nodes_total = ctl.nodes_total;
     if (c->progress) c->progress(nodes_total, 8ull * n, c->progress_user);
@@ -1878,7 +1965,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
 
   if (timing) {
     fprintf(stderr, "gpu decode: %llu rounds in two launches (dec_small_kernel); rounds outside the tail by node count:", (unsigned long long)small_rounds);
-    for (int b = 0; b < 32; ++b) if (wide_hist[b]) fprintf(stderr, " [2^%d) %llu rounds %.1f M nodes;", b, (unsigned long long)wide_hist[b], wide_nodes[b] * 1e-6);
+    for (int b = 0; b < 32; ++b) if (wide_hist[b]) fprintf(stderr, " [2^%d) %llu rounds %.1f M nodes %.3f s;", b, (unsigned long long)wide_hist[b], wide_nodes[b] * 1e-6, wide_time[b]);
     fprintf(stderr, "\n");
   }
   if (timing) fprintf(stderr, "gpu decode: tail kernels: wave %llu launches (%llu rounds, %llu nodes) %.3f s, workgroup %llu launches (%llu rounds, %llu nodes) %.3f s\n",
