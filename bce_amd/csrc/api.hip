@@ -251,6 +251,7 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->h_big) (void)hipHostFree(c->h_big);
+  for (void *q : c->dec_pin) if (q) (void)hipHostFree(q);
   if (c->h_runs) (void)hipHostFree(c->h_runs);
   if (c->h_truns) (void)hipHostFree(c->h_truns);
   if (c->coder) c->coder->drain();

@@ -129,6 +129,8 @@ struct bce_hip_ctx {
   void *h_small = nullptr;                       // 4 KB of pinned host memory for read_back()
   void *h_big = nullptr;                         // pinned host memory for the decoder's host tail (the boundary ranks: 32 (n + 1) bytes), grow-only
   size_t h_big_cap = 0;
+  void *dec_pin[3] = {nullptr, nullptr, nullptr};  // the decoder's pinned query / escape-record / answer buffers, kept from one decode to the next (grow-only)
+  size_t dec_pin_cap[3] = {0, 0, 0};
   bce::FlushSlot slot[3];                        // flushes in flight: GPU fills one while the coders drain the others
   int slot_next = 0;
 

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <memory>
@@ -79,6 +80,10 @@ struct DecArgs {
   uint32_t seq_base;         // number of the first query round of this launch (numbers never repeat within a decode)
   unsigned long long *words; // dec_small_kernel: one tagged count word per tile
   uint32_t round;            // ... and the round number the tags are made of
+  // Six-launch rounds taken in two parts (the busiest plane first, see decompress_device): the planes this launch works
+  // on, the order in which the planes' queries lie in Q (4 bits each, first plane lowest), whether this children pass is
+  // the round's last (it alone adds up the round)
+  uint32_t pmask = 0xFFu, order = 0x76543210u, final = 1u;
 };
 
 __device__ __forceinline__ Node *dec_nodes(const DecArgs &a, uint32_t par, uint32_t p) {
@@ -186,6 +191,7 @@ __global__ __launch_bounds__(K3_T) void dec_tiles_kernel(DecArgs a) {
     uint32_t p = 0;
 #pragma unroll
     for (int k = 1; k < 8; ++k) p += (tile >= tp[k]) ? 1u : 0u;
+    if (!((a.pmask >> p) & 1u)) continue;                        // (a whole tile: uniform over the block)
     const uint32_t ti = tile - tp[p];
     const uint32_t c0n = a.ctl->cnt[a.par][p][0], M = c0n + a.ctl->cnt[a.par][p][1];
     const Node *src = dec_nodes(a, a.par, p);
@@ -274,6 +280,7 @@ __global__ __launch_bounds__(1024) void dec_scan_kernel(DecArgs a) {
   __shared__ uint32_t s_last;
   DecCtl *ctl = a.ctl;
   const uint32_t tid = threadIdx.x, p = blockIdx.x;
+  if (!((a.pmask >> p) & 1u)) return;                            // (the whole block)
   if (tid == 0) dec_tile_prefix(a, tp);
   __syncthreads();
   uint32_t r0 = 0, r1 = 0;
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(1024) void dec_scan_kernel(DecArgs a) {
   if (tid == 0) {
     if (QUERY) { ctl->ptot[p][2] = r0; ctl->ptot[p][3] = r1; } else { ctl->ptot[p][0] = r0; ctl->ptot[p][1] = r1; }
     __threadfence();
-    s_last = atomicAdd(&ctl->ticket, 1u) == 7u ? 1u : 0u;
+    s_last = atomicAdd(&ctl->ticket, 1u) == (uint32_t)__popc(a.pmask) - 1u ? 1u : 0u;
   }
   __syncthreads();
   if (!s_last || tid != 0) return;
@@ -316,13 +323,16 @@ __global__ __launch_bounds__(1024) void dec_scan_kernel(DecArgs a) {
   for (int q = 0; q < 8; ++q) curn += (uint64_t)ctl->cnt[a.par][q][0] + ctl->cnt[a.par][q][1];
   if (QUERY) {
     uint32_t acc = 0, eacc = 0;
-    for (int q = 0; q < 8; ++q) {
-      ctl->qbase[q] = acc;
-      ctl->ebase[q] = eacc;
-      a.info->qbase[q] = acc;
-      a.info->qtot[q] = pt[q][2];
-      a.info->ebase[q] = eacc;
-      a.info->etot[q] = pt[q][3];
+    for (int i = 0; i < 8; ++i) {                                 // (planes of an earlier part of this round lie first: their totals stand)
+      const uint32_t q = (a.order >> (4 * i)) & 7u;
+      if ((a.pmask >> q) & 1u) {
+        ctl->qbase[q] = acc;
+        ctl->ebase[q] = eacc;
+        a.info->qbase[q] = acc;
+        a.info->qtot[q] = pt[q][2];
+        a.info->ebase[q] = eacc;
+        a.info->etot[q] = pt[q][3];
+      }
       acc += pt[q][2];
       eacc += pt[q][3];
     }
@@ -335,14 +345,18 @@ __global__ __launch_bounds__(1024) void dec_scan_kernel(DecArgs a) {
     bool ovf = false;
     for (uint32_t q = 0; q < 8; ++q) {
       const uint32_t qn = (q + 1u) & 7u;
-      ctl->cnt[a.par ^ 1u][qn][0] = pt[q][0];
-      ctl->cnt[a.par ^ 1u][qn][1] = pt[q][1];
+      if ((a.pmask >> q) & 1u) {
+        ctl->cnt[a.par ^ 1u][qn][0] = pt[q][0];
+        ctl->cnt[a.par ^ 1u][qn][1] = pt[q][1];
+        if ((uint64_t)pt[q][0] + pt[q][1] > a.capP) ovf = true;
+      }
       nextn += (uint64_t)pt[q][0] + pt[q][1];
-      if ((uint64_t)pt[q][0] + pt[q][1] > a.capP) ovf = true;
     }
     if (ovf && !ctl->err) ctl->err = 2;
-    ctl->nodes_total += curn;
-    ctl->next_nodes = (uint32_t)nextn;
+    if (a.final) {                                               // (every plane's totals are this round's by now)
+      ctl->nodes_total += curn;
+      ctl->next_nodes = (uint32_t)nextn;
+    }
   }
 }
 
@@ -1215,8 +1229,12 @@ struct QueryPool {
   std::thread th[8];
   std::mutex mu;
   std::condition_variable cv_go, cv_done;
-  uint64_t epoch = 0;
-  int pending = 0;
+  struct Job { const uint32_t *q; const uint4 *e; uint32_t *r; uint32_t cnt; };
+  double t_begin[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_end[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double busy[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // seconds each plane's thread has spent answering, and how many queries (BCE_DEC_TIMING)
+  uint64_t asked_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  Job job[8] = {};
+  uint64_t asked[8] = {0, 0, 0, 0, 0, 0, 0, 0}, answered[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool stop = false;
 
   static void answer(Decoder &d, const uint32_t *q, const uint4 *e, uint32_t *r, uint32_t cnt) {
@@ -1226,36 +1244,64 @@ struct QueryPool {
   void worker(int p) {
     uint64_t seen = 0;
     for (;;) {
+      Job j;
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv_go.wait(lk, [&] { return stop || epoch != seen; });
+        cv_go.wait(lk, [&] { return stop || asked[p] != seen; });
         if (stop) return;
-        seen = epoch;
+        seen = asked[p];
+        j = job[p];
       }
-      answer((*dec)[p], Q + info.qbase[p], E + info.ebase[p], res + info.qbase[p], info.qtot[p]);
+      const double ta = now_s();
+      answer((*dec)[p], j.q, j.e, j.r, j.cnt);
+      t_begin[p] = ta;
+      t_end[p] = now_s();
+      busy[p] += t_end[p] - ta;
+      asked_n[p] += j.cnt;
       {
         std::lock_guard<std::mutex> g(mu);
-        if (--pending == 0) cv_done.notify_all();
+        answered[p] = seen;
       }
+      cv_done.notify_all();
     }
   }
   void start() { for (int p = 0; p < 8; ++p) th[p] = std::thread([this, p] { worker(p); }); }
+  // the planes of `mask` start on jobs[p] (queries, escape records, where the answers go, how many)
+  void run_async(const Job jobs[8], uint32_t mask) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      for (int p = 0; p < 8; ++p)
+        if ((mask >> p) & 1u) { job[p] = jobs[p]; ++asked[p]; }
+    }
+    cv_go.notify_all();
+  }
+  void wait(uint32_t mask) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { for (int p = 0; p < 8; ++p) if (((mask >> p) & 1u) && answered[p] != asked[p]) return false; return true; });
+  }
+  uint32_t done_locked(uint32_t mask) const {
+    uint32_t fin = 0;
+    for (int p = 0; p < 8; ++p) if (((mask >> p) & 1u) && answered[p] == asked[p]) fin |= 1u << p;
+    return fin;
+  }
+  uint32_t done(uint32_t mask) { std::lock_guard<std::mutex> g(mu); return done_locked(mask); }      // which of `mask` have answered
+  uint32_t wait_any(uint32_t mask) {                                                                 // ... at least one of them (mask != 0)
+    std::unique_lock<std::mutex> lk(mu);
+    uint32_t fin = 0;
+    cv_done.wait(lk, [&] { fin = done_locked(mask); return fin != 0 || mask == 0; });
+    return fin;
+  }
   void run(const DecInfo &in) {
-    info = in;
     uint64_t total = 0;
     for (int p = 0; p < 8; ++p) total += in.qtot[p];
     if (total < 2048) {                                          // not worth waking anybody
       for (int p = 0; p < 8; ++p) answer((*dec)[p], Q + in.qbase[p], E + in.ebase[p], res + in.qbase[p], in.qtot[p]);
       return;
     }
-    {
-      std::lock_guard<std::mutex> g(mu);
-      pending = 8;
-      ++epoch;
-    }
-    cv_go.notify_all();
-    std::unique_lock<std::mutex> lk(mu);
-    cv_done.wait(lk, [&] { return pending == 0; });
+    Job jobs[8];
+    for (int p = 0; p < 8; ++p) jobs[p] = Job{Q + in.qbase[p], E + in.ebase[p], res + in.qbase[p], in.qtot[p]};
+    run_async(jobs, 0xFFu);
+    wait(0xFFu);
   }
   ~QueryPool() {
     { std::lock_guard<std::mutex> g(mu); stop = true; }
@@ -1267,17 +1313,26 @@ struct QueryPool {
 struct Pinned {
   void *p = nullptr;
   size_t cap = 0;
+  void **keep_p = nullptr;      // where the buffer lives on after this object (a slot of the context), if anywhere
+  size_t *keep_cap = nullptr;
+  Pinned() = default;
+  Pinned(void **kp, size_t *kc) : p(*kp), cap(*kc), keep_p(kp), keep_cap(kc) {}
+  Pinned(const Pinned &) = delete;
+  Pinned &operator=(const Pinned &) = delete;
   int ensure(bce_hip_ctx *c, size_t bytes) {
     if (bytes <= cap) return BCE_HIP_OK;
+    size_t want = 2 * cap > bytes ? 2 * cap : bytes;          // pinning is slow (~0.15 s per GB): grow geometrically
     if (p) (void)hipHostFree(p);
     p = nullptr; cap = 0;
-    size_t want = 2 * cap > bytes ? 2 * cap : bytes;          // pinning is slow: grow geometrically
     if (want < ((size_t)16 << 20)) want = (size_t)16 << 20;
     BCE_HIP_TRY(c, hipHostMalloc(&p, want, hipHostMallocCoherent | hipHostMallocMapped));   // the wave tail kernel reads answers written while it runs
     cap = want;
     return BCE_HIP_OK;
   }
-  ~Pinned() { if (p) (void)hipHostFree(p); }
+  ~Pinned() {
+    if (keep_p) { *keep_p = p; *keep_cap = cap; }
+    else if (p) (void)hipHostFree(p);
+  }
 };
 
 struct Mailbox {               // a few host-coherent words the wave tail kernel and the host exchange while the kernel runs
@@ -1650,7 +1705,18 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   }
   BCE_HIP_TRY(c, hipMemcpyAsync(c->ctl.p, &ctl, sizeof ctl, hipMemcpyHostToDevice, c->stream));
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  Pinned pin_info, pin_q, pin_e, pin_res;
+  // (query, escape-record and answer buffers stay with the context: pinning their ~150 MB anew was 0.05 s of every decode)
+  Pinned pin_info, pin_q(&c->dec_pin[0], &c->dec_pin_cap[0]), pin_e(&c->dec_pin[1], &c->dec_pin_cap[1]), pin_res(&c->dec_pin[2], &c->dec_pin_cap[2]);
+  struct Events {
+    hipEvent_t e[8] = {};
+    ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+  } ev;
+  uint32_t prev_qtot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t split_rounds = 0;
+  double dbg_r[5] = {0, 0, 0, 0, 0};
+  uint32_t dbg_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double t_split = 0, ts_issue = 0, ts_first = 0, ts_lanes = 0, ts_wait = 0, ts_rb = 0;
+  const bool no_split = getenv("BCE_DEC_NO_SPLIT") != nullptr;
   BCE_TRY(pin_info.ensure(c, sizeof(DecInfo)));
   DecInfo *info = static_cast<DecInfo *>(pin_info.p);
   memset(info, 0, sizeof *info);
@@ -1896,6 +1962,125 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
     if (timing) { while ((2ull << hb) <= cur_nodes && hb < 31) ++hb; wide_hist[hb]++; wide_nodes[hb] += cur_nodes; }
     const bool small = small_round;                                // one launch per pass (dec_small_kernel)
     a.round = round;
+    if (!small && !answered_pending && !no_split) {
+      // A six-launch round plane by plane.  The round's time is the busiest planes' sequential decoders (text: planes 0
+      // and 1 hold half of all queries) with the query passes in front of them and the children passes behind.  The planes
+      // of a round do not meet (plane p's children are plane p + 1's nodes of the NEXT round), so each plane is a lane of
+      // its own -- query pass, copy out, decoder, answers in, children pass -- and the lanes start in the order of their
+      // node counts: the busiest decoder starts as soon as ITS queries are out and only its own children pass is
+      // left when it is done; everything else runs beside it.
+      const double ts0 = now_s();
+      for (int i = 0; i < 8; ++i) if (!ev.e[i]) BCE_HIP_TRY(c, hipEventCreateWithFlags(&ev.e[i], hipEventDisableTiming));
+      uint32_t ord[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+      // (the bulk of the queries moves from plane p to plane p + 1 with every round -- a node's children are the next plane's
+      //  nodes -- and the busiest decoder with it: plane p is as busy as plane p - 1 was last round.  Node counts say less:
+      //  how many of a plane's nodes are forced differs from plane to plane.)
+      uint64_t weight[8];
+      for (int q = 0; q < 8; ++q) weight[q] = ((uint64_t)prev_qtot[(q + 7) & 7] << 1) + ((ctl.cnt[round & 1u][q][0] + ctl.cnt[round & 1u][q][1]) ? 1u : 0u);
+      std::stable_sort(ord, ord + 8, [&](uint32_t x, uint32_t y) { return weight[x] > weight[y]; });
+      uint32_t order = 0;
+      for (int i = 0; i < 8; ++i) order |= ord[i] << (4 * i);
+      BCE_TRY(pin_q.ensure(c, (size_t)(cur_nodes + 16) * 4));      // (a plane's queries lie at its base: the bases are exact, the size is a bound)
+      BCE_TRY(pin_res.ensure(c, (size_t)(cur_nodes + 16) * 4));
+      a.order = order;
+      a.final = 0;
+      auto ask = [&](int i) -> int {                               // the query pass of lane i
+        a.pmask = 1u << ord[i];
+        a.final = 0;
+        hipLaunchKernelGGL((dec_tiles_kernel<0>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+        hipLaunchKernelGGL((dec_scan_kernel<true>), dim3(8), dim3(1024), 0, c->stream, a);
+        hipLaunchKernelGGL((dec_tiles_kernel<1>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+        BCE_HIP_TRY(c, hipEventRecord(ev.e[i], c->stream));
+        return BCE_HIP_OK;
+      };
+      BCE_TRY(ask(0));                                             // (launching costs the host ~60 us a lane: the busiest decoder does not wait for all eight)
+      BCE_TRY(ask(1));
+      const double tsa = now_s();
+      ts_issue += tsa - ts0;
+      QueryPool::Job jobs[8] = {};
+      struct Settle {                                              // no decoder outlives this round (its buffers, an early return)
+        QueryPool &pool; uint32_t mask;
+        ~Settle() { if (mask) pool.wait(mask); }
+      } settle{pool, 0u};
+      uint64_t qtotal = 0;
+      uint32_t new_qtot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      uint32_t launched = 0, children_done = 0;                    // planes whose decoders run / whose children pass is queued
+      auto children = [&](uint32_t p, bool last) -> int {
+        if (jobs[p].cnt) BCE_HIP_TRY(c, hipMemcpyAsync(Rsbuf.as<uint32_t>() + (jobs[p].r - static_cast<uint32_t *>(pin_res.p)), jobs[p].r, (size_t)jobs[p].cnt * 4, hipMemcpyHostToDevice, c->stream));
+        a.pmask = 1u << p;
+        a.final = last ? 1u : 0u;
+        hipLaunchKernelGGL((dec_tiles_kernel<2>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+        hipLaunchKernelGGL((dec_scan_kernel<false>), dim3(8), dim3(1024), 0, c->stream, a);
+        hipLaunchKernelGGL((dec_tiles_kernel<3>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+        children_done |= 1u << p;
+        return BCE_HIP_OK;
+      };
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t p = ord[i];
+        if (i > 0 && i + 1 < 8) BCE_TRY(ask(i + 1));               // one lane ahead of the one being waited for
+        BCE_HIP_TRY(c, hipEventSynchronize(ev.e[i]));
+        if (i == 0) ts_first += now_s() - tsa;
+        const DecInfo in = *info;                                  // (plane p's fields and those of the planes before it; the rest are being written)
+        if (in.err) { snprintf(c->err, sizeof c->err, "decode: inconsistent archive (round %u)", round); return BCE_HIP_E_INTERNAL; }
+        const uint32_t qn = in.qtot[p], en = in.etot[p], qb = in.qbase[p], eb = in.ebase[p];
+        new_qtot[p] = qn;
+        qtotal += qn;
+        if ((size_t)eb + en + 1 > pin_e.cap / sizeof(uint4)) {     // escape records are few, their number is not known ahead: grow between decoders
+          if (settle.mask) { pool.wait(settle.mask); }
+          BCE_TRY(pin_e.ensure(c, 2 * ((size_t)eb + en + 1) * sizeof(uint4)));
+        }
+        if (qn) {
+          BCE_HIP_TRY(c, hipMemcpyAsync(static_cast<uint32_t *>(pin_q.p) + qb, a.Q + qb, (size_t)qn * 4, hipMemcpyDeviceToHost, c->copy_stream));
+          if (en) BCE_HIP_TRY(c, hipMemcpyAsync(static_cast<uint4 *>(pin_e.p) + eb, a.E + eb, (size_t)en * sizeof(uint4), hipMemcpyDeviceToHost, c->copy_stream));
+          BCE_HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+          jobs[p] = QueryPool::Job{static_cast<const uint32_t *>(pin_q.p) + qb, static_cast<const uint4 *>(pin_e.p) + eb, static_cast<uint32_t *>(pin_res.p) + qb, qn};
+          pool.run_async(jobs, 1u << p);
+          settle.mask |= 1u << p;
+          launched |= 1u << p;
+        } else {
+          jobs[p] = QueryPool::Job{nullptr, nullptr, static_cast<uint32_t *>(pin_res.p) + qb, 0u};
+          BCE_TRY(children(p, i == 7 && (launched & ~children_done) == 0u));   // nothing to ask: its children pass at once (the round's last one only if nobody is out)
+        }
+        // decoders that have finished meanwhile: their children passes go out between the copies
+        const uint32_t fin = pool.done(launched & ~children_done);
+        for (uint32_t q = 0; q < 8; ++q)
+          if ((fin >> q) & 1u) { settle.mask &= ~(1u << q); BCE_TRY(children(q, i == 7 && (children_done | (1u << q)) == 0xFFu)); }
+      }
+      const double tsb = now_s();
+      ts_lanes += tsb - tsa;
+      while (children_done != 0xFFu) {
+        const uint32_t fin = pool.wait_any(launched & ~children_done);
+        for (uint32_t q = 0; q < 8; ++q)
+          if ((fin >> q) & 1u) { settle.mask &= ~(1u << q); BCE_TRY(children(q, (children_done | (1u << q)) == 0xFFu)); }
+      }
+      a.pmask = 0xFFu; a.order = 0x76543210u; a.final = 1u;
+      const double tsc = now_s();
+      if (timing) {
+        double last = 0; int lastp = -1;
+        for (int q = 0; q < 8; ++q) if (((launched >> q) & 1u) && pool.t_end[q] > last) { last = pool.t_end[q]; lastp = q; }
+        if ((launched >> ord[0]) & 1u) { dbg_r[0] += pool.t_begin[ord[0]] - ts0; dbg_r[1] += pool.t_end[ord[0]] - ts0; }
+        if (lastp >= 0) { dbg_r[2] += last - ts0; dbg_r[3] += pool.t_begin[lastp] - ts0; dbg_last[lastp]++; }
+        dbg_r[4] += tsc - ts0;
+      }
+      ts_wait += tsc - tsb;
+      BCE_TRY(read_back(c, &ctl, c->ctl.p, sizeof ctl));
+      ts_rb += now_s() - tsc;
+      BCE_HIP_TRY(c, hipGetLastError());
+      if (ctl.err) {
+        snprintf(c->err, sizeof c->err, ctl.err == 2 ? "decode: node list overflow (capP=%u)" : "decode: inconsistent archive (round %u)", ctl.err == 2 ? c->capP : round);
+        return ctl.err == 2 ? BCE_HIP_E_OVERFLOW : BCE_HIP_E_INTERNAL;
+      }
+      for (int q = 0; q < 8; ++q) prev_qtot[q] = new_qtot[q];
+      ++split_rounds;
+      t_split += now_s() - ts0;
+      if (timing) wide_time[hb] += now_s() - t_round0;
+      cur_nodes = ctl.next_nodes;
+      nodes_total = ctl.nodes_total;
+      if (c->progress) c->progress(nodes_total, 8ull * n, c->progress_user);
+      queries_total += qtotal;
+      ++round;
+      continue;
+    }
     if (small) {
       hipLaunchKernelGGL((dec_small_kernel<true>), dim3(grid), dim3(K3_T), 0, c->stream, a);
       ++small_rounds;
@@ -1910,7 +2095,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
     { const double t1 = now_s(); t_q += t1 - t0; t0 = t1; }
     if (in.err) { snprintf(c->err, sizeof c->err, "decode: inconsistent archive (round %u)", round); return BCE_HIP_E_INTERNAL; }
     uint64_t qtotal = 0, etotal = 0;
-    for (int p = 0; p < 8; ++p) { qtotal += in.qtot[p]; etotal += in.etot[p]; }
+    for (int p = 0; p < 8; ++p) { qtotal += in.qtot[p]; etotal += in.etot[p]; prev_qtot[p] = in.qtot[p]; }
     if (qtotal && answered_pending) {
       // the tail kernel emitted exactly these queries (same order) and the decoders answered them: do not ask twice
       BCE_HIP_TRY(c, hipMemcpyAsync(Rsbuf.p, pin_res.p, qtotal * 4, hipMemcpyHostToDevice, c->stream));
@@ -1963,6 +2148,15 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   if (timing) { fprintf(stderr, "gpu decode: %u rounds (%llu of them in the tail kernels, %llu query rounds answered through the mailbox), %llu nodes, %llu queries: %.3f s (query pass %.3f, copy out %.3f, host decoders %.3f, children pass %.3f)\n",
                         round, (unsigned long long)tail_rounds, (unsigned long long)mbox_rounds, (unsigned long long)nodes_total, (unsigned long long)queries_total, now_s() - tp0, t_q, t_copy, t_host, t_c); tp0 = now_s(); }
 
+  if (timing) fprintf(stderr, "gpu decode: %llu six-launch rounds plane by plane (busiest first): %.3f s (launching the query passes %.3f, the first plane's %.3f, all lanes started after %.3f, waiting for decoders %.3f, last children pass %.3f)\n",
+                      (unsigned long long)split_rounds, t_split, ts_issue, ts_first, ts_lanes, ts_wait, ts_rb);
+  if (timing) {
+    fprintf(stderr, "gpu decode: decoder threads (answers through the pool only):");
+    for (int p = 0; p < 8; ++p) fprintf(stderr, " plane %d %.1f M in %.3f s (%.1f ns);", p, pool.asked_n[p] * 1e-6, pool.busy[p], pool.asked_n[p] ? pool.busy[p] * 1e9 / pool.asked_n[p] : 0.0);
+    fprintf(stderr, "\n");
+  }
+  if (timing) fprintf(stderr, "gpu decode: lanes: busiest plane's decoder began %.3f, ended %.3f; the last decoder began %.3f, ended %.3f; all children passes queued %.3f (sums over the rounds, from the round's start); last to end: %u %u %u %u %u %u %u %u\n",
+                      dbg_r[0], dbg_r[1], dbg_r[3], dbg_r[2], dbg_r[4], dbg_last[0], dbg_last[1], dbg_last[2], dbg_last[3], dbg_last[4], dbg_last[5], dbg_last[6], dbg_last[7]);
   if (timing) {
     fprintf(stderr, "gpu decode: %llu rounds in two launches (dec_small_kernel); rounds outside the tail by node count:", (unsigned long long)small_rounds);
     for (int b = 0; b < 32; ++b) if (wide_hist[b]) fprintf(stderr, " [2^%d) %llu rounds %.1f M nodes %.3f s;", b, (unsigned long long)wide_hist[b], wide_nodes[b] * 1e-6, wide_time[b]);
