@@ -113,3 +113,42 @@ def test_deep_tail_finishes_on_the_host(monkeypatch):
     t0 = time.time()
     assert bce_amd.decompress_device(arch) == data
     print("deep tail: %.2f s with the host tail, %.2f s without" % (dt, time.time() - t0))
+
+
+def _with_long_tail(n_text, seed):
+    """Text with big duplicated stretches: wide (six-launch) rounds first, then a tail of tens of thousands of rounds."""
+    t = np.frombuffer(bytes(bce_amd.synth_text(seed, n_text)), dtype=np.uint8)
+    parts = [t, t[n_text // 5:n_text // 5 + 300000], np.zeros(120000, dtype=np.uint8), t[n_text // 2:n_text // 2 + 200000], t[:77777]]
+    return np.concatenate(parts)
+
+
+def test_decoder_paths_of_round_three_agree(monkeypatch):
+    """The switches added in round 3 change the route, never the bytes: six-launch rounds plane by plane or all planes at
+    once (BCE_DEC_NO_SPLIT), the long tail taken over by the host at 8192 nodes a round, after the probe (0) or much
+    earlier, its pinned buffer allocated beside the rounds or when the tail begins, the host tail on one thread.
+    The input is large enough for rounds of > 2 M nodes (six launches) and has a tail long enough for the host."""
+    data = _with_long_tail(40 << 20, 41)
+    arch = bce_amd.compress(data)
+    ref = bce_amd.decompress_device(arch)
+    assert ref == data.tobytes()
+    for env in ({"BCE_DEC_NO_SPLIT": "1"}, {"BCE_DEC_HOST_ENTER": "0"}, {"BCE_DEC_HOST_ENTER": "200000"}, {"BCE_DEC_NO_EARLY_PIN": "1"},
+                {"BCE_DEC_TAIL_SERIAL": "1"}, {"BCE_DEC_NO_SMALL": "1", "BCE_DEC_NO_SPLIT": "1"}, {"BCE_DEC_NO_SMALL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        assert bce_amd.decompress_device(arch) == ref, env
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+def test_one_context_decodes_wide_then_small_then_wide():
+    """The decoder's pinned query buffers stay with the context and only grow: a small archive after a large one (and
+    the large one again) must not see stale sizes or contents."""
+    big = np.frombuffer(bytes(bce_amd.synth_text(5, 9 << 20)), dtype=np.uint8)
+    small = np.frombuffer(bytes(bce_amd.synth_rand(6, 70000)), dtype=np.uint8)
+    a_big, a_small = bce_amd.compress(big), bce_amd.compress(small)
+    ctx = bce_amd.api._Ctx(0)
+    try:
+        for arch, want in ((a_big, big), (a_small, small), (a_big, big), (a_small, small)):
+            assert bce_amd.decompress_device(arch, ctx=ctx) == want.tobytes()
+    finally:
+        ctx.close()
