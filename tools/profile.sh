@@ -46,3 +46,20 @@ timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
   python3 "$ROOT/bench.py" $P --size 1000000000 > "$OUT/write_1e9.log" 2>&1
 python3 "$ROOT/tools/pmc_summary.py" "$OUT" "$TAG" _1e9
 rm -rf "$OUT/fetch_1e9" "$OUT/write_1e9"
+# the GPU-assisted decoder on the three 10^8-byte workloads: 3 decodes of one archive each (kernel statistics only)
+python3 - <<PY
+import sys
+sys.path.insert(0, "$ROOT")
+sys.path.insert(0, "$ROOT/tools")
+import bce_amd
+from scan_time import load
+for kind in ("text", "natural", "binary"):
+    open("/tmp/bce_prof_%s.bce" % kind, "wb").write(bce_amd.compress(load(kind)))
+PY
+for kind in text natural binary; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/dec_$kind" -o run -- \
+    python3 "$ROOT/tools/decode_archive_timing.py" /tmp/bce_prof_$kind.bce 3 > "$OUT/decode_$kind.log" 2>&1
+  find "$OUT/dec_$kind" -name "*kernel_stats.csv" -exec cp {} "$OUT/${TAG}_kernel_stats_decode_${kind}_1e8.csv" \;
+  rm -rf "$OUT/dec_$kind"
+  echo "decode $kind done"
+done
