@@ -117,13 +117,32 @@ def main():
         cap = int(rs.choice([0, 0, 0, 700, 20000]))
         arch = bce_amd.BCE(symbol_capacity=cap).encode(rf)
         ref = oracle.compress(raw)
-        ok = arch == ref and bce_amd.decompress_device(ref, ctx=ctx) == raw
+        # round 3: the decoder's routes (environment variables, read at every decode): six launches per round everywhere
+        # (which makes every round one of eight lanes, plane by plane) or all planes at once, where the host takes the tail
+        denv = {}
+        if rs.randint(0, 2) == 0:
+            if rs.randint(0, 2):
+                denv["BCE_DEC_NO_SMALL"] = "1"
+            if rs.randint(0, 3) == 0:
+                denv["BCE_DEC_NO_SPLIT"] = "1"
+            if rs.randint(0, 2) == 0:
+                denv["BCE_DEC_HOST_ENTER"] = str(int(rs.choice([0, 64, 3000, 100000])))
+            if rs.randint(0, 4) == 0:
+                denv["BCE_DEC_FORCE_HOST_TAIL"] = "1"
+            if rs.randint(0, 4) == 0:
+                denv["BCE_DEC_NO_EARLY_PIN"] = "1"
+        os.environ.update(denv)
+        try:
+            ok = arch == ref and bce_amd.decompress_device(ref, ctx=ctx) == raw
+        finally:
+            for k in denv:
+                del os.environ[k]
         cases += 1
         if not ok:
             fails += 1
             name = "/tmp/stress_fail_%d_%d.bin" % (a.seed, cases)
             open(name, "wb").write(raw)
-            print("FAIL case %d n=%d knobs=%r cap=%d saved %s" % (cases, len(raw), knobs, cap, name), flush=True)
+            print("FAIL case %d n=%d knobs=%r decoder env=%r cap=%d saved %s" % (cases, len(raw), knobs, denv, cap, name), flush=True)
         if cases % 200 == 0:
             print("%d cases, %d failures, %.0f s left" % (cases, fails, t_end - time.time()), flush=True)
     ctx.close()
