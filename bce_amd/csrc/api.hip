@@ -546,6 +546,25 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
   uint32_t kDfsEnter[2] = {c->dbg_no_local ? 65536u : (1u << 20), 2048u};
   if (const char *e = getenv("BCE_HIP_DFS_ENTER")) kDfsEnter[0] = (uint32_t)strtoul(e, nullptr, 10);
   int dfs_try = 0;
+  // A round that finds the symbol buffer too small is a round thrown away: its count kernel has run in full, the rest of
+  // the batch's launches return at once (8 launches of ~5 us) and the round runs again after the flush -- ~90 us per
+  // flush, 1.2 ms of the 13 ms of text.  The host knows how many symbols the last rounds emitted and how much room is
+  // left, so it flushes BEFORE a round that is unlikely to fit and never queues more rounds than the room allows
+  // (an estimate: a round that does not fit after all still takes the old way).
+  uint64_t est_syms = 0;                           // symbols of a coming round, from the last rounds (0: unknown)
+  uint64_t recent_syms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t recent_at = 0;
+  static const bool no_predict = getenv("BCE_HIP_NO_FLUSH_PREDICT") != nullptr;
+  auto rounds_that_fit = [&](uint32_t batch) -> uint32_t {  // 0: flush first
+    if (no_predict || !have_ctl || !est_syms || ctl.need_flush) return batch;
+    const uint64_t room = c->sym_cap > ctl.sym_total ? c->sym_cap - ctl.sym_total : 0;
+    uint64_t need = decaying ? est_syms + (est_syms >> 4) + 1024 : 2 * est_syms + 1024;   // (ramp-up: a round emits twice the last one's)
+    uint64_t acc = 0;
+    uint32_t fit = 0;
+    while (fit < batch && acc + need <= room) { acc += need; if (!decaying) need *= 2; ++fit; }
+    if (!fit && !ctl.sym_total) return batch;              // (an empty buffer that is still too small grows the old way)
+    return fit;
+  };
   for (;;) {
     if (have_ctl && decaying && !ctl.need_flush && ctl.done_round == 0xFFFFFFFFu) {
       // few live nodes and almost everything visited: finish depth-first (k3_dfs.hip).  The walkers' symbols
@@ -570,6 +589,7 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
       }
     }
     const uint32_t first = c->round;
+    bool runs_fetched = false;
     uint32_t executed = 0;
     RoctxRange range("bce K3 rounds");
     BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -597,11 +617,17 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
           batch = b ? b : 1u;
         }
       }
+      {
+        const uint32_t fit = rounds_that_fit(batch);
+        if (!fit) { BCE_TRY(sink(ctl.sym_total)); ctl.sym_total = 0; continue; }
+        batch = fit;
+      }
       BCE_TRY(k3_rounds_small(c, batch, cur_nodes, !decaying));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
       BCE_TRY(k3_sync_ctl(c, &ctl));
       executed = (ctl.need_flush || ctl.small_bail) ? ctl.skip_round - first : batch;
       BCE_TRY(k3_fetch_runs(c, first, executed));
+      runs_fetched = true;
       if (ctl.small_bail) { BCE_TRY(k3_clear_small_bail(c)); wide_once = true; }
     } else {
       // wide rounds: sync often (the round dominates); medium rounds: queue many per sync
@@ -616,16 +642,36 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
         while (b < batch && est < want) { est += nn; nn *= 2; ++b; }
         batch = b ? b : 1u;
       }
+      {
+        const uint32_t fit = rounds_that_fit(batch);
+        if (!fit) { BCE_TRY(sink(ctl.sym_total)); ctl.sym_total = 0; continue; }
+        batch = fit;
+      }
       BCE_TRY(k3_rounds(c, batch, decaying ? cur_nodes : 0));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
       BCE_TRY(k3_sync_ctl(c, &ctl));
       executed = ctl.need_flush ? ctl.skip_round - first : batch;
       BCE_TRY(k3_fetch_runs(c, first, executed));
+      runs_fetched = true;
     }
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms; }
     if (ctl.stalled) { snprintf(c->err, sizeof c->err, "k3: a single-launch round waited too long for a predecessor tile (dispatch order not as assumed)"); return BCE_HIP_E_INTERNAL; }
     if (ctl.overflow) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
     c->round = first + executed;
+    if (executed && runs_fetched) {
+      // what the last eight rounds emitted, each (h_runs holds this batch's run table: one entry per round and plane): the
+      // bulk of the nodes moves from plane to plane with a period of eight rounds, and the symbols per round swing with
+      // it -- the largest of a period is what the next round may bring.  Ramp-up: the last round alone (the next doubles).
+      const RunEntry *re = reinterpret_cast<const RunEntry *>(c->h_runs);
+      for (uint32_t i = 0; i < executed; ++i) {
+        uint64_t t = 0;
+        for (int p = 0; p < 8; ++p) t += re[(size_t)i * 8 + p].count;
+        recent_syms[recent_at++ & 7u] = t;
+      }
+      est_syms = 0;
+      if (decaying) { for (uint64_t v : recent_syms) est_syms = v > est_syms ? v : est_syms; }
+      else est_syms = recent_syms[(recent_at - 1u) & 7u];
+    }
     if (c->progress) c->progress(ctl.nodes_total, 8ull * n, c->progress_user);
     decaying = ctl.next_nodes <= cur_nodes && c->round > 16;   // past the ramp-up: the node count no longer doubles
     if (c->dbg_tail_round && c->round >= c->dbg_tail_round) decaying = true;   // test knob 10: the tail starts while the count still grows
@@ -641,6 +687,7 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
         continue;
       }
       BCE_TRY(sink(ctl.sym_total));
+      ctl.sym_total = 0;                         // (the host copy: what the next batch starts from)
       continue;
     }
     if (done) {
