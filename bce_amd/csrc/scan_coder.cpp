@@ -264,7 +264,7 @@ double scan_add_repeated(double z, double c, uint64_t m) {
 }
 
 double ScanCoder::finish(uint8_t init[9][32], const double base[32], const double trial[32][6]) {
-  z_ = scan_add_repeated(z_, std::log(2), nesc_);            // the escapes of set_packed, `z_ += log(2)` each (:739), in order
+  z_ = scan_add_repeated(z_, std::log(2), nesc_);            // the escapes (set() / ScanSet::consume), `z_ += log(2)` each (:739), in order
   nesc_ = 0;
   for (uint32_t k = 2; k < 31u; ++k) {                       // k = 31 is never optimised (:754)
     double z_min = base[k];

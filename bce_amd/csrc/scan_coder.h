@@ -2,15 +2,17 @@
 // picks, per plane and per range size k, the number of context bits that minimises the simulated adaptive cost.
 // Host C++ (SURVEY section 8f "next #2"): the enumeration that feeds it runs on the GPU (K1-K3 in scan mode),
 // the optimisation itself is a host computation.  The result must equal the reference's byte for byte,
-// which pins two implementation details: the symbols are kept in a
-// std::unordered_map<uint32_t, std::vector<uint8_t>> filled in stream order (its iteration order decides the
-// order of the double additions) and the cost is accumulated in double with log().
+// which pins two implementation details: the reference keeps the symbols in a
+// std::unordered_map<uint32_t, std::vector<uint8_t>> filled in stream order -- the map's ITERATION order decides the
+// order of the double additions -- and accumulates the cost in double with log().
 //
-// What is NOT pinned is who does the work.  In the reference's flush every (k, j) pair owns its accumulator z and
-// its counter table, and only `z_ += z_min` is ordered over k (bce.cpp:754-796); stat_[k] of different k (and of
-// different coders) never meet.  So recording is split by (coder, class of k) and the optimisation by (coder, k, j)
-// over a pool of host threads (ScanSet below), every map keeping its insertion sequence and every sum its order:
-// the same bytes as the sequential reference, ~10 s -> ~1 s per 10^8 input bytes.
+// What is NOT pinned is how the symbols are stored and who does the work.  In the reference's flush every (k, j) pair
+// owns its accumulator z and its counter table, and only `z_ += z_min` is ordered over k (bce.cpp:754-796); stat_[k]
+// of different k (and of different coders) never meet.  Here the map is kept without its vectors (same keys, same
+// insertion sequence, hence the same iteration order) and the symbols go to one append-only stream per (coder, k);
+// recording is split over ranges of a plane's records, the optimisation over (coder, k), on a pool of host threads
+// (ScanSet below); every map keeps its insertion sequence and every sum its order: the same bytes as the sequential
+// reference, ~10 s -> 0.3-0.5 s per 10^8 input bytes.
 #pragma once
 #include <stdint.h>
 
