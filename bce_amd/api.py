@@ -392,18 +392,27 @@ def decompress(archive) -> bytes:
     return out.tobytes()
 
 
-def decompress_device(archive, device=0, ctx=None) -> bytes:
-    """`bce -d` with the GPU doing everything but the eight sequential range decoders (kd_decode.hip)."""
+def decompress_device(archive, device=0, ctx=None, out=None):
+    """`bce -d` with the GPU doing everything but the eight sequential range decoders (kd_decode.hip) -> bytes.
+
+    With `out` (a writable C-contiguous uint8 array at least as large as the original) the bytes are written there, as a
+    caller of the C ABI would have them, and the number of bytes is returned: no allocation and no copy on this side."""
     own = ctx is None
     c = ctx or _Ctx(device)
     try:
         a = _as_u8(archive)
         n = C.c_size_t()
+        if out is not None:
+            if out.dtype != np.uint8 or not out.flags.c_contiguous or not out.flags.writeable:
+                raise ValueError("out must be a writable C-contiguous uint8 array")
+            c.check(c.lib.bce_hip_decompress_device(c.h, a.ctypes.data, len(a), out.ctypes.data, out.size, C.byref(n)),
+                    "bce_hip_decompress_device")
+            return n.value
         c.check(c.lib.bce_hip_decompress_device(c.h, a.ctypes.data, len(a), None, 0, C.byref(n)), "bce_hip_decompress_device")
-        out = np.empty(n.value, dtype=np.uint8)
-        c.check(c.lib.bce_hip_decompress_device(c.h, a.ctypes.data, len(a), out.ctypes.data, n.value, C.byref(n)),
+        buf = np.empty(n.value, dtype=np.uint8)
+        c.check(c.lib.bce_hip_decompress_device(c.h, a.ctypes.data, len(a), buf.ctypes.data, n.value, C.byref(n)),
                 "bce_hip_decompress_device")
-        return out.tobytes()
+        return buf.tobytes()
     finally:
         if own:
             c.close()

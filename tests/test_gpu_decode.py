@@ -152,3 +152,16 @@ def test_one_context_decodes_wide_then_small_then_wide():
             assert bce_amd.decompress_device(arch, ctx=ctx) == want.tobytes()
     finally:
         ctx.close()
+
+
+def test_decode_into_a_callers_buffer():
+    """decompress_device(out=...) is the C ABI's own shape: the bytes land in the caller's array, the length comes back."""
+    data = np.frombuffer(bytes(bce_amd.synth_text(3, 300000)), dtype=np.uint8)
+    arch = bce_amd.compress(data)
+    buf = np.full(len(data) + 100, 0xEE, dtype=np.uint8)
+    assert bce_amd.decompress_device(arch, out=buf) == len(data)
+    assert np.array_equal(buf[:len(data)], data) and (buf[len(data):] == 0xEE).all()
+    with pytest.raises(bce_amd.BceError):
+        bce_amd.decompress_device(arch, out=np.zeros(len(data) - 1, dtype=np.uint8))      # too small: refused, nothing written past it
+    with pytest.raises(ValueError):
+        bce_amd.decompress_device(arch, out=np.zeros(len(data), dtype=np.uint16))
