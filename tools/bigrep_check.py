@@ -1,5 +1,6 @@
-import sys, time, hashlib
-sys.path.insert(0, '.')
+"""A whole-file duplicate (4 MiB twice: 33 M rounds): encode vs the oracle, host-decoder round trip.   python tools/bigrep_check.py"""
+import os, sys, time, hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bce_amd, oracle
 half = bce_amd.synth_text(5, 4 << 20)
 data = np.concatenate([half, half, np.frombuffer(b'#', dtype=np.uint8)])
