@@ -1179,6 +1179,7 @@ int kd_inverse_bw_transform(bce_hip_ctx *c, const uint8_t *T_host, uint8_t *U_ho
   hipLaunchKernelGGL(lf_scatter_kernel, dim3(gn), dim3(256), 0, c->stream, val[res], m_rows, lf);
   uint32_t sh = 0;
   while (((uint64_t)m_rows >> sh) > (1u << 19)) ++sh;          // at most 2^19 walkers
+  while (sh < 8 && ((uint64_t)m_rows >> (sh + 1)) >= 4096) ++sh;   // ... of at least 256 rows each while a few thousand are left (see decompress_device)
   const uint32_t m = (uint32_t)((((uint64_t)m_rows - 1) >> sh) + 1);
   BCE_TRY(ensure(c, c->key[0], (size_t)3 * m * 4 + 16 > b4 ? (size_t)3 * m * 4 + 16 : b4));
   uint32_t *d_len = c->key[0].as<uint32_t>(), *d_end = d_len + m, *d_dest = d_len + 2 * (size_t)m;
@@ -1319,12 +1320,12 @@ struct Pinned {
   Pinned(void **kp, size_t *kc) : p(*kp), cap(*kc), keep_p(kp), keep_cap(kc) {}
   Pinned(const Pinned &) = delete;
   Pinned &operator=(const Pinned &) = delete;
-  int ensure(bce_hip_ctx *c, size_t bytes) {
+  int ensure(bce_hip_ctx *c, size_t bytes, size_t least = (size_t)16 << 20) {
     if (bytes <= cap) return BCE_HIP_OK;
     size_t want = 2 * cap > bytes ? 2 * cap : bytes;          // pinning is slow (~0.15 s per GB): grow geometrically
     if (p) (void)hipHostFree(p);
     p = nullptr; cap = 0;
-    if (want < ((size_t)16 << 20)) want = (size_t)16 << 20;
+    if (want < least) want = least;
     BCE_HIP_TRY(c, hipHostMalloc(&p, want, hipHostMallocCoherent | hipHostMallocMapped));   // the wave tail kernel reads answers written while it runs
     cap = want;
     return BCE_HIP_OK;
@@ -1717,7 +1718,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   uint32_t dbg_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double t_split = 0, ts_issue = 0, ts_first = 0, ts_lanes = 0, ts_wait = 0, ts_rb = 0;
   const bool no_split = getenv("BCE_DEC_NO_SPLIT") != nullptr;
-  BCE_TRY(pin_info.ensure(c, sizeof(DecInfo)));
+  BCE_TRY(pin_info.ensure(c, sizeof(DecInfo), 4096));          // (a few words: not the 16 MB the query buffers start with -- 4 ms of pinning per decode)
   DecInfo *info = static_cast<DecInfo *>(pin_info.p);
   memset(info, 0, sizeof *info);
 
@@ -2219,6 +2220,9 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   hipLaunchKernelGGL(lf_scatter_kernel, dim3(gn), dim3(256), 0, c->stream, val[res], n, lf);
   uint32_t sh = 0;
   while (((uint64_t)n >> sh) > (1u << 19)) ++sh;                // at most 2^19 walkers
+  // ... and at least 256 rows per walker while that leaves a few thousand of them: the host chains the segments one after
+  // the other (a random access each), which for one-row segments of a 1 MB input was 10 ms of a 36 ms decode
+  while (sh < 8 && ((uint64_t)n >> (sh + 1)) >= 4096) ++sh;
   const uint32_t m = (uint32_t)((((uint64_t)n - 1) >> sh) + 1);
   BCE_TRY(ensure(c, c->key[0], (size_t)3 * m * 4 + 16));         // the sort's key buffers are free again
   uint32_t *d_len = c->key[0].as<uint32_t>(), *d_end = d_len + m, *d_dest = d_len + 2 * (size_t)m;
