@@ -224,12 +224,18 @@ class BCE:
         rf._c.check(lib.bce_hip_set_config(h, cfg.ctypes.data if cfg is not None else None), "bce_hip_set_config")
         rf._c.check(lib.bce_hip_set_symbol_capacity(h, self.symbol_capacity), "bce_hip_set_symbol_capacity")
 
-    def encode(self, rf: RankFile) -> bytes:
+    def encode(self, rf: RankFile, out=None):
+        """-> the archive (a bytearray).  With `out` (a writable C-contiguous uint8 numpy array that is large enough) the
+        library lays the archive out there -- the C ABI's own shape: the caller's buffer, e.g. pinned memory a collective
+        sends from -- and a memoryview of its first len(archive) bytes comes back; too small an `out` is ignored."""
         self._apply(rf)
         lib, h = rf._c.lib, rf._c.h
         rf._c.check(lib.bce_hip_encode(h), "bce_hip_encode")
         n = C.c_size_t()
         rf._c.check(lib.bce_hip_archive_size(h, C.byref(n)), "bce_hip_archive_size")
+        if out is not None and isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.flags.c_contiguous and out.flags.writeable and out.size >= n.value:
+            rf._c.check(lib.bce_hip_archive_copy(h, out.ctypes.data, out.size), "bce_hip_archive_copy")
+            return memoryview(out.reshape(-1))[:n.value]
         # the library lays the archive out straight into this buffer (one copy of the coded streams, none in Python):
         # a bytearray compares, hashes, slices and writes like bytes
         out = bytearray(n.value)
@@ -284,13 +290,13 @@ def compress(data, config=None, device=0, ctx=None) -> bytes:
             rf.close()
 
 
-def compress_device(device_ptr, n, config=None, device=0, ctx=None):
-    """Same with the input already resident in HBM.  Returns (archive bytes, stats dict)."""
+def compress_device(device_ptr, n, config=None, device=0, ctx=None, out=None):
+    """Same with the input already resident in HBM.  Returns (archive bytes, stats dict); `out`: see BCE.encode."""
     own = ctx is None
     c = ctx or _Ctx(device)
     try:
         rf = RankFile(n=n, device_ptr=device_ptr, ctx=c)
-        arch = BCE(config).encode(rf)
+        arch = BCE(config).encode(rf, out=out)
         return arch, stats(rf)
     finally:
         if own:

@@ -2,6 +2,7 @@
 one gather of the coded streams to rank 0 (RCCL over xGMI with backend "nccl", gloo on CPU for tests)."""
 import os
 
+import numpy as np
 import torch
 
 
@@ -12,26 +13,76 @@ def block_range(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_streams(archive: bytes, dist, device, dst=0):
+class _GatherBuffers:
+    """Send / receive buffers of gather_streams, kept from one call to the next (grow-only): on a GPU the host side is
+    pinned, so that a step's copies run at the bus' rate instead of through pageable staging."""
+
+    def __init__(self, device, world):
+        self.device, self.world, self.cap = device, world, 0
+        self.send = self.recv = self.host_send = self.host_recv = None
+
+    def ensure(self, need, is_dst):
+        if need <= self.cap and (self.recv is not None or not is_dst):
+            return
+        cap = max(need, 2 * self.cap, 1 << 20)
+        pin = self.device.type == "cuda"
+        self.send = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        self.host_send = torch.empty(cap, dtype=torch.uint8, pin_memory=pin)
+        if is_dst:
+            self.recv = [torch.empty(cap, dtype=torch.uint8, device=self.device) for _ in range(self.world)]
+            self.host_recv = torch.empty(self.world * cap, dtype=torch.uint8, pin_memory=pin)
+        self.cap = cap
+
+
+_gather_buffers = {}
+
+
+def gather_streams(archive, dist, device, dst=0, copy=True, direct=False):
     """Gather every rank's coded stream to `dst`.  Returns the list of streams on dst, None elsewhere.
 
-    Sizes differ per rank: all_gather the lengths (8 B each), then one padded gather.  Each peer has its own
+    Sizes differ per rank: one all_gather of the lengths (8 B each), then one padded gather.  Each peer has its own
     xGMI link to the root, so the direct gather uses them concurrently; the payload (~0.2-0.3 x block) is small.
+    The buffers on both sides live on between calls (pinned host memory on a GPU): per step the host does one copy of its
+    own stream into the send staging and, on dst, one device-to-host copy per stream at the bus' rate.
+    `archive`: bytes-like, or a CPU uint8 tensor; with direct=True the caller vouches that the tensor is pinned (the buffer
+    the encoder wrote the archive into) and it goes to the device without the staging copy (asking the tensor itself,
+    `is_pinned()`, costs milliseconds on ROCm).  copy=False returns memoryviews into the receive buffer, valid until the next call (a step of a pipeline that hands
+    them on at once); copy=True (default) returns bytes.
     """
     world, rank = dist.get_world_size(), dist.get_rank()
-    a = (torch.frombuffer(bytearray(archive), dtype=torch.uint8) if len(archive) else torch.empty(0, dtype=torch.uint8)).to(device)
-    sz = torch.tensor([a.numel()], dtype=torch.int64, device=device)
-    sizes = [torch.zeros_like(sz) for _ in range(world)]
-    dist.all_gather(sizes, sz)
-    sizes = [int(s.item()) for s in sizes]
+    key = (str(device), world)
+    bufs = _gather_buffers.get(key)
+    if bufs is None:
+        bufs = _gather_buffers[key] = _GatherBuffers(device, world)
+    n = len(archive)
+    sz = torch.tensor([n], dtype=torch.int64, device=device)
+    allsz = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(allsz, sz)
+    sizes = [int(x) for x in allsz.cpu().tolist()]
     mx = max(max(sizes), 1)
-    pad = torch.zeros(mx, dtype=torch.uint8, device=device)
-    pad[:a.numel()] = a
-    outs = [torch.empty(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, outs, dst=dst)
+    bufs.ensure(mx, rank == dst)
+    if n:
+        if direct and isinstance(archive, torch.Tensor) and archive.dtype == torch.uint8 and archive.device.type == "cpu" and archive.is_contiguous():
+            bufs.send[:n].copy_(archive.reshape(-1), non_blocking=True)        # (the caller's buffer is sendable as it is: no staging copy)
+        else:
+            if isinstance(archive, torch.Tensor):
+                bufs.host_send[:n].copy_(archive.reshape(-1))
+            else:
+                bufs.host_send[:n].numpy()[:] = np.frombuffer(archive, dtype=np.uint8)     # one memcpy into the (pinned) staging buffer
+            bufs.send[:n].copy_(bufs.host_send[:n], non_blocking=True)
+    outs = [r[:mx] for r in bufs.recv] if rank == dst else None
+    dist.gather(bufs.send[:mx], outs, dst=dst)          # (what lies beyond a rank's own length is not looked at)
     if rank != dst:
         return None
-    return [o[:s].cpu().numpy().tobytes() for o, s in zip(outs, sizes)]
+    cap = bufs.cap
+    for r in range(world):
+        if sizes[r]:
+            bufs.host_recv[r * cap:r * cap + sizes[r]].copy_(bufs.recv[r][:sizes[r]], non_blocking=True)
+    if device.type == "cuda":
+        torch.cuda.current_stream(device).synchronize()
+    host = bufs.host_recv.numpy()
+    views = [memoryview(host[r * cap:r * cap + sizes[r]]) for r in range(world)]
+    return [bytes(v) for v in views] if copy else views
 
 
 def _parse_cpulist(text):

@@ -145,3 +145,33 @@ def test_bench_two_ranks_through_the_hip_path():
 
     import oracle
     assert j["archive_sha256"] == hashlib.sha256(oracle.compress(oracle.synth_text(1, 3000000))).hexdigest()
+
+
+@pytest.mark.gpu
+def test_gather_streams_over_rccl_on_one_gpu():
+    """The nccl (= RCCL) side of gather_streams with device tensors and pinned host buffers, as far as ONE GPU can show
+    it: a process group of one rank, streams of changing sizes (the buffers grow and are reused), bytes and views."""
+    import subprocess
+    port = _free_port()
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="%d", RANK="0", WORLD_SIZE="1")
+import numpy as np, torch, torch.distributed as dist
+from bce_amd import sharding
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+dev = torch.device("cuda", 0)
+rs = np.random.RandomState(3)
+for n in (5, 3000000, 0, 70000, 9000000, 1):
+    data = rs.randint(0, 256, n).astype(np.uint8).tobytes()
+    got = sharding.gather_streams(data, dist, dev)
+    assert isinstance(got, list) and len(got) == 1 and got[0] == data, n
+    view = sharding.gather_streams(data, dist, dev, copy=False)
+    assert bytes(view[0]) == data, n
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_GATHER_OK")
+''' % (ROOT, port)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL_GATHER_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
