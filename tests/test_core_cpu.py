@@ -3,6 +3,7 @@ range coder / framing (host_coder.cpp), driven sequentially by tests/core_emul.c
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -177,3 +178,40 @@ def test_repeated_addition_equals_the_loop(emul):
         f, s = C.c_double(), C.c_double()
         ok = emul.emul_add_repeated(z, c, m, C.byref(f), C.byref(s))
         assert ok and f.value == s.value, (z, c, m, f.value, s.value)
+
+
+def test_scan_coder_under_address_and_ub_sanitizers(tmp_path):
+    """scan_coder.cpp keeps its streams, maps, map nodes and buckets in an arena of its own (placement new, a bump
+    allocator, nothing freed singly) and records from many threads: the sequential and the threaded paths under ASan +
+    UBSan must be clean and give the oracle's table."""
+    asan = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.exists(asan):
+        pytest.skip("no libasan")
+    lib = str(tmp_path / "libcore_emul_san.so")
+    srcs = [os.path.join(ROOT, "tests", "core_emul.cpp"), os.path.join(ROOT, "bce_amd", "csrc", "host_coder.cpp"),
+            os.path.join(ROOT, "bce_amd", "csrc", "scan_coder.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-o", lib] + srcs + ["-lpthread"])
+    code = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, %r)
+import numpy as np, oracle
+L = C.CDLL(%r)
+L.emul_scan.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]
+for gen, seed, n in (("synth_text", 1, 200000), ("synth_rand", 5, 50000)):
+    data = getattr(oracle, gen)(seed, n)
+    cfg, res = oracle.scan(data)
+    bwt, off = oracle.bwt_stage(data)
+    syms = np.ascontiguousarray(oracle.trace_encode_from_bwt(bwt, off)["syms"], dtype=np.uint32)
+    for threads, chunks, mr in ((0, 1, None), (5, 3, None), (16, 1, 50), (3, 2, 1)):
+        if mr is not None:
+            os.environ["BCE_HIP_SCAN_MIN_RANGE"] = str(mr)
+        out = np.zeros(288, dtype=np.uint8); r9 = np.zeros(9)
+        L.emul_scan(syms.ctypes.data, len(syms), threads, chunks, out.ctypes.data, r9.ctypes.data)
+        os.environ.pop("BCE_HIP_SCAN_MIN_RANGE", None)
+        assert out.tobytes() == cfg and list(r9) == res, (gen, threads, chunks, mr)
+print("SANITIZED_SCAN_OK")
+''' % (ROOT, lib)
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=99", UBSAN_OPTIONS="halt_on_error=1:exitcode=98")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "SANITIZED_SCAN_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
