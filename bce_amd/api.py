@@ -63,6 +63,10 @@ SYMBOLS = [
     ("bce_hip_encode", C.c_int, [C.c_void_p]),
     ("bce_hip_archive_size", C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     ("bce_hip_archive_copy", C.c_int, [C.c_void_p, _u8p, C.c_size_t]),
+    ("bce_hip_set_plane_mask", C.c_int, [C.c_void_p, C.c_uint32]),
+    ("bce_hip_plane_stream_size", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]),
+    ("bce_hip_plane_stream_copy", C.c_int, [C.c_void_p, C.c_int, _vp, C.c_size_t]),
+    ("bce_hip_plane_stream_set", C.c_int, [C.c_void_p, C.c_int, _vp, C.c_size_t]),
     ("bce_hip_compress", C.c_int, [C.c_void_p, _u8p, C.c_uint32, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("bce_hip_compress_device", C.c_int, [C.c_void_p, _vp, C.c_uint32, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("bce_hip_enum_begin", C.c_int, [C.c_void_p]),
@@ -280,6 +284,13 @@ def stats(rf: RankFile) -> dict:
     return st.as_dict()
 
 
+def stats_of(ctx) -> dict:
+    """The statistics of the context's last compression (as stats(rf), without the RankFile)."""
+    st = Stats()
+    ctx.check(ctx.lib.bce_hip_get_stats(ctx.h, C.byref(st)), "bce_hip_get_stats")
+    return st.as_dict()
+
+
 def compress(data, config=None, device=0, ctx=None) -> bytes:
     """`bce -c` on an in-memory buffer (bce.cpp:1403-1427 minus file I/O) -> archive bytes."""
     rf = RankFile(data, device=device, ctx=ctx)
@@ -301,6 +312,37 @@ def compress_device(device_ptr, n, config=None, device=0, ctx=None, out=None):
     finally:
         if own:
             c.close()
+
+
+def set_plane_mask(ctx, mask):
+    """The planes whose range coders context `ctx` runs from now on (bit p = plane p; 0xFF = all: the default)."""
+    ctx.check(ctx.lib.bce_hip_set_plane_mask(ctx.h, int(mask) & 0xFF), "bce_hip_set_plane_mask")
+
+
+def plane_stream(ctx, plane) -> np.ndarray:
+    """The finished coded stream of one plane of the context's last encode (u16 words)."""
+    n = C.c_size_t()
+    ctx.check(ctx.lib.bce_hip_plane_stream_size(ctx.h, plane, C.byref(n)), "bce_hip_plane_stream_size")
+    out = np.empty(n.value, dtype=np.uint16)
+    ctx.check(ctx.lib.bce_hip_plane_stream_copy(ctx.h, plane, out.ctypes.data, n.value), "bce_hip_plane_stream_copy")
+    return out
+
+
+def set_plane_stream(ctx, plane, words):
+    """Put another context's finished stream of `plane` (same input, same config) in the place of this context's own."""
+    w = np.ascontiguousarray(words, dtype=np.uint16)
+    ctx.check(ctx.lib.bce_hip_plane_stream_set(ctx.h, plane, w.ctypes.data, w.size), "bce_hip_plane_stream_set")
+
+
+def archive_of(ctx) -> bytearray:
+    """The archive of the context's last encode as it stands (after set_plane_stream: with the streams put in)."""
+    n = C.c_size_t()
+    ctx.check(ctx.lib.bce_hip_archive_size(ctx.h, C.byref(n)), "bce_hip_archive_size")
+    out = bytearray(n.value)
+    view = (C.c_uint8 * n.value).from_buffer(out)
+    ctx.check(ctx.lib.bce_hip_archive_copy(ctx.h, C.addressof(view), n.value), "bce_hip_archive_copy")
+    del view
+    return out
 
 
 class ContextPool:

@@ -786,6 +786,37 @@ static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes) {
   return BCE_HIP_OK;
 }
 
+int bce_hip_set_plane_mask(bce_hip_ctx *c, uint32_t mask) {
+  if (!c) return BCE_HIP_E_ARG;
+  return bce_guarded(c, [&] { c->coder->drain(); c->coder->plane_mask = mask & 0xFFu; return (int)BCE_HIP_OK; });
+}
+
+int bce_hip_plane_stream_size(bce_hip_ctx *c, int plane, size_t *words) {
+  BCE_TRY(check_stage(c, 4));
+  if (!words || plane < 0 || plane > 7) return BCE_HIP_E_ARG;
+  *words = c->coder->plane[plane].data().size();
+  return BCE_HIP_OK;
+}
+
+int bce_hip_plane_stream_copy(bce_hip_ctx *c, int plane, uint16_t *out, size_t cap_words) {
+  BCE_TRY(check_stage(c, 4));
+  if (!out || plane < 0 || plane > 7) return BCE_HIP_E_ARG;
+  const std::vector<uint16_t> &d = c->coder->plane[plane].data();
+  if (cap_words < d.size()) return BCE_HIP_E_OVERFLOW;
+  memcpy(out, d.data(), d.size() * 2);
+  return BCE_HIP_OK;
+}
+
+int bce_hip_plane_stream_set(bce_hip_ctx *c, int plane, const uint16_t *words, size_t count) {
+  BCE_TRY(check_stage(c, 4));
+  if ((!words && count) || plane < 0 || plane > 7) return BCE_HIP_E_ARG;
+  return bce_guarded(c, [&] {
+    c->coder->set_stream(plane, words, count);
+    c->coder->rebuild_header(c->config, c->n, c->offset);
+    return (int)BCE_HIP_OK;
+  });
+}
+
 int bce_hip_archive_size(bce_hip_ctx *c, size_t *bytes) {
   BCE_TRY(check_stage(c, 4));
   if (!bytes) return BCE_HIP_E_ARG;

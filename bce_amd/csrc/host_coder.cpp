@@ -180,7 +180,7 @@ void HostCoder::run(int p) {
     // the encode entry point reports BCE_HIP_E_NOMEM (failed()).
     try {
       if (b->wait_ready) b->wait_ready();
-      if (!failed_.load(std::memory_order_relaxed)) {
+      if (!failed_.load(std::memory_order_relaxed) && ((plane_mask >> p) & 1u)) {
         consume(p, b->runs[p].data(), b->runs[p].size(), b->out);
         for (const SymRun &r : b->runs[p]) w.nsym += r.count;
       }
@@ -230,8 +230,13 @@ double HostCoder::busy_seconds() {
 void HostCoder::finish(const uint8_t config[9][32], uint32_t n, uint32_t offset) {
   if (getenv("BCE_HIP_CODER_DEBUG"))
     for (int p = 0; p < 8; ++p) fprintf(stderr, "coder %d: busy %.1f ms, %llu symbols, %zu words\n", p, w_[p].busy * 1e3, (unsigned long long)w_[p].nsym, plane[p].data().size());
-  unsigned size = 0u;                                   // :1134-1138
-  for (int i = 0; i < 8; ++i) { plane[i].flush(); size += (unsigned)plane[i].data().size(); }
+  for (int i = 0; i < 8; ++i) plane[i].flush();         // :1134-1138
+  rebuild_header(config, n, offset);
+}
+
+void HostCoder::rebuild_header(const uint8_t config[9][32], uint32_t n, uint32_t offset) {
+  unsigned size = 0u;
+  for (int i = 0; i < 8; ++i) size += (unsigned)plane[i].data().size();
   RangeCoder mainc;                                     // coder_type main(-1) :1141 -> config row 8
   mainc.preamble(config[8]);
   mainc.setv(n);

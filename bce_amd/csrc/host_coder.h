@@ -65,6 +65,13 @@ struct CoderBatch {
 
 struct HostCoder {
   RangeCoder plane[8];
+  // Planes whose records this coder codes (default: all eight).  One archive from several GPUs (SURVEY section 8e-2's aim, by
+  // the split that costs least here): every rank enumerates and models everything -- the GPU's part is a fifth of a step --
+  // but runs the sequential range coders, which ARE the step, only for its own planes; the finished streams of the other
+  // planes come from their owners (set_stream) before the header is coded.
+  uint32_t plane_mask = 0xFFu;
+  void set_stream(int p, const uint16_t *words, size_t n) { plane[p].data().assign(words, words + n); }
+  void rebuild_header(const uint8_t config[9][32], uint32_t n, uint32_t offset);   // the header part of finish() (:1141-1150), again
   HostCoder();
   ~HostCoder();
   // BCE::encode :1124-1130: construct the 8 coders (preamble from config rows 0..7) and code

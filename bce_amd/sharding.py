@@ -85,6 +85,63 @@ def gather_streams(archive, dist, device, dst=0, copy=True, direct=False):
     return [bytes(v) for v in views] if copy else views
 
 
+def planes_of(rank, world):
+    """The planes rank `rank` of `world` codes in the one-archive mode: p with p % world == rank (the busiest planes of text
+    are 0..3: round robin spreads them)."""
+    return [p for p in range(8) if p % world == rank]
+
+
+def single_archive(ctx, dist, device, data=None, device_ptr=None, n=None, config=None, dst=0, timings=None):
+    """ONE archive, the one `bce -c` writes, from all ranks together (SURVEY section 8e-2's aim).
+
+    Every rank holds the SAME input and runs the whole GPU part (rotation sort, planes, enumeration, model: a fifth of a
+    step); the eight sequential range coders -- the step -- are shared out by plane (planes_of).  Each rank then sends its
+    finished plane streams to `dst` in ONE gather (a 64-byte table of word counts, then the streams), `dst` puts them in the
+    place of its own and the header is coded from the final sizes.  Returns the archive (bytearray) on dst, None elsewhere.
+    No faster than one GPU -- the busiest plane's coder is the step wherever it runs -- but the compressed size is the
+    whole-file one, which block sharding cannot give.  timings["gather_s"] accumulates what the mode adds to a compression."""
+    from . import api
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = planes_of(rank, world)
+    mask = 0
+    for p in mine:
+        mask |= 1 << p
+    api.set_plane_mask(ctx, mask)
+    try:
+        rf = api.RankFile(data, ctx=ctx) if device_ptr is None else api.RankFile(n=n, device_ptr=device_ptr, ctx=ctx)
+        api.BCE(config).encode(rf)
+        streams = {p: api.plane_stream(ctx, p) for p in mine}
+        table = np.zeros(8, dtype=np.uint64)
+        for p in mine:
+            table[p] = streams[p].size
+        import time
+        t0 = time.perf_counter()
+        blob = table.tobytes() + b"".join(streams[p].tobytes() for p in mine)
+        got = gather_streams(blob, dist, device, dst=dst, copy=False)
+        if rank != dst:
+            if timings is not None:
+                timings["gather_s"] = timings.get("gather_s", 0.0) + time.perf_counter() - t0
+            return None
+        for r, g in enumerate(got):
+            if r == rank:
+                continue
+            g = np.frombuffer(g, dtype=np.uint8)
+            sizes = np.frombuffer(g[:64].tobytes(), dtype=np.uint64)
+            at = 64
+            for p in planes_of(r, world):
+                words = int(sizes[p])
+                api.set_plane_stream(ctx, p, np.frombuffer(g[at:at + 2 * words].tobytes(), dtype=np.uint16))
+                at += 2 * words
+            if at != g.size:
+                raise ValueError("rank %d sent %d bytes, its table says %d" % (r, g.size, at))
+        arch = api.archive_of(ctx)
+        if timings is not None:       # (gather + putting the streams in + laying the archive out: what the mode adds to a compression)
+            timings["gather_s"] = timings.get("gather_s", 0.0) + time.perf_counter() - t0
+        return arch
+    finally:
+        api.set_plane_mask(ctx, 0xFF)
+
+
 def _parse_cpulist(text):
     cpus = set()
     for part in text.strip().split(","):

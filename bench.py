@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--no-big", action="store_true", help="skip the 10^9-byte and the scanned 2x10^8-byte workloads (BASELINE configs 3 and 5)")
     ap.add_argument("--scan-config", action="store_true",
                     help="BASELINE config 5: run `bce -s` on the input first (untimed), compress with the scanned table")
+    ap.add_argument("--single-archive", action="store_true",
+                    help="N > 1: every rank holds the SAME input and codes its share of the eight planes; rank 0 ends with the ONE archive "
+                         "`bce -c` writes (sharding.single_archive; whole-file compressed size, no throughput gain). Default: one block per GPU")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real multi-GPU path); gloo = rehearsal of the N>1 control flow on one GPU")
     return ap.parse_args()
@@ -73,8 +76,9 @@ def make_input(args, rank, world):
         return np.ascontiguousarray(data[lo:hi]), "file:%s[%d B, sha256 %s]" % (
             os.path.basename(args.file), len(data), hashlib.sha256(data.tobytes()).hexdigest()[:16])
     gen = bce_amd.synth_text if args.workload == "synth-text" else bce_amd.synth_rand
-    return gen(1 + rank, args.size), "%s-v1 seed %d, %d B per GPU (enwik8-sized stand-in: the corpus is not available offline)" % (
-        args.workload, 1 + rank, args.size)
+    seed = 1 if getattr(args, "single_archive", False) else 1 + rank          # (one archive: the same input on every rank)
+    return gen(seed, args.size), "%s-v1 seed %d, %d B per GPU (enwik8-sized stand-in: the corpus is not available offline)" % (
+        args.workload, seed, args.size)
 
 
 def golden_table():
@@ -368,7 +372,18 @@ def main():
     arch_t = torch.empty(n + n // 8 + 65536, dtype=torch.uint8, pin_memory=True)
     arch_np = arch_t.numpy()
 
+    one = bool(args.single_archive and dist is not None)
+    one_arch = [None]
+
     def step():
+        if one:
+            tm = {}
+            a1 = sharding.single_archive(ctx, dist, comm_dev, device_ptr=t_in.data_ptr(), n=n, config=config, timings=tm)
+            st1 = bce_amd.api.stats_of(ctx)
+            comm_s[0] += tm.get("gather_s", 0.0)      # streams out, gather, streams in, archive laid out: what the step costs beyond this rank's own compression
+            if a1 is not None:
+                one_arch[0] = a1
+            return a1, st1
         arch, st = bce_amd.compress_device(t_in.data_ptr(), n, config=config, ctx=ctx, out=arch_np)
         if dist is not None:
             # RCCL gather of the per-block coded streams to rank 0 (size exchange, then padded gather)
@@ -390,6 +405,8 @@ def main():
         sts.append(st)
     barrier()
     dt_local = time.perf_counter() - t0
+    if one:
+        arch = one_arch[0] if one_arch[0] is not None else b""
     arch = bytes(arch)                          # (out of the reused buffer: later legs compress again)
     tt = torch.tensor([dt_local], dtype=torch.float64, device=comm_dev if dist is not None else dev)
     per_rank = [dt_local]
@@ -422,18 +439,19 @@ def main():
                 roof["traffic_source"] = "profiles/r03_k3_traffic.json (static: measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this workload, not in this run)"
         except Exception:
             pass
-        if dist is not None and gathered[0] is not None:
+        if dist is not None and gathered[0] is not None and not one:
             # the gathered per-block streams form the multi-block container (bce_amd/container.py)
             from bce_amd import container
             blob = container.pack_blocks(gathered[0], [n] * n_gpus)
             assert container.unpack_blocks(blob)[0][0] == arch
         out = {
-            "metric": "MB/s compressed", "value": round(n_gpus * n * steps / dt / 1e6, 3), "unit": "MB/s",
+            "metric": "MB/s compressed", "value": round((1 if one else n_gpus) * n * steps / dt / 1e6, 3), "unit": "MB/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32 integer",
+            "higher_is_better": True, "scaling": "strong" if one else "weak", "vs_baseline": None, "dtype": "u8/u32 integer",
             "data": "synthetic" if not args.file else "file",
             "config": {"workload": workload, "bytes_per_gpu": n, "coder_config": coder_config,
-                       "sharding": "one independent block per GPU, RCCL gather of coded streams to rank 0" if n_gpus > 1 else "single block"},
+                       "sharding": ("ONE input on every GPU, the eight plane coders shared out by plane, finished streams gathered to rank 0: one archive, the one `bce -c` writes"
+                                    if one else "one independent block per GPU, RCCL gather of coded streams to rank 0") if n_gpus > 1 else "single block"},
             "archive_bytes": len(arch), "archive_sha256": hashlib.sha256(arch).hexdigest(),
             "oracle_golden": golden_verdict(table, data, arch) if config is None else None,
             "ratio": round(len(arch) / n, 5),

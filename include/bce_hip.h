@@ -119,6 +119,18 @@ int bce_hip_encode(bce_hip_ctx *ctx);
 int bce_hip_archive_size(bce_hip_ctx *ctx, size_t *bytes);
 int bce_hip_archive_copy(bce_hip_ctx *ctx, uint8_t *out, size_t cap);
 
+/* ---- extension: ONE archive from several contexts / GPUs (SURVEY section 8e-2's aim) ------------------
+ * The eight plane coders of BCE::encode (bce.cpp:1124-1150) are independent sequential streams; the archive is header +
+ * the eight streams (:1152-1157).  A context codes only the planes of `mask` (bit p = plane p; default 0xFF; set before
+ * bce_hip_encode, it stays until changed); after bce_hip_encode the finished stream of a plane it owns can be read, and
+ * the stream of a plane another context owns can be put in its place -- the header is coded again from the new sizes --
+ * so that bce_hip_archive_size / _copy give the archive `bce -c` writes.  Every context must have encoded the same input
+ * with the same config.  Streams are native-endian u16 words. */
+int bce_hip_set_plane_mask(bce_hip_ctx *ctx, uint32_t mask);
+int bce_hip_plane_stream_size(bce_hip_ctx *ctx, int plane, size_t *words);
+int bce_hip_plane_stream_copy(bce_hip_ctx *ctx, int plane, uint16_t *out, size_t cap_words);
+int bce_hip_plane_stream_set(bce_hip_ctx *ctx, int plane, const uint16_t *words, size_t count);
+
 /* ---- one-shot: main() -c branch minus file I/O (bce.cpp:1403-1427) -------------------------------- */
 int bce_hip_compress(bce_hip_ctx *ctx, const uint8_t *in, uint32_t n, uint8_t *out, size_t cap, size_t *out_len);
 /* same with the input already in HBM */
