@@ -73,6 +73,8 @@ def gather_streams(archive, dist, device, dst=0, copy=True, direct=False):
     outs = [r[:mx] for r in bufs.recv] if rank == dst else None
     dist.gather(bufs.send[:mx], outs, dst=dst)          # (what lies beyond a rank's own length is not looked at)
     if rank != dst:
+        if device.type == "cuda":                       # the caller may reuse its (pinned) source buffer: the copy out of it is done
+            torch.cuda.current_stream(device).synchronize()
         return None
     cap = bufs.cap
     for r in range(world):
@@ -110,14 +112,28 @@ def single_archive(ctx, dist, device, data=None, device_ptr=None, n=None, config
     try:
         rf = api.RankFile(data, ctx=ctx) if device_ptr is None else api.RankFile(n=n, device_ptr=device_ptr, ctx=ctx)
         api.BCE(config).encode(rf)
-        streams = {p: api.plane_stream(ctx, p) for p in mine}
-        table = np.zeros(8, dtype=np.uint64)
-        for p in mine:
-            table[p] = streams[p].size
+        import ctypes as C
         import time
         t0 = time.perf_counter()
-        blob = table.tobytes() + b"".join(streams[p].tobytes() for p in mine)
-        got = gather_streams(blob, dist, device, dst=dst, copy=False)
+        # the rank's message -- eight u64 word counts, then its streams -- is laid out by the library straight in a send buffer
+        # that lives on between calls (pinned on a GPU: the gather sends from it as it is)
+        sizes = np.zeros(8, dtype=np.uint64)
+        for p in mine:
+            w = C.c_size_t()
+            ctx.check(ctx.lib.bce_hip_plane_stream_size(ctx.h, p, C.byref(w)), "bce_hip_plane_stream_size")
+            sizes[p] = w.value
+        total = 64 + 2 * int(sizes.sum())
+        key = ("one-archive", str(device))
+        msg = _gather_buffers.get(key)
+        if msg is None or msg.numel() < total:
+            msg = _gather_buffers[key] = torch.empty(max(total + total // 4, 1 << 20), dtype=torch.uint8, pin_memory=device.type == "cuda")
+        m = msg.numpy()
+        m[:64] = np.frombuffer(sizes.tobytes(), dtype=np.uint8)
+        at = 64
+        for p in mine:
+            ctx.check(ctx.lib.bce_hip_plane_stream_copy(ctx.h, p, m.ctypes.data + at, int(sizes[p])), "bce_hip_plane_stream_copy")
+            at += 2 * int(sizes[p])
+        got = gather_streams(msg[:total], dist, device, dst=dst, copy=False, direct=True)
         if rank != dst:
             if timings is not None:
                 timings["gather_s"] = timings.get("gather_s", 0.0) + time.perf_counter() - t0
@@ -126,11 +142,13 @@ def single_archive(ctx, dist, device, data=None, device_ptr=None, n=None, config
             if r == rank:
                 continue
             g = np.frombuffer(g, dtype=np.uint8)
-            sizes = np.frombuffer(g[:64].tobytes(), dtype=np.uint64)
+            theirs = np.frombuffer(g[:64], dtype=np.uint64)
             at = 64
             for p in planes_of(r, world):
-                words = int(sizes[p])
-                api.set_plane_stream(ctx, p, np.frombuffer(g[at:at + 2 * words].tobytes(), dtype=np.uint16))
+                words = int(theirs[p])
+                if at + 2 * words > g.size:
+                    raise ValueError("rank %d sent %d bytes, its table asks for more" % (r, g.size))
+                ctx.check(ctx.lib.bce_hip_plane_stream_set(ctx.h, p, g.ctypes.data + at, words), "bce_hip_plane_stream_set")
                 at += 2 * words
             if at != g.size:
                 raise ValueError("rank %d sent %d bytes, its table says %d" % (r, g.size, at))
