@@ -42,6 +42,7 @@ class Stats(C.Structure):
 _u8p, _u32p, _vp = C.c_void_p, C.c_void_p, C.c_void_p
 SYMBOLS = [
     ("bce_hip_create", C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    ("bce_hip_create_sized", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_uint64]),
     ("bce_hip_destroy", None, [C.c_void_p]),
     ("bce_hip_strerror", C.c_char_p, [C.c_int]),
     ("bce_hip_last_error", C.c_char_p, [C.c_void_p]),

@@ -191,24 +191,39 @@ int flush_symbols(bce_hip_ctx *c, uint64_t nsym) {
 
 extern "C" {
 
-static int create_body(bce_hip_ctx **out, int device);
-int bce_hip_create(bce_hip_ctx **out, int device) {
+static int create_body(bce_hip_ctx **out, int device, uint64_t expected);
+int bce_hip_create(bce_hip_ctx **out, int device) { return bce_hip_create_sized(out, device, 0); }
+int bce_hip_create_sized(bce_hip_ctx **out, int device, uint64_t expected_input_bytes) {
   if (!out) return BCE_HIP_E_ARG;
   *out = nullptr;
   // (HostCoder starts 8 threads: std::system_error must not cross the C ABI)
-  return bce_guarded(nullptr, [&] { return create_body(out, device); });
+  return bce_guarded(nullptr, [&] { return create_body(out, device, expected_input_bytes); });
 }
-static int create_body(bce_hip_ctx **out, int device) {
-  int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return BCE_HIP_E_DEVICE;
+static void stage_release(bce_hip_ctx *c, int state) {
+  { std::lock_guard<std::mutex> lk(c->stage_mu); c->stage_state = state; }
+  c->stage_cv.notify_all();
+}
+static int create_body(bce_hip_ctx **out, int device, uint64_t expected) {
   bce_hip_ctx *c = new (std::nothrow) bce_hip_ctx();
   if (!c) return BCE_HIP_E_NOMEM;
   c->device = device;
   memcpy(c->config, kDefaultConfig, sizeof c->config);
   memset(&c->stats, 0, sizeof c->stats);
+  // a one-shot caller that knows its input's size: the flush slots' host staging is allocated and touched on threads of
+  // its own while this thread brings the runtime up (k4_prepin); the threads register it once the runtime is there
+  if (expected > 0 && expected < 0x80000000ull) { c->stage_state = 0; k4_prepin(c, (uint32_t)expected); }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+    stage_release(c, 2);
+    k4_prepin_join(c, true);
+    delete c;
+    return BCE_HIP_E_DEVICE;
+  }
+  stage_release(c, 1);
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev_k4) != hipSuccess ||
       hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+    k4_prepin_join(c, true);
     delete c;
     return BCE_HIP_E_DEVICE;
   }
@@ -248,6 +263,7 @@ void bce_hip_destroy(bce_hip_ctx *c) {
                     &c->tileoff, &c->runs, &c->smwords, &c->k3tw, &c->k3grp, &c->truns, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
                     &c->sesc, &c->stat, &c->dcfg, &c->k4w, &c->scanrec, &c->dfs, &c->skey_alt, &c->sesc_alt, &c->rs_hist_k4};
   for (DevBuf *b : bufs) release(*b);
+  k4_prepin_join(c, true);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->h_big) (void)hipHostFree(c->h_big);
@@ -256,7 +272,7 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   if (c->h_truns) (void)hipHostFree(c->h_truns);
   if (c->coder) c->coder->drain();
   for (FlushSlot &sl : c->slot) {
-    if (sl.h_out) (void)hipHostFree(sl.h_out);
+    slot_free_host(sl);
     if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
     if (sl.ev_copy) (void)hipEventDestroy(sl.ev_copy);
   }
@@ -503,6 +519,7 @@ static int encode_body(bce_hip_ctx *c) {
   gate_acquire(c);
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t n = c->n;
+  k4_prepin(c, n);                                 // (the staged interface: the one-shot entry points have started it at the load)
   BCE_TRY(k4_prepare(c));
   BCE_TRY(k3_begin(c));
   uint32_t C[8];
@@ -837,16 +854,22 @@ static int compress_loaded(bce_hip_ctx *c, uint8_t *out, size_t cap, size_t *out
   BCE_TRY(bce_hip_build_planes(c, nullptr));
   BCE_TRY(bce_hip_encode(c));
   c->stats.t_total = now_s() - t0 + c->stats.t_load;
+  if (getenv("BCE_CLI_TIMING"))
+    fprintf(stderr, "lib: load %.3f bwt %.3f planes %.3f encode %.3f s (K3 %.1f ms, coder busiest %.3f s, waited for coders %.3f s); device allocations %u calls %.1f MB %.3f s, pinned %u calls %.1f MB %.3f s\n",
+            c->stats.t_load, c->stats.t_bwt, c->stats.t_planes, c->stats.t_total - c->stats.t_load - c->stats.t_bwt - c->stats.t_planes, c->stats.k3_ms,
+            c->stats.t_coder_busy, c->stats.t_coder, c->alloc_calls, c->alloc_bytes / 1e6, c->alloc_s, c->pin_calls, c->pin_bytes / 1e6, c->pin_s);
   if (out_len) *out_len = c->coder->archive_words() * 2;
   if (out) return bce_hip_archive_copy(c, out, cap);
   return BCE_HIP_OK;
 }
 
 int bce_hip_compress(bce_hip_ctx *c, const uint8_t *in, uint32_t n, uint8_t *out, size_t cap, size_t *out_len) {
+  if (c && in && n && n < 0x80000000u) k4_prepin(c, n);      // the flush slots' pinned staging, beside the copy and K1 (cold contexts)
   BCE_TRY(bce_hip_load_host(c, in, n));
   return compress_loaded(c, out, cap, out_len);
 }
 int bce_hip_compress_device(bce_hip_ctx *c, const void *d_in, uint32_t n, uint8_t *out, size_t cap, size_t *out_len) {
+  if (c && d_in && n && n < 0x80000000u) k4_prepin(c, n);
   BCE_TRY(bce_hip_load_device(c, d_in, n));
   return compress_loaded(c, out, cap, out_len);
 }

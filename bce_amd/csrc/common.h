@@ -6,10 +6,12 @@
 #include <string.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <exception>
 #include <new>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/bce_hip.h"
@@ -57,7 +59,22 @@ struct FlushSlot {
   hipEvent_t ev_start = nullptr, ev_copy = nullptr;   // K4 start (compute stream), outputs in h_out (copy stream)
   bool timed = false;            // the events of the last flush have not been added to stats.t_model yet
   std::shared_ptr<std::once_flag> once;   // the first coder thread to arrive waits for ev_copy, the others for it
+  bool registered = false;       // h_out is malloc'ed memory under hipHostRegister (k4_prepin), not hipHostMalloc's
+  // staged ahead of its first use, on a thread of its own (k4_prepin): the buffer it prepares, adopted by the next flush
+  std::thread pin_th;
+  uint64_t *pin_p = nullptr;
+  size_t pin_cap = 0;
+  double pin_s = 0;
 };
+
+// free a slot's host staging, whichever way it was pinned
+inline void slot_free_host(FlushSlot &s) {
+  if (s.h_out) {
+    if (s.registered) { (void)hipHostUnregister(s.h_out); free(s.h_out); }
+    else (void)hipHostFree(s.h_out);
+  }
+  s.h_out = nullptr; s.cap = 0; s.registered = false;
+}
 
 struct RunEntry { uint64_t start; uint32_t count; uint32_t round; };  // symbols of (round, plane): [start, start+count)
 
@@ -141,9 +158,22 @@ struct bce_hip_ctx {
 
   bce::HostCoder *coder = nullptr;
   bce_hip_stats stats;
+  // where a cold context's time goes (BCE_CLI_TIMING=1 prints them): device allocations, pinned host allocations
+  // k4_prepin's threads touch their pages at once and register them with the runtime when it is up (bce_hip_create_sized
+  // starts them BEFORE the runtime's initialisation): 0 = wait, 1 = go, 2 = give up
+  std::mutex stage_mu;
+  std::condition_variable stage_cv;
+  int stage_state = 1;
+  double alloc_s = 0, pin_s = 0;
+  uint64_t alloc_bytes = 0, pin_bytes = 0;
+  uint32_t alloc_calls = 0, pin_calls = 0;
 };
 
 namespace bce {
+
+inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 inline int set_err(bce_hip_ctx *c, hipError_t e, const char *what, int line) {
   snprintf(c->err, sizeof c->err, "%s:%d: %s", what, line, hipGetErrorString(e));
@@ -172,8 +202,17 @@ inline int ensure(bce_hip_ctx *c, DevBuf &b, size_t bytes) {
     (void)hipFree(b.p);
     b.p = nullptr; b.cap = 0;
   }
+  const double t0 = now_s();
   BCE_HIP_TRY(c, hipMalloc(&b.p, bytes));
+  c->alloc_s += now_s() - t0; c->alloc_bytes += bytes; c->alloc_calls++;
   b.cap = bytes;
+  return BCE_HIP_OK;
+}
+// pinned host memory of the context (timed like the device allocations)
+inline int pin_alloc(bce_hip_ctx *c, void **p, size_t bytes) {
+  const double t0 = now_s();
+  BCE_HIP_TRY(c, hipHostMalloc(p, bytes, hipHostMallocDefault));
+  c->pin_s += now_s() - t0; c->pin_bytes += bytes; c->pin_calls++;
   return BCE_HIP_OK;
 }
 inline void release(DevBuf &b) {
@@ -185,7 +224,7 @@ inline void release(DevBuf &b) {
 // variable -- goes through the runtime's staging buffers, which all host threads and contexts share).
 inline int read_back(bce_hip_ctx *c, void *dst, const void *dev_src, size_t bytes) {
   if (bytes > 4096) return BCE_HIP_E_ARG;
-  if (!c->h_small) BCE_HIP_TRY(c, hipHostMalloc(&c->h_small, 4096, hipHostMallocDefault));
+  if (!c->h_small) BCE_TRY(pin_alloc(c, &c->h_small, 4096));
   BCE_HIP_TRY(c, hipMemcpyAsync(c->h_small, dev_src, bytes, hipMemcpyDeviceToHost, c->stream));
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
   memcpy(dst, c->h_small, bytes);
@@ -213,10 +252,6 @@ struct RoctxRange {
  private:
   bool on_;
 };
-
-inline double now_s() {
-  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
 
 constexpr uint32_t K3_TAIL_CAP = 1024;        // nodes the tail kernel holds in LDS (all 8 planes together)
 constexpr uint32_t K3_SMALL_MAXTILES = 2048;  // tile table of the one-launch round kernel
@@ -250,6 +285,9 @@ int k3_get_nodes(bce_hip_ctx *c, int plane, uint32_t *out, uint32_t cap, uint32_
 int k3_reset_symbols(bce_hip_ctx *c);               // after a flush: sym_total = 0, need_flush = 0
 int k3_grow_symbols(bce_hip_ctx *c, uint64_t cap);  // enlarge the (empty) symbol buffer, clear need_flush
 int k4_prepare(bce_hip_ctx *c);                     // k4_model.hip: counters to zero, cfg upload
+uint64_t k3_symbol_capacity(const bce_hip_ctx *c, uint32_t n);   // records between two model flushes for an input of n bytes
+void k4_prepin(bce_hip_ctx *c, uint32_t n);         // start pinning the flush slots' host staging for an input of n bytes (threads)
+void k4_prepin_join(bce_hip_ctx *c, bool drop);     // wait for those threads (drop: free what they pinned and nobody adopted)
 int k4_flush(bce_hip_ctx *c, uint64_t nsym, FlushSlot &slot);         // synchronous: outputs are in slot.h_out on return
 int k4_flush_async(bce_hip_ctx *c, uint64_t nsym, FlushSlot &slot);   // outputs are in slot.h_out once slot.ev_copy has fired   // sort + replay + D2H into the slot (synchronous)
 

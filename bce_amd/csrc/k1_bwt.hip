@@ -797,7 +797,7 @@ static int k1_sort_rotations(bce_hip_ctx *c, const uint8_t *T, uint32_t n, bool 
   if (nsym > 16u) nsym = 16u;
   const uint32_t keybits = nsym * bits;
   {
-    if (!c->h_small) BCE_HIP_TRY(c, hipHostMalloc(&c->h_small, 4096, hipHostMallocDefault));
+    if (!c->h_small) BCE_TRY(pin_alloc(c, &c->h_small, 4096));
     memcpy(c->h_small, code, sizeof code);
     BCE_HIP_TRY(c, hipMemcpyAsync(scalars + K1_SC_CODE, c->h_small, sizeof code, hipMemcpyHostToDevice, c->stream));
   }

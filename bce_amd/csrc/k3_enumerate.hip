@@ -926,6 +926,18 @@ static uint32_t default_capP(bce_hip_ctx *c, uint32_t n) {
   return (uint32_t)(worst < soft ? worst : soft);
 }
 
+uint64_t k3_symbol_capacity(const bce_hip_ctx *c, uint32_t n) {
+  uint64_t cap = c->sym_cap_user;
+  if (!cap) {
+    // default flush granularity: 16M records (pipelines with the host coders); a round that needs more
+    // grows the buffer on demand (k3_grow_symbols)
+    const char *env = getenv("BCE_HIP_FLUSH_RECORDS");
+    const uint64_t want = (uint64_t)8 * n + 1024, soft = env ? strtoull(env, nullptr, 10) : ((uint64_t)1 << 24);
+    cap = want < soft ? want : soft;
+  }
+  return cap;
+}
+
 int k3_begin(bce_hip_ctx *c) {
   const uint32_t n = c->n;
   c->capP = default_capP(c, n);
@@ -941,17 +953,10 @@ int k3_begin(bce_hip_ctx *c) {
   BCE_HIP_TRY(c, hipMemsetAsync(c->k3grp.p, 0, c->k3_groups * 32 + 64, c->stream));
   BCE_TRY(ensure(c, c->ctl, sizeof(EnumCtl)));
   BCE_TRY(ensure(c, c->runs, (size_t)K3_MAXBATCH * 8 * sizeof(RunEntry)));
-  if (!c->h_ctl) BCE_HIP_TRY(c, hipHostMalloc(&c->h_ctl, sizeof(EnumCtl), hipHostMallocDefault));
-  if (!c->h_runs) BCE_HIP_TRY(c, hipHostMalloc(&c->h_runs, (size_t)K3_MAXBATCH * 8 * sizeof(RunEntry), hipHostMallocDefault));
+  if (!c->h_ctl) BCE_TRY(pin_alloc(c, &c->h_ctl, sizeof(EnumCtl)));
+  if (!c->h_runs) BCE_TRY(pin_alloc(c, &c->h_runs, (size_t)K3_MAXBATCH * 8 * sizeof(RunEntry)));
   // symbol buffer capacity
-  uint64_t cap = c->sym_cap_user;
-  if (!cap) {
-    // default flush granularity: 16M records (pipelines with the host coders); a round that needs more
-    // grows the buffer on demand (k3_grow_symbols)
-    const char *env = getenv("BCE_HIP_FLUSH_RECORDS");
-    const uint64_t want = (uint64_t)8 * n + 1024, soft = env ? strtoull(env, nullptr, 10) : ((uint64_t)1 << 24);
-    cap = want < soft ? want : soft;
-  }
+  const uint64_t cap = k3_symbol_capacity(c, n);
   c->sym_cap = cap;
   BCE_TRY(ensure(c, c->skey[0], (size_t)cap * 4));
   BCE_TRY(ensure(c, c->sesc, (size_t)cap * 4));
@@ -1054,7 +1059,7 @@ int k3_clear_small_bail(bce_hip_ctx *c) {
 int k3_tail(bce_hip_ctx *c, uint32_t max_rounds) {
   if (max_rounds == 0 || max_rounds > K3_TAIL_MAXROUNDS) max_rounds = K3_TAIL_MAXROUNDS;
   BCE_TRY(ensure(c, c->truns, (size_t)K3_TAIL_MAXROUNDS * 8 * sizeof(RunEntry)));
-  if (!c->h_truns) BCE_HIP_TRY(c, hipHostMalloc(&c->h_truns, (size_t)K3_TAIL_MAXROUNDS * 8 * sizeof(RunEntry), hipHostMallocDefault));
+  if (!c->h_truns) BCE_TRY(pin_alloc(c, &c->h_truns, (size_t)K3_TAIL_MAXROUNDS * 8 * sizeof(RunEntry)));
   const K3Args a = k3_make_args(c, c->round, 0);
   if (c->scan_mode) hipLaunchKernelGGL(k3_tail_kernel<true>, dim3(1), dim3(KT_T), 0, c->stream, a, c->truns.as<RunEntry>(), max_rounds);
   else hipLaunchKernelGGL(k3_tail_kernel<false>, dim3(1), dim3(KT_T), 0, c->stream, a, c->truns.as<RunEntry>(), max_rounds);

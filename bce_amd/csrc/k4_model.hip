@@ -32,6 +32,9 @@
 // Counter state persists in HBM between flushes, so flushes can be arbitrarily small.
 #include <algorithm>
 
+#include <stdlib.h>
+#include <sys/mman.h>
+
 #include "common.h"
 #include "scan_util.h"
 
@@ -391,11 +394,21 @@ int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   BCE_TRY(ensure(c, c->skey[1], b4));
   for (int i = 0; i < 2; ++i) BCE_TRY(ensure(c, c->sval[i], b4));
   BCE_TRY(ensure(c, c->sout, (size_t)nsym * 8 + 16));      // + slack: the copy-out moves 16-byte units
+  if (slot.pin_th.joinable()) slot.pin_th.join();                    // pinned ahead (k4_prepin): adopt it
+  if (slot.pin_p) {
+    if (slot.pin_cap > slot.cap) {
+      slot_free_host(slot);
+      slot.h_out = slot.pin_p; slot.cap = slot.pin_cap; slot.registered = true;
+      c->pin_s += slot.pin_s; c->pin_bytes += slot.pin_cap * 8 + 16; c->pin_calls++;
+    } else {
+      (void)hipHostUnregister(slot.pin_p); free(slot.pin_p);
+    }
+    slot.pin_p = nullptr; slot.pin_cap = 0;
+  }
   if (slot.cap < nsym) {
-    if (slot.h_out) (void)hipHostFree(slot.h_out);
-    slot.h_out = nullptr; slot.cap = 0;
+    slot_free_host(slot);
     size_t cap = (size_t)c->sym_cap > nsym ? (size_t)c->sym_cap : nsym;
-    BCE_HIP_TRY(c, hipHostMalloc((void **)&slot.h_out, cap * 8 + 16, hipHostMallocDefault));
+    BCE_TRY(pin_alloc(c, (void **)&slot.h_out, cap * 8 + 16));
     slot.cap = cap;
   }
   // the stream the flush runs on: its own (beside the next K3 rounds) or the main one
@@ -480,6 +493,52 @@ int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   c->copy_busy = slot.ev_copy;
   slot.timed = true;
   return BCE_HIP_OK;
+}
+
+// A cold context's largest fixed cost is the pinned staging of its three flush slots (sym_cap records x 8 B each: 3 x 128 MB
+// at the default flush size).  hipHostMalloc takes ~25 ms per 128 MB, nearly all of it the kernel handing out and zeroing
+// the pages; registering pages that are already there takes 3-6 ms (tools/hip_floor.hip).  So each slot gets a thread that
+// allocates and touches plain memory -- which needs no runtime, and bce_hip_create_sized starts it before the runtime's own
+// 0.1 s of initialisation --, waits for the runtime, registers the memory (hipHostRegister) and leaves it for the slot's
+// first flush to adopt.  (The first version called hipHostMalloc on the threads: three of them beside the input's
+// host-to-device copy made that copy, from pageable memory, take 0.1 s instead of 0.011.)  Staging below 8 MB is pinned on
+// the spot as before.
+void k4_prepin(bce_hip_ctx *c, uint32_t n) {
+  const size_t cap = (size_t)k3_symbol_capacity(c, n);
+  if (cap * 8 < ((size_t)8 << 20) || c->scan_mode) return;
+  for (FlushSlot &slot : c->slot) {
+    if (slot.cap >= cap || slot.pin_th.joinable() || slot.pin_p) continue;
+    slot.pin_cap = cap;
+    FlushSlot *sp = &slot;
+    const int dev = c->device;
+    try {
+      slot.pin_th = std::thread([sp, dev, c] {
+        const double t0 = now_s();
+        const size_t bytes = (sp->pin_cap * 8 + 16 + 4095) & ~(size_t)4095;
+        void *q = nullptr;
+        if (posix_memalign(&q, (size_t)2 << 20, bytes) != 0) q = nullptr;
+        if (q) {
+          (void)madvise(q, bytes, MADV_HUGEPAGE);
+          for (size_t o = 0; o < bytes; o += 4096) static_cast<volatile uint8_t *>(q)[o] = 0;
+        }
+        int go;
+        { std::unique_lock<std::mutex> lk(c->stage_mu); c->stage_cv.wait(lk, [c] { return c->stage_state != 0; }); go = c->stage_state; }
+        if (q && (go != 1 || hipSetDevice(dev) != hipSuccess || hipHostRegister(q, bytes, hipHostRegisterDefault) != hipSuccess)) {
+          (void)hipGetLastError();
+          free(q); q = nullptr;
+        }
+        sp->pin_p = static_cast<uint64_t *>(q);
+        sp->pin_s = now_s() - t0;
+      });
+    } catch (...) { slot.pin_cap = 0; }                                // no thread: the flush pins on the spot
+  }
+}
+
+void k4_prepin_join(bce_hip_ctx *c, bool drop) {
+  for (FlushSlot &slot : c->slot) {
+    if (slot.pin_th.joinable()) slot.pin_th.join();
+    if (drop && slot.pin_p) { (void)hipHostUnregister(slot.pin_p); free(slot.pin_p); slot.pin_p = nullptr; slot.pin_cap = 0; }
+  }
 }
 
 bool k4_in_flight(bce_hip_ctx *c) {

@@ -8,6 +8,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <exception>
 #include <fstream>
@@ -31,12 +35,51 @@ static void progress(uint64_t done, uint64_t total, void *user) {
 }
 static void progress_end() { printf("                    \r"); }
 
+// File::File (bce.cpp:842-856): the whole file in memory.  Read on a thread of its own while the main thread initialises the
+// HIP runtime (bce_hip_create: ~0.1 s on this platform, the largest fixed cost of a one-shot run) -- plain read(2) into
+// memory nobody has zeroed first (a std::vector's resize touches every page once more).
+struct HostFile {
+  uint8_t *p = nullptr;
+  size_t n = 0;
+  int status = -1;            // 0 ok, -1 not found / unreadable, -2 short read
+  ~HostFile() { free(p); }
+  const uint8_t *data() const { return p; }
+  size_t size() const { return n; }
+};
+static void read_whole_file(const char *path, HostFile *f) {
+  const int fd = open(path, O_RDONLY | O_CLOEXEC);
+  if (fd < 0) return;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 0) { close(fd); return; }
+  const size_t n = (size_t)st.st_size;
+  f->p = static_cast<uint8_t *>(malloc(n ? n : 1));
+  if (!f->p) { close(fd); return; }
+  size_t got = 0;
+  while (got < n) {
+    const ssize_t r = read(fd, f->p + got, n - got);
+    if (r <= 0) break;
+    got += (size_t)r;
+  }
+  close(fd);
+  f->n = got;
+  f->status = got == n ? 0 : -2;
+}
+
+// The output is on disk and stdout is flushed: leave without the tear-down of 20 GB of device buffers, 400 MB of pinned
+// memory and the runtime's own exit handlers (0.1-0.25 s that a user of a one-shot tool would wait for nothing; the kernel
+// reclaims everything).  BCE_CLI_CLEAN_EXIT=1 takes the long way (leak checkers).
+static void fast_exit(int code) {
+  fflush(stdout);
+  fflush(stderr);
+  if (!getenv("BCE_CLI_CLEAN_EXIT")) _exit(code);
+}
+
 // ---- multi-block container (an extension; the reference has one block per archive, bce.cpp:1151-1157) ----
 // b"BCEM" | u32 version = 1 | u32 nblocks | nblocks x (u64 raw_bytes, u64 archive_bytes) | the archives.  Every
 // embedded archive is exactly what `bce -c` writes for that block alone.  Same layout as bce_amd/container.py
 // (the 8-GPU path of bench.py gathers its blocks into it).  A plain archive cannot start with "BCEM": that would
 // be a header of 0x4342 words.
-static bool is_container(const std::vector<uint8_t> &a) { return a.size() >= 12 && memcmp(a.data(), "BCEM", 4) == 0; }
+static bool is_container(const HostFile &a) { return a.size() >= 12 && memcmp(a.data(), "BCEM", 4) == 0; }
 static void put_u32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
 static void put_u64(std::vector<uint8_t> &v, uint64_t x) { for (int i = 0; i < 8; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
 static uint64_t get_le(const uint8_t *p, int bytes) { uint64_t x = 0; for (int i = 0; i < bytes; ++i) x |= (uint64_t)p[i] << (8 * i); return x; }
@@ -44,7 +87,7 @@ static uint64_t get_le(const uint8_t *p, int bytes) { uint64_t x = 0; for (int i
 // `bce -cN`: N contiguous blocks over the GPUs of the node.  With more blocks than GPUs every device gets up to three
 // gated contexts (bce_hip_set_gated), one host thread each: their GPU phases take turns while the coder threads of the
 // context that has just left the GPU finish its block.  Blocks are handed out in order to whichever context is free.
-static int compress_blocks(const std::vector<uint8_t> &data, uint32_t nblocks, const uint8_t *config, std::vector<uint8_t> &out) {
+static int compress_blocks(const HostFile &data, uint32_t nblocks, const uint8_t *config, std::vector<uint8_t> &out) {
   std::vector<bce_hip_ctx *> ctx;
   int ndev = 0;
   for (int dev = 0; dev < 64; ++dev) {
@@ -124,9 +167,15 @@ int main(int argc, char **argv) {
 
   if ((argc == 4 || argc == 5) && argv[1][0] == '-' && argv[1][1] == 'c') {
     auto start = std::chrono::high_resolution_clock::now();
+    HostFile data;
+    std::thread reader(read_whole_file, argv[3], &data);           // File::File, bce.cpp:842-856 -- beside the runtime's start-up
     bce_hip_ctx *ctx = nullptr;
-    int rc = bce_hip_create(&ctx, 0);
+    uint64_t expect = 0;                                          // the file's size, if it says: what the context prepares for
+    { struct stat st; if (stat(argv[3], &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) expect = (uint64_t)st.st_size; }
+    if (atoi(argv[1] + 2) >= 2) expect = 0;                       // (-cN: the blocks get contexts of their own)
+    int rc = bce_hip_create_sized(&ctx, 0, expect);
     if (rc != 0) {
+      reader.join();
       printf("No usable HIP device: %s\n", bce_hip_strerror(rc));
       return -3;
     }
@@ -150,16 +199,8 @@ int main(int argc, char **argv) {
         else if (bce_hip_set_config(ctx, cfgbuf.data()) != 0) { printf("Config rejected: %s\n", bce_hip_last_error(ctx)); cfgbuf.clear(); }
       }
     }
-    std::ifstream file(argv[3], std::ios::binary | std::ios::ate);   // File::File, bce.cpp:842-856
-    std::streamoff fsize = file ? (std::streamoff)file.tellg() : -1;
-    std::vector<uint8_t> data;
-    bool ok = fsize > 0 && fsize < (std::streamoff)0x80000000ll;
-    if (ok) {
-      data.resize((size_t)fsize);
-      file.seekg(0, std::ios::beg);
-      ok = (bool)file.read(reinterpret_cast<char *>(data.data()), fsize);
-    }
-    if (!ok) {   // also covers the empty file, on which the reference crashes
+    reader.join();
+    if (data.status != 0 || data.size() == 0 || data.size() >= (size_t)0x80000000ull) {   // also covers the empty file, on which the reference crashes
       printf("Error loading file\n");
       bce_hip_destroy(ctx);
       return -1;
@@ -176,6 +217,8 @@ int main(int argc, char **argv) {
       printf("Compressed from %zu B -> %zu B in %.1f s\n", data.size(), blob.size(), duration.count());
       std::ofstream archive(std::string(argv[2]), std::ios::binary | std::ios::trunc);
       archive.write(reinterpret_cast<const char *>(blob.data()), (std::streamsize)blob.size());
+      archive.close();
+      fast_exit(0);
       return 0;
     }
     size_t alen = 0;
@@ -196,17 +239,23 @@ int main(int argc, char **argv) {
     printf("Compressed from %zu B -> %zu B in %.1f s\n", data.size(), arch.size(), duration.count());
     std::ofstream archive(std::string(argv[2]), std::ios::binary | std::ios::trunc);
     archive.write(reinterpret_cast<const char *>(arch.data()), (std::streamsize)arch.size());
+    archive.close();
+    lap("written");
+    fast_exit(0);
     bce_hip_destroy(ctx);
+    lap("destroyed");
     return 0;
   } else if (argc == 4 && argv[1][0] == '-' && argv[1][1] == 'd') {
     // Decompress (bce.cpp:1428-1472).
     auto start = std::chrono::high_resolution_clock::now();
-    std::ifstream archive(std::string(argv[3]), std::ios::binary | std::ios::ate);
-    std::streamoff size = archive ? (std::streamoff)archive.tellg() : -1;
-    if (size < 0) { printf("Archive not found.\n"); return -1; }
-    std::vector<uint8_t> adata((size_t)size);
-    archive.seekg(0, std::ios::beg);
-    if (size == 0 || !archive.read(reinterpret_cast<char *>(adata.data()), size)) { printf("Could not read Archive.\n"); return -2; }
+    HostFile adata;
+    const bool use_gpu = argv[1][2] != 's';
+    std::thread reader(read_whole_file, argv[3], &adata);          // beside the runtime's start-up (-d)
+    bce_hip_ctx *ctx0 = nullptr;
+    int rc0 = use_gpu ? bce_hip_create(&ctx0, 0) : 0;
+    reader.join();
+    if (adata.status == -1) { printf("Archive not found.\n"); if (ctx0) bce_hip_destroy(ctx0); return -1; }
+    if (adata.status != 0 || adata.size() == 0) { printf("Could not read Archive.\n"); if (ctx0) bce_hip_destroy(ctx0); return -2; }
     // -d: GPU-assisted decoder (kd_decode.hip), needs the GPU like -c.  -ds (the reference's low-memory unbwt variant,
     // :1466): the plain host decoder (decoder.cpp), on purpose and by name -- there is no silent fallback.
     // A BCEM container (bce -cN, the sharded bench) is decoded block by block.
@@ -226,14 +275,12 @@ int main(int argc, char **argv) {
     }
     int rc = 0;
     std::vector<uint8_t> out;
-    const bool use_gpu = argv[1][2] != 's';
     if (blocks.size() == 1) {
       uint64_t prog = 0;
-      bce_hip_ctx *ctx = nullptr;
+      bce_hip_ctx *ctx = ctx0;
       if (use_gpu) {
-        rc = bce_hip_create(&ctx, 0);
-        if (rc != 0) {
-          printf("No usable HIP device: %s (bce -ds decodes on the host)\n", bce_hip_strerror(rc));
+        if (rc0 != 0) {
+          printf("No usable HIP device: %s (bce -ds decodes on the host)\n", bce_hip_strerror(rc0));
           return -3;
         }
         bce_hip_set_progress(ctx, progress, &prog);
@@ -277,8 +324,8 @@ int main(int argc, char **argv) {
       if (use_gpu) {
         int ndev = 0;
         for (int dev = 0; dev < 64 && ctxs.size() < blocks.size(); ++dev) {
-          bce_hip_ctx *c = nullptr;
-          if (bce_hip_create(&c, dev) != 0) break;
+          bce_hip_ctx *c = dev == 0 ? ctx0 : nullptr;
+          if (!c && bce_hip_create(&c, dev) != 0) break;
           ctxs.push_back(c);
           ndev = dev + 1;
         }
@@ -318,23 +365,19 @@ int main(int argc, char **argv) {
     printf("Decompressed from %zu B -> %zu B in %.1f s\n", adata.size(), out.size(), duration.count());
     std::ofstream file(std::string(argv[2]), std::ios::binary | std::ios::trunc);
     file.write(reinterpret_cast<const char *>(out.data()), (std::streamsize)out.size());
+    file.close();
+    fast_exit(0);
     return 0;
   } else if (argc == 4 && argv[1][0] == '-' && argv[1][1] == 's') {
     // Scan (bce.cpp:1384-1402): enumeration on the GPU, ScanCoder optimisation on the host, 288-byte config out
     auto start = std::chrono::high_resolution_clock::now();
+    HostFile data;
+    std::thread reader(read_whole_file, argv[3], &data);
     bce_hip_ctx *ctx = nullptr;
     int rc = bce_hip_create(&ctx, 0);
+    reader.join();
     if (rc != 0) { printf("No usable HIP device: %s\n", bce_hip_strerror(rc)); return -3; }
-    std::ifstream file(argv[3], std::ios::binary | std::ios::ate);
-    std::streamoff fsize = file ? (std::streamoff)file.tellg() : -1;
-    std::vector<uint8_t> data;
-    bool ok = fsize > 0 && fsize < (std::streamoff)0x80000000ll;
-    if (ok) {
-      data.resize((size_t)fsize);
-      file.seekg(0, std::ios::beg);
-      ok = (bool)file.read(reinterpret_cast<char *>(data.data()), fsize);
-    }
-    if (!ok) { printf("Error loading file\n"); bce_hip_destroy(ctx); return -1; }
+    if (data.status != 0 || data.size() == 0 || data.size() >= (size_t)0x80000000ull) { printf("Error loading file\n"); bce_hip_destroy(ctx); return -1; }
     uint8_t cfg[BCE_HIP_CONFIG_BYTES];
     double res[9];
     rc = bce_hip_load_host(ctx, data.data(), (uint32_t)data.size());
@@ -351,6 +394,8 @@ int main(int argc, char **argv) {
     auto end = std::chrono::high_resolution_clock::now();
     std::chrono::duration<double> duration = end - start;
     printf("Scanned %zu B in %.1f s\n", data.size(), duration.count());
+    f.close();
+    fast_exit(0);
     bce_hip_destroy(ctx);
     return 0;
   }

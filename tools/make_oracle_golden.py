@@ -44,6 +44,14 @@ JOBS = [
     # apart from scan parity.
     ("mixed-2e8-scanned", "mixed", 200_000_000),
 ]
+# BASELINE configs[3] stand-in: ONE input (synth-text v1 seed 1, 10^9 B) cut into N contiguous blocks (sharding.block_range),
+# one archive per block as the reference would write it for that block alone (bce.cpp:1151-1157: one block per archive).
+# 14 blocks for N = 2, 4, 8; ~0.6 s of oracle per MB, ~13 B of memory per input byte.
+BLOCK_WORLDS = (2, 4, 8)
+BLOCK_N = 1_000_000_000
+for _w in BLOCK_WORLDS:
+    for _r in range(_w):
+        JOBS.append(("synth-text-1e9-b%dof%d" % (_r, _w), "synth_text_block", BLOCK_N))
 
 
 def corpus(kind, n, cache="/tmp"):
@@ -54,7 +62,17 @@ def corpus(kind, n, cache="/tmp"):
     return np.fromfile(path, dtype=np.uint8)
 
 
-def make_input(kind, n):
+_whole = {}
+
+
+def make_input(kind, n, name=None):
+    if kind == "synth_text_block":
+        from bce_amd.sharding import block_range
+        if n not in _whole:
+            _whole[n] = np.frombuffer(oracle.synth_text(1, n), dtype=np.uint8)
+        r, w = (int(x) for x in name.rsplit("-b", 1)[1].split("of"))
+        lo, hi = block_range(n, w, r)
+        return _whole[n][lo:hi]
     if kind in ("synth_text", "synth_rand"):
         return np.frombuffer(getattr(oracle, kind)(1, n), dtype=np.uint8)
     if kind == "mixed":
@@ -75,7 +93,12 @@ def main():
     for name, kind, n in JOBS:
         if a.only and name not in a.only:
             continue
-        data = make_input(kind, n)
+        data = make_input(kind, n, name)
+        block = None
+        if kind == "synth_text_block":
+            r_, w_ = (int(x) for x in name.rsplit("-b", 1)[1].split("of"))
+            block = {"rank": r_, "world": w_, "of_n": n}
+            n = len(data)
         assert len(data) == n, (name, len(data))
         extra = {}
         cfg = None
@@ -91,6 +114,8 @@ def main():
                      "input_sha256": hashlib.sha256(data.tobytes()).hexdigest(),
                      "archive_bytes": len(arch), "archive_sha256": hashlib.sha256(arch).hexdigest(),
                      "oracle_seconds_1_thread": round(dt, 1), **extra}
+        if block:
+            res[name]["block"] = block
         print(json.dumps(res[name]), flush=True)
         doc = {"provenance": "oracle/bce_oracle.c (CPU restatement of bce -c, single thread) run by tools/make_oracle_golden.py; "
                              "no GPU code involved.  The natural/binary corpora are built from the files of this container image, so "
