@@ -7,25 +7,20 @@
 // offset_ = the first index at which a minimal rotation starts.  Equal rotations (periodic inputs)
 // have equal preceding bytes, so their relative order does not matter.
 //
-// Algorithm (MI355X-first, no sentinel, no recursion): prefix doubling on cyclic ranks.
-//   round 0: sort positions by their first 4 bytes (32-bit keys, 4 radix passes).
-//   round h: the sequence SA[j]-h (j ascending) is already ordered by rank[p+h]; a STABLE sort of it by
-//            rank[p] alone therefore orders by (rank[p], rank[p+h]) -- half the radix passes of a
-//            pair sort (the Manber-Myers induction written as a stable LSD radix sort).
-//   ranks are "index of the group head", so they only ever refine; stop when every group is a
-//   singleton or h >= n.
-// All passes are coalesced streams over u32 arrays plus two random gathers and one scatter per round.
-//
-// Round 3 (k1_sort_rotations, "v2"; the rounds above stay as k1_sort_rotations_v1 behind BCE_K1_V1=1 for A/B runs):
+// Algorithm (MI355X-first, no sentinel, no recursion): prefix doubling on cyclic ranks; ranks are "index of the group head",
+// so they only ever refine; stop when every group is a singleton or h >= n.  The sorter is k1_sort_rotations ("v2"):
 //   * first sort on a 64-BIT key of as many symbols as fit (alphabet compacted to ceil(log2 sigma) bits: 12 symbols
 //     of text, 8 of arbitrary bytes) built in text order -- no gather at all; ranks by one scatter.
 //   * every later round works on the ACTIVE list only (elements of non-singleton groups, ascending SA slots, head
 //     flags in bit 31) and sorts each group where it lies: a workgroup loads the groups that START in its 2048-element
 //     chunk into LDS, gathers rank[p + h] once, rank-sorts each group (all-pairs counting, groups <= 2048), writes the
-//     suffixes back to their slots and the new ranks to a staging array -- two random accesses per element instead of
-//     six and no radix pass.  Groups larger than 2048 are DEFERRED to the global path (the active round of v1 on the
-//     list of deferred elements).  New ranks are applied by a second kernel: a gather of another workgroup must never
-//     see a rank of this round (mixing old and new ranks inside one comparison can order two suffixes wrongly).
+//     suffixes back to their slots and the new ranks to a staging array -- two random accesses per element and no radix
+//     pass.  Groups larger than 2048 are DEFERRED to one wide radix sort on (group number, rank[p + h]).  New ranks are
+//     applied by a second kernel: a gather of another workgroup must never see a rank of this round (mixing old and new
+//     ranks inside one comparison can order two suffixes wrongly).
+// The sorter of rounds 1-2 stays as k1_sort_rotations_v1 behind BCE_K1_V1=1 for A/B runs only: a 4-byte first key (4 radix
+// passes), then full rounds in which the sequence SA[j]-h (j ascending) is already ordered by rank[p+h], so a STABLE sort
+// of it by rank[p] alone orders by (rank[p], rank[p+h]) (the Manber-Myers induction as a stable LSD radix sort).
 #include <stdlib.h>
 
 #include <utility>

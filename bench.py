@@ -5,13 +5,19 @@
 
 A step = one full compression (K1 rotation sort/BWT, K2 planes, K3 enumeration, K4 model, host range
 coders, framing) of one input block per GPU, input already resident in HBM, archive bytes ready on the
-host at the end.  N > 1 (launched by torch.distributed.run, one rank per GPU): every rank compresses
-its own block (weak scaling, no data-path collective) and the coded streams are gathered to rank 0
-over RCCL inside the timed step.  Rank 0 prints ONE JSON line.
+host at the end.  Rank 0 prints ONE JSON line.
 
-Workload: BASELINE.json config[1] is enwik8 (10^8 bytes).  The corpus is not available offline; if a
-file is given with --file (or $BCE_BENCH_FILE) it is used, otherwise the stand-in is synth-text v1
-(SURVEY 8c generator) at 10^8 bytes, seed 1 + rank.
+N = 1: BASELINE.json configs[1], enwik8 (10^8 bytes).  The corpus is not available offline; if a file is given
+with --file (or $BCE_BENCH_FILE) it is used, otherwise the stand-in is synth-text v1 (SURVEY 8c generator) at
+10^8 bytes, seed 1.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE.json configs[3] as stated -- ONE input,
+enwik9-sized (synth-text v1 seed 1, 10^9 bytes; --file if given), cut into N contiguous blocks
+(sharding.block_range); every rank compresses its block with no data-path collective and the coded streams
+are gathered to rank 0 over RCCL inside the timed step, where they form the BCEM container `bce -cN` writes.
+The total work is fixed (strong scaling): value = 10^9 B x steps / time.  Every gathered block is compared on
+rank 0 with the ORACLE's archive of that block alone (tests/golden/oracle_fullsize.json, synth-text-1e9-bRofN:
+the reference has one block per archive, bce.cpp:1151-1157): `oracle_golden_blocks`.
 
 Besides the headline the line carries (N = 1 only, all untimed with respect to `value`):
   workloads         the same measurement on harder inputs of the same size class: the natural and binary corpora built
@@ -38,6 +44,8 @@ from bce_amd import sharding  # noqa: E402
 
 REF_ENCODE_RATIO = 1.82  # reference encode-stage seconds / oracle encode-stage seconds (BASELINE.md, round 3 calibration)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+TRAFFIC_FILE = "r04_k3_traffic.json"          # tools/profile.sh + tools/pmc_summary.py (per-launch-unit HBM bytes of K3)
+TRAFFIC_FILE_1E9 = "r04_k3_traffic_1e9.json"
 K3_KERNELS = ("K3 interval-count (k3_count2_kernel + k3_tiles_kernel<write> for wide rounds, k3_small_kernel for narrow ones, "
               "k3_local_kernel / k3_dfs_kernel / k3_tail_kernel for the ends; all rounds of one compression = one launch unit)")
 
@@ -47,7 +55,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=100_000_000, help="input bytes per GPU (enwik8 = 10^8)")
+    ap.add_argument("--size", type=int, default=100_000_000, help="N = 1: input bytes (enwik8 = 10^8)")
+    ap.add_argument("--total-size", type=int, default=1_000_000_000,
+                    help="N > 1: bytes of the ONE input that is cut into N contiguous blocks (enwik9 = 10^9)")
+    ap.add_argument("--container-out", default=None, help="N > 1: rank 0 writes the BCEM container of the last step here (what `bce -d` decodes)")
     ap.add_argument("--workload", default="synth-text", choices=["synth-text", "synth-rand"])
     ap.add_argument("--file", default=os.environ.get("BCE_BENCH_FILE"))
     ap.add_argument("--cpu-sample", type=int, default=48 << 20, help="bytes of the workload the CPU baseline compresses")
@@ -57,6 +68,7 @@ def parse():
     ap.add_argument("--stream-steps", type=int, default=0, help="inputs of the stream leg (default: max(12, --steps); 12 for the extra workloads)")
     ap.add_argument("--no-decode", action="store_true", help="skip the untimed decode-and-compare leg (N=1 only)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (H2D inside) leg")
+    ap.add_argument("--no-cli", action="store_true", help="skip the cold `bce -c / -d / -s` child-process leg (N=1 only)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the extra workloads (natural / binary corpus, synth-rand)")
     ap.add_argument("--no-big", action="store_true", help="skip the 10^9-byte and the scanned 2x10^8-byte workloads (BASELINE configs 3 and 5)")
     ap.add_argument("--scan-config", action="store_true",
@@ -70,15 +82,24 @@ def parse():
 
 
 def make_input(args, rank, world):
+    """-> (this rank's bytes, description, the whole input or None).  N > 1 without --single-archive: ONE input cut into
+    `world` contiguous blocks (BASELINE configs[3]); every rank builds the whole input (the generator is sequential) and
+    keeps its block; rank 0 keeps the whole for the per-block checks."""
+    gen = bce_amd.synth_text if args.workload == "synth-text" else bce_amd.synth_rand
+    one = getattr(args, "single_archive", False)
+    if world > 1 and not one:
+        if args.file:
+            whole = np.fromfile(args.file, dtype=np.uint8)
+            desc = "file:%s[%d B]" % (os.path.basename(args.file), len(whole))
+        else:
+            whole = gen(1, args.total_size)
+            desc = "%s-v1 seed 1, %d B (enwik9-sized stand-in: the corpus is not available offline)" % (args.workload, args.total_size)
+        lo, hi = sharding.block_range(len(whole), world, rank)
+        return np.ascontiguousarray(whole[lo:hi]), desc + ", cut into %d contiguous blocks (this rank: [%d, %d))" % (world, lo, hi), (whole if rank == 0 else None)
     if args.file:
         data = np.fromfile(args.file, dtype=np.uint8)
-        lo, hi = sharding.block_range(len(data), world, rank)      # one contiguous block per rank (world size, not --gpus)
-        return np.ascontiguousarray(data[lo:hi]), "file:%s[%d B, sha256 %s]" % (
-            os.path.basename(args.file), len(data), hashlib.sha256(data.tobytes()).hexdigest()[:16])
-    gen = bce_amd.synth_text if args.workload == "synth-text" else bce_amd.synth_rand
-    seed = 1 if getattr(args, "single_archive", False) else 1 + rank          # (one archive: the same input on every rank)
-    return gen(seed, args.size), "%s-v1 seed %d, %d B per GPU (enwik8-sized stand-in: the corpus is not available offline)" % (
-        args.workload, seed, args.size)
+        return data, "file:%s[%d B, sha256 %s]" % (os.path.basename(args.file), len(data), hashlib.sha256(data.tobytes()).hexdigest()[:16]), None
+    return gen(1, args.size), "%s-v1 seed 1, %d B (enwik8-sized stand-in: the corpus is not available offline)" % (args.workload, args.size), None
 
 
 def golden_table():
@@ -219,10 +240,11 @@ def big_workload(local, dev, table, n=1_000_000_000):
         st = sts[-1]
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_k3_traffic_1e9.json")))
-            if tj["bytes_per_gpu"] == n:
-                traffic = {"corrected": tj["traffic_bytes_corrected"], "raw": tj["traffic_bytes_raw"], "algorithmic": r["algorithmic_bytes"],
-                           "source": "profiles/r03_k3_traffic_1e9.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at this size)"}
+            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE_1E9)))
+            if tj["bytes_per_gpu"] == n and tj.get("archive_sha256") == hashlib.sha256(arch).hexdigest():
+                traffic = {"bytes": tj["traffic_bytes"], "raw_counters": tj["traffic_bytes_raw"], "algorithmic": r["algorithmic_bytes"],
+                           "over_algorithmic": round(tj["traffic_bytes"] / r["algorithmic_bytes"], 3),
+                           "source": "profiles/%s (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at this size; read-side factor %s)" % (TRAFFIC_FILE_1E9, tj.get("fetch_factor"))}
         except Exception:
             pass
         return {"workload": desc, "bytes": n, "input_sha256": hashlib.sha256(data.tobytes()).hexdigest()[:16], "steps": 1, "warmup": 1,
@@ -286,6 +308,47 @@ def scanned_workload(local, dev, table, n=200_000_000):
         return {"workload": desc, "error": "%s: %s" % (type(e).__name__, e)}
 
 
+def cli_leg(data):
+    """Runs FIRST, before this process creates any GPU context of its own (a second process' idle context on the device
+    made the child's 10^8-byte run take 0.6 s instead of 0.27).  -> (dict, the archive the CLI wrote).
+    What a drop-in CLI user sees (`n / wall seconds of -c`, file read -> archive on disk; the reference times
+    its whole -c branch, bce.cpp:1404,1419-1422): wall seconds of `bce_amd/bin/bce` in a FRESH child process each time --
+    process start, HIP runtime initialisation, every allocation of a cold context, file read and write included -- for -c
+    (5 runs), -d and -s on the headline input, and -c on a 1000-byte file (the fixed cost).  The archive the CLI writes must
+    be the headline archive, and -d must give the input back."""
+    import statistics
+    import tempfile
+    exe = os.path.join(ROOT, "bce_amd", "bin", "bce")
+    if not os.path.exists(exe):
+        return {"error": "bce_amd/bin/bce has not been built"}, None
+    n = len(data)
+    with tempfile.TemporaryDirectory() as td:
+        fin, farc, fback, fcfg, fsmall = (os.path.join(td, x) for x in ("in.bin", "out.bce", "back.bin", "c.bcc", "small.bin"))
+        np.asarray(data).tofile(fin)
+        np.asarray(data[:1000]).tofile(fsmall)
+
+        def wall(args):
+            time.sleep(0.4)       # (the driver tears the previous process' 18 GB of device memory down in the background; a user's one run does not queue behind one)
+            t0 = time.perf_counter()
+            r = subprocess.run([exe] + args, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            return time.perf_counter() - t0, r.returncode
+
+        tc = sorted(wall(["-c", farc, fin]) for _ in range(5))
+        cli_arch = open(farc, "rb").read()
+        td_, rc_d = wall(["-d", fback, farc])
+        back = np.fromfile(fback, dtype=np.uint8) if rc_d == 0 else None
+        ts_, rc_s = wall(["-s", fcfg, fin])
+        tsm = sorted(wall(["-c", farc + ".small", fsmall]) for _ in range(5))
+        return {"compress_seconds": round(tc[0][0], 3), "compress_seconds_median": round(statistics.median(t for t, _ in tc), 3),
+                "value": round(n / tc[0][0] / 1e6, 2), "value_median": round(n / statistics.median(t for t, _ in tc) / 1e6, 2), "unit": "MB/s",
+                "archive_identical_to_headline": None, "all_runs_ok": all(rc == 0 for _, rc in tc),
+                "decompress_seconds": round(td_, 3), "decompress_roundtrip_identical": bool(back is not None and np.array_equal(back, np.asarray(data).reshape(-1))),
+                "scan_seconds": round(ts_, 3), "scan_ok": rc_s == 0 and os.path.getsize(fcfg) == 288,
+                "compress_1000_B_seconds": round(tsm[0][0], 3), "compress_1000_B_seconds_median": round(statistics.median(t for t, _ in tsm), 3),
+                "note": "wall seconds of a fresh `bce` process per call (min of 5 and median for -c): process start, HIP initialisation, cold-context "
+                        "allocations, file read and archive write included; `value` of the line excludes all of these (input resident in HBM, warm context)"}, cli_arch
+
+
 def cpu_baseline(data, sample_bytes, ctx, dev):
     """The oracle (bit-exact CPU restatement of bce -c) timed on this host on a bounded sample: single thread (the
     reference built without OpenMP) and 8 threads (its OpenMP build: one thread per plane, joined every round,
@@ -342,13 +405,32 @@ def main():
             dist.init_process_group(backend="gloo")
             local = local % max(1, torch.cuda.device_count())     # rehearsal: ranks may share a GPU
     n_gpus = world
+    cli, cli_arch = None, None
+    if world == 1 and not args.no_cli:
+        # the cold `bce` child processes run before this process touches the GPU (see cli_leg)
+        try:
+            cli_data = np.fromfile(args.file, dtype=np.uint8) if args.file else (bce_amd.synth_text if args.workload == "synth-text" else bce_amd.synth_rand)(1, args.size)
+            cli, cli_arch = cli_leg(cli_data)
+            del cli_data
+        except Exception as e:
+            cli = {"error": "%s: %s" % (type(e).__name__, e)}
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
     pinned = sharding.pin_to_local_numa(local)   # the rank's 8 coder threads stay on the GPU's NUMA node
 
-    data, workload = make_input(args, rank, world)
+    data, workload, whole = make_input(args, rank, world)
     n = len(data)
+    sizes = [n]
+    if dist is not None:
+        total_n = args.total_size if not args.file else None
+        if args.single_archive:
+            sizes = [n] * world
+        else:
+            szt = torch.tensor([n], dtype=torch.int64, device=comm_dev)
+            allsz = [torch.zeros_like(szt) for _ in range(world)]
+            dist.all_gather(allsz, szt)
+            sizes = [int(x.item()) for x in allsz]
     t_in = torch.from_numpy(data).to(dev)       # input resident in HBM before the timed region
     torch.cuda.synchronize()
     ctx = bce_amd.api._Ctx(local)
@@ -430,31 +512,55 @@ def main():
         st = sts[-1]
         roof = roofline(n, sts)
         table = golden_table()
-        # HBM bytes from the PMC counters are collected offline (tools/profile.sh: separate rocprofv3 --pmc passes), not in this run
+        # HBM bytes from the PMC counters are collected offline (tools/profile.sh: separate rocprofv3 --pmc passes), not in this
+        # run; the static file is only quoted when it was measured on THIS workload with THIS result (same archive hash)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_k3_traffic.json")))
-            if tj["bytes_per_gpu"] == n and not args.file and args.workload == "synth-text":
-                roof["traffic"] = tj["traffic_bytes_corrected"]
-                roof["traffic_raw"] = tj["traffic_bytes_raw"]
-                roof["traffic_source"] = "profiles/r03_k3_traffic.json (static: measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this workload, not in this run)"
+            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+            if tj["bytes_per_gpu"] == n and not args.file and args.workload == "synth-text" and n_gpus == 1:
+                if tj.get("archive_sha256") == hashlib.sha256(arch).hexdigest():
+                    roof["traffic"] = tj["traffic_bytes"]
+                    roof["traffic_raw_counters"] = tj["traffic_bytes_raw"]
+                    roof["traffic_source"] = ("profiles/%s (static: measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this workload, not in this run; "
+                                              "read-side factor %s from profiles/%s)" % (TRAFFIC_FILE, tj.get("fetch_factor"), tj.get("calibration_file")))
+                else:
+                    roof["traffic_source"] = "profiles/%s REFUSED: its archive_sha256 is not this run's" % TRAFFIC_FILE
         except Exception:
             pass
+        blocks_verdict, blocks_detail, container_bytes = None, None, None
         if dist is not None and gathered[0] is not None and not one:
-            # the gathered per-block streams form the multi-block container (bce_amd/container.py)
+            # the gathered per-block streams form the multi-block container (bce_amd/container.py, = what `bce -cN` writes);
+            # every block is checked against the ORACLE's archive of that block alone (rank 0 holds the whole input)
             from bce_amd import container
-            blob = container.pack_blocks(gathered[0], [n] * n_gpus)
-            assert container.unpack_blocks(blob)[0][0] == arch
+            blob = container.pack_blocks(gathered[0], sizes)
+            assert bytes(container.unpack_blocks(blob)[0][0]) == bytes(arch)
+            container_bytes = len(blob)
+            if args.container_out:
+                with open(args.container_out, "wb") as f:
+                    f.write(blob)
+            del blob
+            if config is None and whole is not None:
+                blocks_detail = []
+                for r in range(world):
+                    lo, hi = sharding.block_range(len(whole), world, r)
+                    blocks_detail.append(golden_verdict(table, whole[lo:hi], gathered[0][r]))
+                blocks_verdict = ("identical" if all(v == "identical" for v in blocks_detail) else
+                                  "DIFFERENT" if any(v == "DIFFERENT" for v in blocks_detail) else None)
+        total_bytes = n if (one or dist is None) else sum(sizes)
+        total_arch = len(arch) if (one or dist is None or gathered[0] is None) else int(sum(len(g) for g in gathered[0]))
         out = {
-            "metric": "MB/s compressed", "value": round((1 if one else n_gpus) * n * steps / dt / 1e6, 3), "unit": "MB/s",
+            "metric": "MB/s compressed", "value": round(total_bytes * steps / dt / 1e6, 3), "unit": "MB/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "strong" if one else "weak", "vs_baseline": None, "dtype": "u8/u32 integer",
+            "higher_is_better": True, "scaling": "strong" if n_gpus > 1 else "weak", "vs_baseline": None, "dtype": "u8/u32 integer",
             "data": "synthetic" if not args.file else "file",
-            "config": {"workload": workload, "bytes_per_gpu": n, "coder_config": coder_config,
+            "config": {"workload": workload, "total_bytes": total_bytes, "bytes_per_gpu": sizes if n_gpus > 1 else n, "coder_config": coder_config,
                        "sharding": ("ONE input on every GPU, the eight plane coders shared out by plane, finished streams gathered to rank 0: one archive, the one `bce -c` writes"
-                                    if one else "one independent block per GPU, RCCL gather of coded streams to rank 0") if n_gpus > 1 else "single block"},
-            "archive_bytes": len(arch), "archive_sha256": hashlib.sha256(arch).hexdigest(),
+                                    if one else "ONE input cut into %d contiguous blocks, one per GPU, no data-path collective; RCCL gather of the coded streams to rank 0 "
+                                                "(BASELINE configs[3]: enwik9 block-sharded)" % n_gpus) if n_gpus > 1 else "single block"},
+            "archive_bytes": total_arch, "archive_sha256": hashlib.sha256(arch).hexdigest(),
+            "archive_sha256_of": "rank 0's block" if (n_gpus > 1 and not one) else "the archive",
             "oracle_golden": golden_verdict(table, data, arch) if config is None else None,
-            "ratio": round(len(arch) / n, 5),
+            "oracle_golden_blocks": blocks_verdict, "oracle_golden_per_block": blocks_detail, "container_bytes": container_bytes,
+            "ratio": round(total_arch / total_bytes, 5),
             "roofline": roof,
             "breakdown_s": {k: round(st[k], 4) for k in ("t_load", "t_bwt", "t_planes", "t_enum", "t_model", "t_coder", "t_coder_busy")},
             "counts": {"nodes": st["nodes"], "symbols": st["symbols"], "rounds": st["rounds"], "sort_rounds": st["sort_rounds"], "flushes": st["flushes"]},
@@ -478,6 +584,10 @@ def main():
             out["value_end_to_end"] = {"value": round(n / te / 1e6, 3), "unit": "MB/s", "ms_per_step": round(te * 1e3, 2),
                                        "identical_to_headline": bool(bytes(a2) == bytes(arch)),
                                        "note": "host buffer -> archive bytes on the host: the H2D copy of the input is inside the timed region (PCIe); not `value`"}
+        if cli is not None:
+            if "error" not in cli:
+                cli["archive_identical_to_headline"] = bool(cli_arch == bytes(arch)) and cli.pop("all_runs_ok")
+            out["cli"] = cli
         pool = None
         if n_gpus == 1 and not args.no_stream:
             try:
@@ -505,6 +615,12 @@ def main():
                 out["workloads"].append(big_workload(local, dev, table))         # BASELINE configs[2] stand-in (10^9 B)
         if pool is not None:
             pool.close()
+        if "workloads" in out:
+            # a changed image cannot shrink the parity set silently: workloads whose input has no oracle-made known answer on
+            # this box (the natural / binary corpora are rebuilt from the image's own files) are counted
+            missing = [w_.get("workload", "?")[:40] for w_ in out["workloads"] if w_.get("oracle_golden") is None]
+            out["skipped_vectors"] = len(missing) + (1 if out["oracle_golden"] is None and config is None else 0)
+            out["skipped_vector_names"] = missing
         if n_gpus == 1 and not args.no_cpu:
             cb = cpu_baseline(data, min(args.cpu_sample, n), ctx, dev)
             out["cpu_baseline"] = cb

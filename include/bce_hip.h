@@ -70,7 +70,7 @@ int bce_hip_set_progress(bce_hip_ctx *ctx, bce_hip_progress_fn fn, void *user);
 
 /* test knobs for the enumeration's alternative code paths (all 0 by default): 0 = nodes a depth-first walker
  * classifies per pass, 1 = disable the depth-first tail, 2 = disable the persistent LDS tail kernel, 3 = disable chain skipping, 4 = disable the one-launch kernel for narrow rounds, 6 = three launches per wide round (separate scan kernel) instead of two, 7 = disable the workgroup-local rounds before the depth-first tail,
- * 8 = live nodes above which the tail starts with them (default 65 536), 9 = rounds a workgroup runs before it hands on (default 1024),
+ * 8 = live nodes below which the walkers take over from the workgroup-local rounds (default 16 384; the tail itself starts at 1 M live nodes with the local rounds, at 65 536 without them: BCE_HIP_DFS_ENTER), 9 = rounds a workgroup runs per pass before it hands on (default 192),
  * 10 = round from which the tail may start although the node count still grows (exercises the spill path),
  * 11 = model flushes (K4) on a stream of their own beside the next K3 rounds, double-buffered symbol records (also BCE_HIP_OVERLAP=1).
  * The archive never depends on them. */

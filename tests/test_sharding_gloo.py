@@ -115,24 +115,62 @@ def test_gather_streams_ragged_sizes_world3():
     assert q.get(timeout=5) is True
 
 
-@pytest.mark.gpu
-def test_bench_two_ranks_through_the_hip_path():
+def _run_bench_ranks(world, total, extra=(), timeout=900):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), rehearsed on ONE GPU with
-    the gloo backend: every rank compresses its block on the GPU, rank 0 gathers the HIP archives through
-    sharding.gather_streams -- the code path the nccl backend takes over RCCL -- and packs the container."""
+    the gloo backend.  -> (the JSON line, the BCEM container rank 0 wrote)."""
     import json
     import subprocess
+    import tempfile
     port = _free_port()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--size", "3000000", "--backend", "gloo", "--no-cpu"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    j = json.loads(line)
-    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    with tempfile.TemporaryDirectory() as td:
+        cpath = os.path.join(td, "blocks.bcem")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+               "--total-size", str(total), "--backend", "gloo", "--no-cpu", "--container-out", cpath] + list(extra)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        with open(cpath, "rb") as f:
+            blob = f.read()
+    return json.loads(line), blob
+
+
+def _check_blocks_against_oracle(j, blob, world, total):
+    """BASELINE configs[3]'s contract: ONE input cut into `world` contiguous blocks, every block's archive the one the
+    reference writes for that block alone (bce.cpp:1151-1157), and the container decodes back to the input."""
+    import subprocess
+    import tempfile
+
+    import numpy as np
+    import oracle
+    from bce_amd import container, sharding
+    whole = np.frombuffer(oracle.synth_text(1, total), dtype=np.uint8)
+    archives, raws = container.unpack_blocks(blob)
+    assert len(archives) == world
+    for r in range(world):
+        lo, hi = sharding.block_range(total, world, r)
+        assert raws[r] == hi - lo == j["config"]["bytes_per_gpu"][r]
+        assert archives[r] == oracle.compress(whole[lo:hi]), "block %d of %d differs from the oracle's archive of that block" % (r, world)
+    assert j["config"]["total_bytes"] == total and j["archive_bytes"] == sum(len(a) for a in archives)
+    assert j["container_bytes"] == len(blob)
+    with tempfile.TemporaryDirectory() as td:                      # `bce -d` takes the container as it is
+        cp, op = os.path.join(td, "c.bcem"), os.path.join(td, "out.bin")
+        with open(cp, "wb") as f:
+            f.write(blob)
+        r = subprocess.run([os.path.join(ROOT, "bce_amd", "bin", "bce"), "-d", op, cp], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:]
+        assert np.array_equal(np.fromfile(op, dtype=np.uint8), whole)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_one_input_in_two_blocks():
+    """N = 2 rehearsal at reduced size: ONE input cut into two contiguous blocks, every rank compresses its block on the
+    GPU, rank 0 gathers the HIP archives through sharding.gather_streams -- the code path the nccl backend takes over RCCL --
+    and packs the container; every block equals the oracle's archive of it and the container decodes to the input."""
+    total = 6_000_001                                           # (odd: the blocks differ by one byte)
+    j, blob = _run_bench_ranks(2, total)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
     assert len(j["ms_per_step_per_rank"]) == 2 and all(t > 0 for t in j["ms_per_step_per_rank"])
-    assert j["config"]["bytes_per_gpu"] == 3000000
     # what a first 8-GPU run needs to explain itself: backend, world size, gather time and bytes, per-rank host facts
     c = j["comm"]
     assert c["backend"] == "gloo" and c["world"] == 2 and c["gather_ms"] >= 0 and len(c["gather_ms_per_rank"]) == 2
@@ -140,11 +178,50 @@ def test_bench_two_ranks_through_the_hip_path():
     assert len(j["per_rank"]) == 2
     for r_ in j["per_rank"]:
         assert r_["coder_busy_ms"] > 0 and r_["k1_ms"] > 0 and r_["cpus"] >= 1 and isinstance(r_["cpu_set"], str) and "numa_pinned" in r_
-    # rank 0's block is synth-text seed 1: its archive must be the oracle's
-    import hashlib
+    _check_blocks_against_oracle(j, blob, 2, total)
 
-    import oracle
-    assert j["archive_sha256"] == hashlib.sha256(oracle.compress(oracle.synth_text(1, 3000000))).hexdigest()
+
+@pytest.mark.gpu
+def test_bench_four_ranks_one_input_in_four_blocks():
+    """N = 4 on the one GPU (the box allows six processes on the card; the driver's N = 8 run is the same code with world 8)."""
+    total = 5_000_003
+    j, blob = _run_bench_ranks(4, total)
+    assert j["n_gpus"] == 4 and j["scaling"] == "strong" and len(j["per_rank"]) == 4
+    _check_blocks_against_oracle(j, blob, 4, total)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_full_size_blocks_against_the_oracle_goldens():
+    """N = 2 at FULL size: synth-text v1 seed 1, 10^9 B, two blocks of 5 x 10^8 B (two contexts on the one GPU).  bench.py itself
+    compares every gathered block with the oracle-made known answer (tests/golden/oracle_fullsize.json, synth-text-1e9-bRof2,
+    tools/make_oracle_golden.py) -- what the driver's 8-GPU line reports as oracle_golden_blocks."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_fullsize.json")) as f:
+        gold = {v["name"]: v for v in json.load(f)["vectors"]}
+    total = 1_000_000_000
+    j, blob = _run_bench_ranks(2, total, timeout=1500)
+    assert j["oracle_golden_blocks"] == "identical" and j["oracle_golden_per_block"] == ["identical", "identical"]
+    assert j["archive_bytes"] == sum(gold["synth-text-1e9-b%dof2" % r]["archive_bytes"] for r in range(2))
+    assert j["config"]["total_bytes"] == total and j["config"]["bytes_per_gpu"] == [500_000_000, 500_000_000]
+    from bce_amd import container
+    archives, raws = container.unpack_blocks(blob)
+    import hashlib
+    for r in range(2):
+        assert hashlib.sha256(archives[r]).hexdigest() == gold["synth-text-1e9-b%dof2" % r]["archive_sha256"]
+
+
+def test_block_goldens_cover_the_stated_config():
+    """BASELINE configs[3] (enwik9-sized input cut over 2 / 4 / 8 GPUs): an oracle-made archive hash for every block."""
+    import json
+    from bce_amd import sharding
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_fullsize.json")) as f:
+        gold = {v["name"]: v for v in json.load(f)["vectors"]}
+    for world in (2, 4, 8):
+        for r in range(world):
+            v = gold["synth-text-1e9-b%dof%d" % (r, world)]
+            lo, hi = sharding.block_range(1_000_000_000, world, r)
+            assert v["n"] == hi - lo and v["block"] == {"rank": r, "world": world, "of_n": 1_000_000_000}
+            assert len(v["archive_sha256"]) == 64 and len(v["input_sha256"]) == 64 and v["archive_bytes"] > 0
 
 
 @pytest.mark.gpu

@@ -10,6 +10,7 @@ sizes = (1000, 1 << 20, 100_000_000)
 for n in sizes:
     bce_amd.synth_text(1, n).tofile('/tmp/in_%d.txt' % n)
 def wall(cmd, env=None):
+    time.sleep(float(os.environ.get("CLI_COLD_GAP", "0.4")))     # let the driver finish tearing the previous process down
     t0 = time.perf_counter(); subprocess.run(cmd, capture_output=True, env=env); return time.perf_counter() - t0
 for n in sizes:
     f = '/tmp/in_%d.txt' % n

@@ -34,10 +34,11 @@ def main():
     fetch, calls = sums(outdir, "fetch" + sfx, "FETCH_SIZE")
     write, _ = sums(outdir, "write" + sfx, "WRITE_SIZE")
     rows = sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) + write.get(k, 0)))
-    with open(os.path.join(outdir, "%s_pmc_fetch_write%s.csv" % (tag, sfx)), "w") as f:
-        f.write("kernel,dispatches,FETCH_SIZE_KB_sum,WRITE_SIZE_KB_sum\n")
+    with open(os.path.join(outdir, "%s_pmc_fetch_write%s.csv" % (tag, sfx)), "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)       # kernel names hold commas (template arguments): quoted
+        w.writerow(["kernel", "dispatches", "FETCH_SIZE_KB_sum", "WRITE_SIZE_KB_sum"])
         for k in rows:
-            f.write("%s,%d,%.1f,%.1f\n" % (k, calls.get(k, 0), fetch.get(k, 0.0), write.get(k, 0.0)))
+            w.writerow([k, calls.get(k, 0), round(fetch.get(k, 0.0), 1), round(write.get(k, 0.0), 1)])
     k3 = [k for k in rows if "k3_" in k]
     fr = sum(fetch.get(k, 0.0) for k in k3) * 1024.0
     wr = sum(write.get(k, 0.0) for k in k3) * 1024.0
@@ -47,9 +48,23 @@ def main():
             line = json.loads([l for l in f if l.startswith("{")][-1])
     except Exception:
         pass
+    # read-side factor: FETCH_SIZE's calibration on K3's own access patterns (tools/fetch_calib.sh -> profiles/<tag>_fetch_calibration.json);
+    # without it, the guide's x2 for wide coalesced streams (an upper estimate for 12 B / lane node reads)
+    factor, calib_file = 2.0, None
+    for cand in (os.path.join(outdir, "..", "fetch_calib", "fetch_calibration.json"),
+                 os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "%s_fetch_calibration.json" % tag)):
+        try:
+            cal = json.load(open(cand))["patterns"]
+            factor = round(1.0 / cal["calib_nodes12"]["fetch_over_known"], 3)      # K3's HBM reads are the node stream (the rank granules hit in cache)
+            calib_file = "%s_fetch_calibration.json" % tag
+            break
+        except Exception:
+            pass
     tj = {
         "workload": line.get("config", {}).get("workload"),
         "bytes_per_gpu": line.get("config", {}).get("bytes_per_gpu"),
+        "fetch_factor": factor, "calibration_file": calib_file,
+        "traffic_bytes": factor * fr + wr,
         "archive_sha256": line.get("archive_sha256"),
         "kernel": "K3 (" + " + ".join(k3) + ", all rounds of one compression)",
         "fetch_size_bytes_raw": fr, "write_size_bytes": wr,
