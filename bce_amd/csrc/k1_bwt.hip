@@ -157,6 +157,53 @@ __global__ __launch_bounds__(K1_T) void k1_apply_kernel(const uint32_t *__restri
   }
 }
 
+// ---- rank scatters as sorts (inputs far beyond the caches: 10^9 B) ----
+// rank[SA[j]] = v and rank[vs[i]] = nr[i] are one random 4-byte store per element into an array of 4 n bytes: at n = 10^9
+// every one misses every cache and moves a line for its four bytes (k1_apply_kernel: 45 ms for one scatter of 4 GB, 23 G
+// stores / s; 2.3 ms at 10^8).  Measured first, and rejected: ONE radix pass on the top bits of the destination, then stores
+// into 16 MB windows -- the stores ran at the same 26 G / s (the eight XCDs' L2s each hold a part of every line of the
+// window and write it back partly filled), and the BWT as a byte scatter bwt[rank[p]] = T[p - 1] into 4 MB windows took 28 ms
+// against 19 for the gather.  What does pay is to SORT the pairs by destination (three 9/10-bit passes of the pair sort,
+// ~4.5 ms each per 10^9 pairs): the scatter of a permutation becomes the sorted value array itself, that of a subset a
+// store stream in ascending order.
+#ifndef K1_PART_MIN
+#define K1_PART_MIN (1u << 27)                   // elements from which the sorted form is used
+#endif
+
+// hv[j] = max(nrk[0..j]) = index of j's group head (what k1_apply_kernel scatters), written in place of order j
+__global__ __launch_bounds__(K1_T) void k1_headidx_kernel(const uint32_t *__restrict__ nrk, const uint32_t *__restrict__ blockmax, uint32_t n,
+                                                          uint32_t per_block, uint32_t *__restrict__ hv) {
+  uint32_t c = 0;
+  for (uint32_t b = threadIdx.x; b < blockIdx.x; b += K1_T) { const uint32_t v = blockmax[b]; c = c > v ? c : v; }
+  uint32_t carry = block_reduce_max<K1_T>(c);
+  const uint64_t beg = (uint64_t)blockIdx.x * per_block;
+  uint64_t end = beg + per_block;
+  if (end > n) end = n;
+  for (uint64_t base = beg; base < end; base += K1_T) {
+    const uint64_t j = base + threadIdx.x;
+    const bool valid = j < end;
+    const uint32_t v = valid ? nrk[j] : 0u;
+    uint32_t tot;
+    uint32_t inc = block_incl_scan_max<K1_T>(v, &tot);
+    inc = inc > carry ? inc : carry;
+    if (valid) hv[j] = inc;
+    carry = carry > tot ? carry : tot;
+  }
+}
+// dst[key[i]] = val[i] for the keys below `limit` (pairs grouped by destination range)
+__global__ __launch_bounds__(K1_T) void k1_scatter32_kernel(const uint32_t *__restrict__ key, const uint32_t *__restrict__ val, uint32_t m,
+                                                            uint32_t limit, uint32_t *__restrict__ dst) {
+  for (uint64_t i = (uint64_t)blockIdx.x * K1_T + threadIdx.x; i < m; i += (uint64_t)gridDim.x * K1_T) {
+    const uint32_t k = key[i];
+    if (k < limit) dst[k] = val[i];
+  }
+}
+// the segmented round's results as pairs: key = the suffix (0xFFFFFFFF for deferred elements: they are applied elsewhere)
+__global__ __launch_bounds__(K1_T) void k1_seg_pairs_kernel(const uint32_t *__restrict__ vs, const uint8_t *__restrict__ flag, uint8_t defer, uint32_t m,
+                                                            uint32_t *__restrict__ key) {
+  for (uint64_t i = (uint64_t)blockIdx.x * K1_T + threadIdx.x; i < m; i += (uint64_t)gridDim.x * K1_T)
+    key[i] = (flag[i] & defer) ? 0xFFFFFFFFu : vs[i];
+}
 __global__ __launch_bounds__(K1_T) void k1_bwt_kernel(const uint8_t *__restrict__ T, const uint32_t *__restrict__ sa,
                                                       uint32_t n, uint8_t *__restrict__ bwt) {
   for (uint64_t j = (uint64_t)blockIdx.x * K1_T + threadIdx.x; j < n; j += (uint64_t)gridDim.x * K1_T) {
@@ -812,7 +859,11 @@ static int k1_sort_rotations(bce_hip_ctx *c, const uint8_t *T, uint32_t n, bool 
   // ranks: group heads from the sorted keys, one scatter; the first active list
   BCE_HIP_TRY(c, hipMemsetAsync(scalars, 0, 16, c->stream));
   hipLaunchKernelGGL(k1_heads_kernel, dim3(pl.nb), dim3(K1_T), 0, c->stream, hi[res], lo[res], n, pl.per_block, nrk, blockmax, scalars);
-  hipLaunchKernelGGL(k1_apply_kernel, dim3(pl.nb), dim3(K1_T), 0, c->stream, nrk, blockmax, n, pl.per_block, val[res], rank);
+  const uint32_t rbits = ceil_log2(n);
+  static const uint32_t part_min = getenv("BCE_K1_PART_MIN") ? (uint32_t)strtoul(getenv("BCE_K1_PART_MIN"), nullptr, 10) : K1_PART_MIN;
+  const bool sorted_apply = n >= part_min;
+  if (sorted_apply) hipLaunchKernelGGL(k1_headidx_kernel, dim3(pl.nb), dim3(K1_T), 0, c->stream, nrk, blockmax, n, pl.per_block, k2);
+  else hipLaunchKernelGGL(k1_apply_kernel, dim3(pl.nb), dim3(K1_T), 0, c->stream, nrk, blockmax, n, pl.per_block, val[res], rank);
   uint32_t *act[2] = {c->act[0].as<uint32_t>(), c->act[1].as<uint32_t>()};
   uint32_t *actv[2] = {c->actv[0].as<uint32_t>(), c->actv[1].as<uint32_t>()};
   uint32_t m = 0;
@@ -820,6 +871,17 @@ static int k1_sort_rotations(bce_hip_ctx *c, const uint8_t *T, uint32_t n, bool 
                      blockmax, act[0], scalars + 2, 1u, (const uint32_t *)val[res], actv[0]);
   hipLaunchKernelGGL(k1_active_kernel<1>, dim3(pl.nb), dim3(K1_T), 0, c->stream, nrk, (const uint32_t *)nullptr, n, pl.per_block, pl.nb,
                      blockmax, act[0], scalars + 2, 1u, (const uint32_t *)val[res], actv[0]);
+  if (sorted_apply) {
+    // rank = the head indices (k2) sorted by suffix: the first pass reads the suffix array and leaves it alone, the last one
+    // writes the rank array itself
+    const uint32_t b1 = rbits / ((rbits + 9u) / 10u);                       // the digit of a balanced pass
+    uint32_t *pk[2] = {val[res], lo[res ^ 1]}, *pv[2] = {k2, rank};
+    int pr = 0;
+    BCE_TRY(radix_sort_pairs(c, pk, pv, n, 0, b1, &pr, 10));                // one pass: (lo[res^1], rank)
+    uint32_t *qk[2] = {lo[res ^ 1], hi[res ^ 1]}, *qv[2] = {rank, val[res ^ 1]};
+    BCE_TRY(radix_sort_pairs(c, qk, qv, n, b1, rbits - b1, &pr, 10));
+    if (pr) BCE_HIP_TRY(c, hipMemcpyAsync(rank, qv[1], (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));   // (an odd number of passes behind the first: n > 2^30)
+  }
   BCE_TRY(read_back(c, &m, scalars + 2, 4));
   lap("first ranks", nsym, m, 0);
 
@@ -827,7 +889,6 @@ static int k1_sort_rotations(bce_hip_ctx *c, const uint8_t *T, uint32_t n, bool 
   uint64_t h = nsym;
   uint32_t *sa = val[res];
   uint32_t *nr = hi[0], *vs = hi[1];             // (the high key words are free now)
-  const uint32_t rbits = ceil_log2(n);
   while (m > 0 && h < n) {
     const uint32_t *A = act[0];
     const uint32_t nblk = (uint32_t)(((uint64_t)m + SEG_CH - 1) / SEG_CH);
@@ -868,7 +929,19 @@ static int k1_sort_rotations(bce_hip_ctx *c, const uint8_t *T, uint32_t n, bool 
       uint32_t *vjr = bv[rb];
       hipLaunchKernelGGL(k1_defer_flags_kernel, dim3(ga), dim3(K1_T), 0, c->stream, snrk, idx, (const uint32_t *)vjr, nd, flag, vs);
     }
-    hipLaunchKernelGGL(k1_seg_apply_kernel, dim3(grid_for(m)), dim3(K1_T), 0, c->stream, nr, vs, flag, m, rank);
+    if (m >= part_min) {
+      // (the deferred groups' buffers -- lo[], k2, the other suffix array -- are free again: their kernels are queued ahead)
+      const uint32_t b1 = rbits / ((rbits + 9u) / 10u);
+      uint32_t *pk[2] = {lo[0], lo[1]}, *pv[2] = {nr, k2};
+      hipLaunchKernelGGL(k1_seg_pairs_kernel, dim3(grid_for(m)), dim3(K1_T), 0, c->stream, (const uint32_t *)vs, (const uint8_t *)flag, KF_DEFER, m, pk[0]);
+      int pr = 0;
+      BCE_TRY(radix_sort_pairs(c, pk, pv, m, 0, b1, &pr, 10));               // one pass: (lo[1], k2); nr is left alone
+      uint32_t *qk[2] = {lo[1], lo[0]}, *qv[2] = {k2, val[res ^ 1]};
+      BCE_TRY(radix_sort_pairs(c, qk, qv, m, b1, rbits - b1, &pr, 10));
+      hipLaunchKernelGGL(k1_scatter32_kernel, dim3(grid_for(m)), dim3(K1_T), 0, c->stream, (const uint32_t *)qk[pr], (const uint32_t *)qv[pr], m, n, rank);
+    } else {
+      hipLaunchKernelGGL(k1_seg_apply_kernel, dim3(grid_for(m)), dim3(K1_T), 0, c->stream, nr, vs, flag, m, rank);
+    }
     hipLaunchKernelGGL((k1_relist_kernel<0, 1>), dim3(ap.nb), dim3(K1_T), 0, c->stream, A, (const uint32_t *)vs, flag, m, ap.per_block, ap.nb, blockmax, act[1],
                        actv[1], scalars + 2);
     hipLaunchKernelGGL((k1_relist_kernel<1, 1>), dim3(ap.nb), dim3(K1_T), 0, c->stream, A, (const uint32_t *)vs, flag, m, ap.per_block, ap.nb, blockmax, act[1],

@@ -30,6 +30,10 @@ struct K3Args {
   uint32_t capP, ngran, n;
   uint32_t zeros[8];
   uint32_t par, round, run_slot;
+  uint32_t pmask;         // planes whose symbols are recorded (bit p; 0xFF = all).  One archive from several contexts
+                          // (bce_hip_set_plane_mask): the rounds of this file emit no record for a plane another context codes, so
+                          // the model, its sort and the device-to-host copy shrink with the mask.  (The tail's kernels, k3_dfs.hip,
+                          // record every plane: a few per cent of the symbols, which the masked coders skip.)
 };
 
 __device__ __forceinline__ Node *plane_nodes(const K3Args &a, uint32_t par, uint32_t p) {

@@ -100,6 +100,7 @@ __device__ __forceinline__ void k3_classify(const K3Args &a, uint32_t p, uint32_
   const Granule *G = a.gran + (size_t)p * a.ngran;
   const uint32_t zp = a.zeros[p];
   const PlaneCfg &cfg = a.cfg[p];
+  const uint32_t pen = (a.pmask >> p) & 1u;      // is this plane's symbol stream recorded here? (see K3Args::pmask)
   uint32_t valid[K3_NPT];
 #pragma unroll
   for (int it = 0; it < K3_NPT; ++it) valid[it] = tile_in_plane * K3_TILE + (uint32_t)it * K3_T + tid < M ? 1u : 0u;
@@ -132,7 +133,7 @@ __device__ __forceinline__ void k3_classify(const K3Args &a, uint32_t p, uint32_
     node_flat_post(nd[it], zp, nf[it], rm, t.has0[it], t.c0[it], t.has1[it], t.c1[it], sym, k);
     t.has0[it] &= valid[it];
     t.has1[it] &= valid[it];
-    t.hassym[it] = nf[it].need_mid & valid[it];
+    t.hassym[it] = nf[it].need_mid & valid[it] & pen;
     t.kw[it] = t.ew[it] = 0;
     if (SCAN) {
       t.kw[it] = sym; t.ew[it] = k;
@@ -901,6 +902,7 @@ K3Args k3_make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot) {
   a.capP = c->capP; a.ngran = c->ngran; a.n = c->n;
   for (int i = 0; i < 8; ++i) a.zeros[i] = c->zeros[i];
   a.par = round & 1u; a.round = round; a.run_slot = run_slot;
+  a.pmask = (c->scan_mode || !c->coder) ? 0xFFu : (c->coder->plane_mask & 0xFFu);
   return a;
 }
 
