@@ -102,52 +102,140 @@ struct alignas(128) Decoder {
       t.R <<= 16;
     }
   }
+  // b = (D >= p) ? a : b without a branch on the decoded symbol (a coin flip).  gcc turns the plain ternary into a branch
+  // and strings setcc / neg / and / xor together for the mask form: five dependent cycles on the chain R -> step -> R' where
+  // cmp + cmov is two.
+  static __attribute__((always_inline)) inline uint64_t sel_ge(uint64_t D, uint64_t p, uint64_t a, uint64_t b) {
+#if defined(__x86_64__)
+    __asm__("cmpq %[p], %[D]\n\tcmovaeq %[a], %[b]" : [b] "+r"(b) : [D] "r"(D), [p] "r"(p), [a] "r"(a) : "cc");
+    return b;
+#else
+    const uint64_t m = 0ull - (uint64_t)(D >= p);
+    return (a & m) | (b & ~m);
+#endif
+  }
+  // One adaptive symbol with k <= 4 (82 % of the symbols of text: k = 2 62 %, k = 3 14 %, k = 4 6 %), ONE straight-line path:
+  // the alphabet size changes from query to query (binary <-> other: three queries in ten), so a branch on it is a coin
+  // flip too.  The slot's counters come in one 4-byte load (the bytes beyond k masked off), the three inner boundaries
+  // step * cum_i are three independent multiplications, the symbol is the number of boundaries at or below D (the walk of
+  // bce.cpp:577-583 stops at s = k - 1 whatever D is: boundaries beyond k - 1 do not count), and the new range comes out of
+  // a chain of conditional moves.  The counter goes back as the same four bytes (this decoder's thread is the only one that
+  // touches its counters, the neighbours' bytes are written back as they were), so that the next query of the same slot --
+  // one in nine -- gets them forwarded from the store.
+  static __attribute__((always_inline)) inline uint32_t st_slot4(const uint16_t *data, size_t size, const Recip *recip, St &t,
+                                                               uint8_t *ctx, uint32_t k) {
+    uint32_t raw;
+    __builtin_memcpy(&raw, ctx, 4);
+    const uint32_t km = 0xFFFFFFFFu >> (32u - 8u * k);                 // k = 2, 3, 4
+    const uint32_t y = (raw & km) + (0x01010101u & km);                 // byte i = counter i + 1 for i < k, else 0 (counters <= 254)
+    const uint32_t a1 = y & 0xFFu, a2 = a1 + ((y >> 8) & 0xFFu), a3 = a2 + ((y >> 16) & 0xFFu), tot = a3 + (y >> 24);
+    if (__builtin_expect(t.R - 1 < tot, 0)) st_reset(data, size, t);
+    const uint64_t step = div_small(t.R - 1, tot, recip);
+    const uint64_t p1 = step * a1, p2 = step * a2, p3 = step * a3, p4 = step * tot;
+    const uint64_t D = t.D;
+    // boundaries beyond k - 1 must not count: for them the comparison is made against a value D cannot reach (all ones; no
+    // branch on k either).  The sums saturate at tot behind the last counter (a2 = tot for k = 2, a3 = tot for k <= 3), so
+    // the upper ends need no case distinction: the range above p1 is [p1, p2) = step * (c1 + 1) whatever k is.
+    const uint64_t q2 = p2 | (0ull - (uint64_t)(k < 3u)), q3 = p3 | (0ull - (uint64_t)(k < 4u));
+    const uint32_t s = (uint32_t)(D >= p1) + (uint32_t)(D >= q2) + (uint32_t)(D >= q3);
+    uint64_t lo = 0, hi = p1;
+    lo = sel_ge(D, p1, p1, lo); hi = sel_ge(D, p1, p2, hi);
+    lo = sel_ge(D, q2, p2, lo); hi = sel_ge(D, q2, p3, hi);
+    lo = sel_ge(D, q3, p3, lo); hi = sel_ge(D, q3, p4, hi);
+    t.l += lo;
+    t.D = D - lo;
+    t.R = hi - lo;
+    const uint32_t upd = raw + (1u << (8u * s));
+    __builtin_memcpy(ctx, &upd, 4);
+    if (__builtin_expect(((upd >> (8u * s)) & 0xFFu) == 0xFFu, 0)) for (uint32_t i = 0; i < k; ++i) ctx[i] >>= 1;
+    st_shift_in(data, size, t);
+    return s;
+  }
+  // one uniform bit, get(2) of bce.cpp:592-608, on a local state: step = (R - 1) / 2 is a shift, and s = D / step is 0 or 1
+  // for every stream an encoder wrote (a corrupt one can ask for more: the division then)
+  static __attribute__((always_inline)) inline uint32_t st_bit(const uint16_t *data, size_t size, St &t) {
+    if (__builtin_expect(t.R - 1 < 2u, 0)) st_reset(data, size, t);
+    const uint64_t step = (t.R - 1) >> 1;
+    uint64_t s = t.D >= step ? 1u : 0u;
+    if (__builtin_expect(t.D - step >= step && s, 0)) s = t.D / step;
+    t.l += step * s;
+    t.D -= step * s;
+    t.R = step;
+    st_shift_in(data, size, t);
+    return (uint32_t)s;
+  }
   // one adaptive symbol with k <= 8 or without AVX2 (scalar), on a local state
   static __attribute__((always_inline)) inline uint32_t st_slot(const uint16_t *data, size_t size, const Recip *recip, St &t,
                                                               uint8_t *ctx, uint32_t k) {
     if (k == 2) {
-      // binary contexts (most symbols), branch-free
-      const uint32_t c0 = ctx[0], c1 = ctx[1], tot = c0 + c1 + 2u;
+      // binary contexts (most symbols).  Measured step by step (tools/decoder_step_bisect.cpp, 40 M coin flips): the symbol
+      // taken by cmp + cmov instead of setcc / neg / and / xor masks: 25.3 -> 24.0 cycles; and, the big one, the counter
+      // written back as the slot's two bytes at the slot's OWN address instead of one byte at ctx + s: 24.0 -> 17.4 --
+      // a store whose address hangs on the decoded symbol keeps the next symbols' counter loads waiting until it is known
+      // (they might alias), which strings load -> total -> reciprocal -> multiply behind every symbol.
+      uint16_t w;
+      __builtin_memcpy(&w, ctx, 2);
+      const uint32_t c0 = w & 0xFFu, c1 = w >> 8, tot = c0 + c1 + 2u;
       if (__builtin_expect(t.R - 1 < tot, 0)) st_reset(data, size, t);
       const uint64_t step = div_small(t.R - 1, tot, recip);       // tot < 8192: exact single-multiply division
       const uint64_t x0 = step * ((uint64_t)c0 + 1), x1 = step * ((uint64_t)c1 + 1);
-      const uint32_t s = t.D >= x0 ? 1u : 0u;
-      const uint64_t mask = 0ull - (uint64_t)s;                  // explicit masks: the symbol is a coin flip, no branch on it
-      const uint64_t lo = x0 & mask;
+      uint64_t lo = 0, R = x0;
+      uint32_t s;
+#if defined(__x86_64__)
+      __asm__("xorl %k[s], %k[s]\n\tcmpq %[x0], %[D]\n\tcmovaeq %[x0], %[lo]\n\tcmovaeq %[x1], %[R]\n\tsetae %b[s]"
+              : [lo] "+r"(lo), [R] "+r"(R), [s] "=&q"(s) : [D] "r"(t.D), [x0] "r"(x0), [x1] "r"(x1) : "cc");
+#else
+      s = t.D >= x0 ? 1u : 0u;
+      { const uint64_t mask = 0ull - (uint64_t)s; lo = x0 & mask; R = x0 ^ ((x0 ^ x1) & mask); }
+#endif
       t.l += lo;
       t.D -= lo;
-      t.R = x0 ^ ((x0 ^ x1) & mask);
-      if (__builtin_expect(++ctx[s] == 0xFF, 0)) { ctx[0] >>= 1; ctx[1] >>= 1; }
+      t.R = R;
+      w = (uint16_t)(w + (1u << (8u * s)));
+      __builtin_memcpy(ctx, &w, 2);
+      if (__builtin_expect(((w >> (8u * s)) & 0xFFu) == 0xFFu, 0)) { ctx[0] >>= 1; ctx[1] >>= 1; }
       st_shift_in(data, size, t);
       return s;
     }
     if (k <= 8) {
-      // small alphabets: a fixed walk (3 steps for k <= 4, 7 for k <= 8) with masks instead of a loop that ends where
-      // the data says.  The counter bytes come in one load (the slot's neighbours / the array's slack beyond k are
-      // masked off).
-      uint64_t x;
-      __builtin_memcpy(&x, ctx, 8);
-      x &= ~0ull >> (64 - 8 * k);
-      const uint64_t ev = x & 0x00FF00FF00FF00FFull, od = (x >> 8) & 0x00FF00FF00FF00FFull;
-      const uint32_t tot = k + (uint32_t)(((ev + od) * 0x0001000100010001ull) >> 48);
+      // small alphabets, one straight-line path for k = 3..8.  Everything that hangs on the counters alone -- the eight
+      // bytes of the slot in one load (the neighbours' bytes masked off), counter + 1 per byte, their prefix sums a_1..a_8,
+      // the total -- is off the chain R -> step -> R' (the core works it out while the symbol before is still in flight).
+      // On the chain: step, then SEVEN INDEPENDENT products step * a_i (the first version walked s = 0, 1, ... with a
+      // multiply-add and a masked compare per step: 7 x 7 dependent cycles, 26 ns per such symbol against 9 for a binary
+      // one), the symbol = the number of boundaries at or below D (those beyond k - 1 are compared against all ones: the
+      // walk of bce.cpp:577-583 stops at s = k - 1 whatever D is), and two more products for the new range.
+      uint64_t xraw;
+      __builtin_memcpy(&xraw, ctx, 8);
+      const uint64_t km = ~0ull >> (64 - 8 * k);
+      const uint64_t y = (xraw & km) + (0x0101010101010101ull & km);          // byte i = b_i = counter i + 1 (<= 255) for i < k, else 0
+      // prefix sums a_i = b_0 + .. + b_(i-1) in 16-bit lanes (a_8 <= 2040): pairs, their running sums by one multiplication,
+      // and the odd ones from those -- a dozen operations instead of a shift, a mask and an add per byte
+      const uint64_t ev = y & 0x00FF00FF00FF00FFull, od = (y >> 8) & 0x00FF00FF00FF00FFull;
+      const uint64_t pc = (ev + od) * 0x0001000100010001ull;                  // lanes: a_2, a_4, a_6, a_8
+      const uint64_t po = (pc << 16) + ev;                                    // lanes: a_1, a_3, a_5, a_7
+      alignas(8) uint16_t A[12];                                              // A[i] = a_i (A[0] = 0)
+      __builtin_memcpy(&A[4], &pc, 8);                                        // (interleaved below)
+      const uint32_t a1 = (uint32_t)po & 0xFFFFu, a2 = (uint32_t)pc & 0xFFFFu, a3 = (uint32_t)(po >> 16) & 0xFFFFu, a4 = (uint32_t)(pc >> 16) & 0xFFFFu,
+                     a5 = (uint32_t)(po >> 32) & 0xFFFFu, a6 = (uint32_t)(pc >> 32) & 0xFFFFu, a7 = (uint32_t)(po >> 48), tot = (uint32_t)(pc >> 48);
+      A[0] = 0; A[1] = (uint16_t)a1; A[2] = (uint16_t)a2; A[3] = (uint16_t)a3; A[4] = (uint16_t)a4; A[5] = (uint16_t)a5; A[6] = (uint16_t)a6; A[7] = (uint16_t)a7; A[8] = (uint16_t)tot;
       if (__builtin_expect(t.R - 1 < tot, 0)) st_reset(data, size, t);
       const uint64_t step = div_small(t.R - 1, tot, recip);
-      uint64_t acc = 0, lo = 0;
-      uint32_t s = 0;
-#define BCE_WALK_STEP(i)                                                                                      \
-      {                                                                                                        \
-        acc += step * (((x >> (8 * (i))) & 0xFFu) + 1);          /* step * cum_i, increasing in i */           \
-        const uint64_t adv = 0ull - (uint64_t)(((i) + 1u < k) & (acc <= t.D));   /* all ones while the walk goes on */ \
-        lo = (acc & adv) | (lo & ~adv);                                                                        \
-        s += (uint32_t)(adv & 1u);                                                                             \
-      }
-      BCE_WALK_STEP(0) BCE_WALK_STEP(1) BCE_WALK_STEP(2)
-      if (k > 4) { BCE_WALK_STEP(3) BCE_WALK_STEP(4) BCE_WALK_STEP(5) BCE_WALK_STEP(6) }
-#undef BCE_WALK_STEP
+      const uint64_t D = t.D;
+      // the sums saturate at the total behind the last counter, so a boundary beyond k - 1 is step * total: D reaches it
+      // only from the unused top of the range, where every real boundary counts as well -- the cap at k - 1 does the rest
+      uint32_t cnt = (uint32_t)(D >= step * a1) + (uint32_t)(D >= step * a2) + (uint32_t)(D >= step * a3) + (uint32_t)(D >= step * a4) +
+                     (uint32_t)(D >= step * a5) + (uint32_t)(D >= step * a6) + (uint32_t)(D >= step * a7);
+      const uint32_t s = cnt < k - 1u ? cnt : k - 1u;
+      const uint64_t lo = step * A[s];
       t.l += lo;
-      t.D -= lo;
-      t.R = step * (((x >> (8 * s)) & 0xFFu) + 1);
-      if (__builtin_expect(++ctx[s] == 0xFF, 0)) for (uint32_t i = 0; i < k; ++i) ctx[i] >>= 1;
+      t.D = D - lo;
+      t.R = step * (uint64_t)(A[s + 1] - A[s]);
+      // (the eight bytes go back where they came from, the neighbours' as they were: see the binary case; this decoder's
+      //  thread is the only one that touches its counters, and the array has 32 bytes of slack behind the last slot)
+      const uint64_t up = xraw + (1ull << (8 * s));
+      __builtin_memcpy(ctx, &up, 8);
+      if (__builtin_expect(((up >> (8 * s)) & 0xFFu) == 0xFFu, 0)) for (uint32_t i = 0; i < k; ++i) ctx[i] >>= 1;
       st_shift_in(data, size, t);
       return s;
     }
@@ -189,6 +277,7 @@ struct alignas(128) Decoder {
     const uint16_t *const dat = data;
     const size_t sz = size;
     const Recip *const rc = recip;
+    const uint32_t off2 = cfg.off[2];
     for (uint32_t i = 0; i < cnt; ++i) {
       if (i + 8 < cnt) {                                         // the counters of a query soon to come
         const uint32_t qn = q[i + 8];
@@ -196,15 +285,36 @@ struct alignas(128) Decoder {
       }
       const uint32_t qi = q[i];
       const uint32_t k = qi & 31u;
+      if (__builtin_expect((qi & (kEscapeQuery | 31u)) == 2u, 1)) {        // binary slots: six symbols in ten
+        r[i] = st_slot(dat, sz, rc, t, sbase + off2 + (qi >> 5) * 2u, 2u);
+        continue;
+      }
 #if defined(__x86_64__)
       const bool wide = have_avx2 && k > 8;
 #else
       const bool wide = false;
 #endif
-      if (__builtin_expect((qi & kEscapeQuery) || wide, 0)) {    // rare paths work on the object
+      if (__builtin_expect((qi & kEscapeQuery) != 0, 0)) {
+        // k > 31 (bce.cpp:557-560): uniform bits, LSB first, each halving the range, then the slot of the k that is left
+        uint32_t kk = e->k, bits = 0, nb = 0;
+        while (kk > (uint32_t)kMaxK) {
+          const uint32_t sb = st_bit(dat, sz, t);
+          bits |= sb << nb; ++nb;
+          kk = (kk + (~sb & 1u)) >> 1;
+        }
+        const uint32_t b = cfg.bits[kk];
+        const uint32_t ctxv = (((uint32_t)(e->c1 << b) / e->cs) << b) | ((uint32_t)(e->c2 << b) / e->cs);   // :671-677
+        uint8_t *ctx = sbase + cfg.off[kk] + ctxv * kk;
+        uint32_t top;
+        if (have_wide_path() && kk > 8) { restore(t); top = get_slot(kk, ctxv); t = save(); }
+        else top = st_slot(dat, sz, rc, t, ctx, kk);
+        r[i] = (top << nb) | bits;
+        ++e;
+        continue;
+      }
+      if (__builtin_expect(wide, 0)) {                            // k = 9..31 with AVX2: on the object
         restore(t);
-        if (qi & kEscapeQuery) { r[i] = get_adaptive(e->k, e->c1, e->c2, e->cs); ++e; }
-        else r[i] = get_slot(k, qi >> 5);
+        r[i] = get_slot(k, qi >> 5);
         t = save();
         continue;
       }
@@ -258,6 +368,9 @@ struct alignas(128) Decoder {
     return s;
   }
   bool have_avx2 = __builtin_cpu_supports("avx2") != 0;
+  bool have_wide_path() const { return have_avx2; }
+#else
+  bool have_wide_path() const { return false; }
 #endif
   void prefetch_slot(uint32_t k, uint32_t ctxv) const { __builtin_prefetch(stat.data() + cfg.off[k] + ctxv * k); }
   const Recip *recip = recip_table();

@@ -6,6 +6,7 @@
 
 extern "C" {
 int bce_hip_create(bce_hip_ctx **out, int) { if (out) *out = nullptr; return BCE_HIP_E_DEVICE; }
+int bce_hip_create_sized(bce_hip_ctx **out, int, uint64_t) { if (out) *out = nullptr; return BCE_HIP_E_DEVICE; }
 void bce_hip_destroy(bce_hip_ctx *) {}
 const char *bce_hip_strerror(int) { return "no device (sanitizer build)"; }
 const char *bce_hip_last_error(const bce_hip_ctx *) { return ""; }

@@ -154,12 +154,19 @@ def _check_blocks_against_oracle(j, blob, world, total):
     assert j["config"]["total_bytes"] == total and j["archive_bytes"] == sum(len(a) for a in archives)
     assert j["container_bytes"] == len(blob)
     with tempfile.TemporaryDirectory() as td:                      # `bce -d` takes the container as it is
-        cp, op = os.path.join(td, "c.bcem"), os.path.join(td, "out.bin")
+        cp, op, ip, c2 = (os.path.join(td, x) for x in ("c.bcem", "out.bin", "in.bin", "cli.bcem"))
         with open(cp, "wb") as f:
             f.write(blob)
-        r = subprocess.run([os.path.join(ROOT, "bce_amd", "bin", "bce"), "-d", op, cp], capture_output=True, text=True, timeout=600)
+        exe = os.path.join(ROOT, "bce_amd", "bin", "bce")
+        r = subprocess.run([exe, "-d", op, cp], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:]
         assert np.array_equal(np.fromfile(op, dtype=np.uint8), whole)
+        # the same blocks through the CLI: `bce -cN` cuts the file the same way and writes the same container, byte for byte
+        whole.tofile(ip)
+        r = subprocess.run([exe, "-c%d" % world, c2, ip], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:]
+        with open(c2, "rb") as f:
+            assert f.read() == blob
 
 
 @pytest.mark.gpu
