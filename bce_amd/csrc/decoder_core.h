@@ -4,6 +4,7 @@
 // (bce.cpp:692-705).  Plain host C++.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -101,55 +102,6 @@ struct alignas(128) Decoder {
       t.l <<= 16;
       t.R <<= 16;
     }
-  }
-  // b = (D >= p) ? a : b without a branch on the decoded symbol (a coin flip).  gcc turns the plain ternary into a branch
-  // and strings setcc / neg / and / xor together for the mask form: five dependent cycles on the chain R -> step -> R' where
-  // cmp + cmov is two.
-  static __attribute__((always_inline)) inline uint64_t sel_ge(uint64_t D, uint64_t p, uint64_t a, uint64_t b) {
-#if defined(__x86_64__)
-    __asm__("cmpq %[p], %[D]\n\tcmovaeq %[a], %[b]" : [b] "+r"(b) : [D] "r"(D), [p] "r"(p), [a] "r"(a) : "cc");
-    return b;
-#else
-    const uint64_t m = 0ull - (uint64_t)(D >= p);
-    return (a & m) | (b & ~m);
-#endif
-  }
-  // One adaptive symbol with k <= 4 (82 % of the symbols of text: k = 2 62 %, k = 3 14 %, k = 4 6 %), ONE straight-line path:
-  // the alphabet size changes from query to query (binary <-> other: three queries in ten), so a branch on it is a coin
-  // flip too.  The slot's counters come in one 4-byte load (the bytes beyond k masked off), the three inner boundaries
-  // step * cum_i are three independent multiplications, the symbol is the number of boundaries at or below D (the walk of
-  // bce.cpp:577-583 stops at s = k - 1 whatever D is: boundaries beyond k - 1 do not count), and the new range comes out of
-  // a chain of conditional moves.  The counter goes back as the same four bytes (this decoder's thread is the only one that
-  // touches its counters, the neighbours' bytes are written back as they were), so that the next query of the same slot --
-  // one in nine -- gets them forwarded from the store.
-  static __attribute__((always_inline)) inline uint32_t st_slot4(const uint16_t *data, size_t size, const Recip *recip, St &t,
-                                                               uint8_t *ctx, uint32_t k) {
-    uint32_t raw;
-    __builtin_memcpy(&raw, ctx, 4);
-    const uint32_t km = 0xFFFFFFFFu >> (32u - 8u * k);                 // k = 2, 3, 4
-    const uint32_t y = (raw & km) + (0x01010101u & km);                 // byte i = counter i + 1 for i < k, else 0 (counters <= 254)
-    const uint32_t a1 = y & 0xFFu, a2 = a1 + ((y >> 8) & 0xFFu), a3 = a2 + ((y >> 16) & 0xFFu), tot = a3 + (y >> 24);
-    if (__builtin_expect(t.R - 1 < tot, 0)) st_reset(data, size, t);
-    const uint64_t step = div_small(t.R - 1, tot, recip);
-    const uint64_t p1 = step * a1, p2 = step * a2, p3 = step * a3, p4 = step * tot;
-    const uint64_t D = t.D;
-    // boundaries beyond k - 1 must not count: for them the comparison is made against a value D cannot reach (all ones; no
-    // branch on k either).  The sums saturate at tot behind the last counter (a2 = tot for k = 2, a3 = tot for k <= 3), so
-    // the upper ends need no case distinction: the range above p1 is [p1, p2) = step * (c1 + 1) whatever k is.
-    const uint64_t q2 = p2 | (0ull - (uint64_t)(k < 3u)), q3 = p3 | (0ull - (uint64_t)(k < 4u));
-    const uint32_t s = (uint32_t)(D >= p1) + (uint32_t)(D >= q2) + (uint32_t)(D >= q3);
-    uint64_t lo = 0, hi = p1;
-    lo = sel_ge(D, p1, p1, lo); hi = sel_ge(D, p1, p2, hi);
-    lo = sel_ge(D, q2, p2, lo); hi = sel_ge(D, q2, p3, hi);
-    lo = sel_ge(D, q3, p3, lo); hi = sel_ge(D, q3, p4, hi);
-    t.l += lo;
-    t.D = D - lo;
-    t.R = hi - lo;
-    const uint32_t upd = raw + (1u << (8u * s));
-    __builtin_memcpy(ctx, &upd, 4);
-    if (__builtin_expect(((upd >> (8u * s)) & 0xFFu) == 0xFFu, 0)) for (uint32_t i = 0; i < k; ++i) ctx[i] >>= 1;
-    st_shift_in(data, size, t);
-    return s;
   }
   // one uniform bit, get(2) of bce.cpp:592-608, on a local state: step = (R - 1) / 2 is a shift, and s = D / step is 0 or 1
   // for every stream an encoder wrote (a corrupt one can ask for more: the division then)

@@ -15,7 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 # rocprofv3's kernel trace serialises the copy stream's blit kernel with the compute stream and charges the copy's
 # 2.4 ms to the K3 kernel queued behind each flush; with synchronous flushes every kernel is timed alone.
 export BCE_HIP_SYNC_FLUSH=1
-B="--steps 2 --warmup 1 --no-cpu --no-decode --no-workloads --no-e2e --no-stream"   # 3 compressions per run
+B="--steps 2 --warmup 1 --no-cpu --no-decode --no-workloads --no-e2e --no-stream --no-cli"   # 3 compressions per run
 run() {  # name, bench args...
   local name=$1; shift
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -o run -- \
@@ -30,9 +30,9 @@ run natural_1e8 --file /tmp/bce_natural_100000000.bin
 run binary_1e8 --file /tmp/bce_binary_100000000.bin
 run synthrand_32Mi --workload synth-rand --size 33554432
 # BASELINE configs[2] (enwik9-sized): 2 compressions of 10^9 bytes (--steps 1 --warmup 1 replaces $B's counts)
-B="--steps 1 --warmup 1 --no-cpu --no-decode --no-workloads --no-e2e --no-stream"
+B="--steps 1 --warmup 1 --no-cpu --no-decode --no-workloads --no-e2e --no-stream --no-cli"
 run synthtext_1e9 --size 1000000000
-P="--steps 1 --warmup 0 --no-cpu --no-decode --no-workloads --no-e2e --no-stream"   # ONE compression
+P="--steps 1 --warmup 0 --no-cpu --no-decode --no-workloads --no-e2e --no-stream --no-cli"   # ONE compression
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o run -- \
   python3 "$ROOT/bench.py" $P > "$OUT/fetch.log" 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o run -- \
