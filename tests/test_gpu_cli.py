@@ -5,6 +5,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import bce_amd
 import oracle
 from conftest import ROOT
 
@@ -132,3 +133,30 @@ def test_two_bce_processes_on_one_gpu_take_turns(tmp_path):
         assert p.returncode == 0, out + err
     for i, d in enumerate(datas):
         assert (tmp_path / ("a%d.bce" % i)).read_bytes() == oracle.compress(d)
+
+
+def test_create_sized_prepares_and_is_only_a_hint():
+    """bce_hip_create_sized (what `bce -c` calls with the file's size): the flush slots' pinned staging is allocated and touched
+    on threads beside the runtime's start-up and registered afterwards.  The hint binds nothing: inputs smaller and larger than
+    it, several compressions in a row and a context that is destroyed unused all behave as with bce_hip_create."""
+    import ctypes as C
+
+    import numpy as np
+    lib = bce_amd.load_library()
+    for hint in (0, 1000, 40_000_000, 3_000_000_000):            # (the last one is beyond 2^31: ignored)
+        h = C.c_void_p()
+        assert lib.bce_hip_create_sized(C.byref(h), 0, hint) == 0
+        lib.bce_hip_destroy(h)                                     # unused: the staging threads are joined, their memory freed
+    h = C.c_void_p()
+    assert lib.bce_hip_create_sized(C.byref(h), 0, 40_000_000) == 0
+    try:
+        for data in (oracle.synth_text(3, 5000), oracle.synth_text(4, 6_000_000), oracle.synth_rand(5, 3_000_000), oracle.synth_text(3, 5000)):
+            a = np.frombuffer(data, dtype=np.uint8)
+            n = C.c_size_t()
+            assert lib.bce_hip_compress(h, a.ctypes.data, len(a), None, 0, C.byref(n)) == 0
+            out = np.empty(n.value, dtype=np.uint8)
+            assert lib.bce_hip_archive_copy(h, out.ctypes.data, n.value) == 0
+            assert out.tobytes() == oracle.compress(data)
+    finally:
+        lib.bce_hip_destroy(h)
+    assert lib.bce_hip_create_sized(None, 0, 0) != 0

@@ -95,3 +95,44 @@ def test_old_sorter_agrees(monkeypatch):
     monkeypatch.setenv("BCE_K1_V1", "1")
     old = [k1(d) for d in inputs]
     assert new == old
+
+
+def test_rank_scatters_as_sorts_on_small_inputs():
+    """Above 2^27 elements K1 writes its ranks by SORTING the (destination, value) pairs instead of scattering them (10^9-byte
+    inputs; k1_bwt.hip).  BCE_K1_PART_MIN=0 takes that form at every size: the same inputs as above -- alphabets, groups around
+    the LDS limit (the deferred path's buffers are reused by the sort), periodic inputs -- and the libdivsufsort seam (T$: a
+    sentinel as one more symbol) in a child process, each against the oracle."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import bce_amd, oracle
+from tests.test_gpu_k1 import check, repeats
+rng = np.random.RandomState(5)
+for n in (2, 3, 300, 70001, 1 << 20):
+    check(rng.randint(0, 256, n).astype(np.uint8))
+    check(rng.randint(97, 101, n).astype(np.uint8))
+for count in (2, 2047, 2048, 2049, 9000):
+    check(repeats(rng.bytes(40), count, rng))
+check(b"ab" * 5000)
+check(b"a" * 4097)
+check(oracle.synth_text(3, 3_000_000))
+data = oracle.synth_text(4, 1_500_000)
+assert bytes(bce_amd.compress(data)) == oracle.compress(data)
+# the libdivsufsort seam (T$ with the sentinel as one more symbol goes through the same sorter)
+import ctypes as C
+L = C.CDLL(os.path.join(%r, "bce_amd", "lib", "libdivsufsort_hip.so"))
+L.divbwt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]; L.divbwt.restype = C.c_int32
+for t in (b"abracadabra", oracle.synth_text(6, 700001), b"ab" * 4000):
+    a = np.frombuffer(bytes(t), dtype=np.uint8).copy(); u = np.empty_like(a)
+    pidx = L.divbwt(a.ctypes.data, u.ctypes.data, None, len(a))
+    wu, wp = oracle.divbwt(bytes(t))
+    assert pidx == wp and u.tobytes() == bytes(wu), len(t)
+print("SORTED_SCATTERS_OK")
+''' % (os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."), os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    env = dict(os.environ, BCE_K1_PART_MIN="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env,
+                       cwd=os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    assert r.returncode == 0 and "SORTED_SCATTERS_OK" in r.stdout, r.stderr[-3000:]

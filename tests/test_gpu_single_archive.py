@@ -45,6 +45,24 @@ def test_streams_of_masked_contexts_make_the_oracles_archive(masks):
             c.close()
 
 
+def test_masked_context_records_only_its_planes():
+    """Since round 4 the enumeration's rounds record no symbol for a plane another context codes (K3Args::pmask): the model,
+    its sort and the device-to-host copy shrink with the mask.  The symbol counts of two complementary masks add up to a little
+    more than the full run's (the tail's kernels still record every plane) and each is well below it."""
+    data = oracle.synth_text(17, 3_000_000)
+    full = _encode_with_mask(data, 0xFF)
+    lo = _encode_with_mask(data, 0x0F)
+    hi = _encode_with_mask(data, 0xF0)
+    try:
+        n_full, n_lo, n_hi = (bce_amd.api.stats_of(c)["symbols"] for c in (full, lo, hi))
+        assert n_lo < n_full and n_hi < n_full
+        assert n_full <= n_lo + n_hi < 2 * n_full          # (the tail's share is recorded by both: large on a 3 MB input)
+        assert min(n_lo, n_hi) < (n_full * 9) // 10
+    finally:
+        for c in (full, lo, hi):
+            c.close()
+
+
 def test_mask_is_kept_and_can_be_taken_back():
     data = oracle.synth_text(13, 120000)
     want = oracle.compress(data)
