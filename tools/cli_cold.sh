@@ -2,6 +2,8 @@
 # Cold `bce -c / -d / -s` as a user runs them: wall seconds of a fresh process per input size (5 runs: min / median),
 # the stage laps of BCE_CLI_TIMING=1 and the floor of any one-shot HIP program on this box (tools/hip_floor.hip).
 cd "$(dirname "$0")/.."
+mkdir -p tools/_build
+[ -x tools/_build/hip_floor ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/hip_floor.hip -o tools/_build/hip_floor -lpthread
 python3 - <<'PY'
 import subprocess, time, os, statistics
 import bce_amd

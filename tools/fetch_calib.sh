@@ -2,7 +2,8 @@
 # FETCH_SIZE / WRITE_SIZE calibration on K3's access patterns (tools/fetch_calib.hip): counter KB per kernel against known bytes.
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/fetch_calib
-mkdir -p "$OUT"
+mkdir -p "$OUT" "$ROOT/tools/_build"
+[ -x "$ROOT/tools/_build/fetch_calib" ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 "$ROOT/tools/fetch_calib.hip" -o "$ROOT/tools/_build/fetch_calib" || exit 1
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 200 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$OUT/$ctr" -o run -- "$ROOT/tools/_build/fetch_calib" > "$OUT/$ctr.log" 2>&1
