@@ -59,6 +59,61 @@ def test_block_sharding_gather_and_container_world2():
     assert q.get(timeout=5) is True
 
 
+def _worker8(rank, world, port, q):
+    """World 8, the stated shape of BASELINE configs[3] (one input, eight contiguous blocks, gather to rank 0), on the CPU: the
+    oracle stands in for the GPU path, everything around it -- block split, size exchange, padded gather, container, and the
+    host decoder reading the container's blocks back -- is the code the 8-GPU run uses."""
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from bce_amd import container, sharding
+    data = oracle.synth_text(9, 160003)                     # (ragged: three blocks of 20001, five of 20000)
+    lo, hi = sharding.block_range(len(data), world, rank)
+    mine = oracle.compress(data[lo:hi])
+    for _ in range(2):
+        streams = sharding.gather_streams(mine, dist, torch.device("cpu"), copy=False)
+    if rank == 0:
+        raws = [sharding.block_range(len(data), world, r) for r in range(world)]
+        blob = container.pack_blocks(streams, [b - a for a, b in raws])
+        archives, sizes = container.unpack_blocks(blob)
+        ok = len(archives) == 8 and sizes == [b - a for a, b in raws] and sum(sizes) == len(data)
+        import bce_amd
+        lib = bce_amd.load_library()
+        back = bytearray()
+        for r, (a, b) in enumerate(raws):
+            ok = ok and archives[r] == oracle.compress(data[a:b])
+            arr = np.frombuffer(archives[r], dtype=np.uint8)
+            out = np.empty(b - a, dtype=np.uint8)
+            n = C.c_size_t()
+            ok = ok and lib.bce_hip_decompress(arr.ctypes.data, len(arr), out.ctypes.data, len(out), C.byref(n)) == 0 and n.value == b - a
+            back += out.tobytes()
+        q.put(bool(ok and bytes(back) == bytes(data)))
+    else:
+        assert streams is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_block_sharding_world8_one_input_in_eight_blocks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_block_range_partitions_exactly():
     from bce_amd import sharding
     for n in (1, 7, 8, 100, 1000003):
