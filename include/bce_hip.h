@@ -35,9 +35,10 @@ enum bce_hip_status {
 /* ---- lifetime ---------------------------------------------------------------------------------- */
 int bce_hip_create(bce_hip_ctx **out, int device);
 /* The same for a one-shot caller that knows the size of the input it is about to compress (`bce -c`: the file's size, main()
- * bce.cpp:1403-1427): host-side preparation that depends on it -- the pinned staging of the model flushes, 3 x 128 MB from
- * 16 MB of input up -- runs on threads of its own beside the HIP runtime's initialisation instead of inside the first
- * compression.  A hint only: any input may follow; 0 = unknown (= bce_hip_create). */
+ * bce.cpp:1403-1427): host-side preparation that depends on it -- the pinned staging of the model flushes, 8 bytes per
+ * symbol record of a flush in three slots: 3 x 8 MB from 128 KB of input, 3 x 128 MB from 2 MB up -- runs on threads of
+ * its own beside the HIP runtime's initialisation instead of inside the first compression.  A hint only: any input may
+ * follow; 0 = unknown (= bce_hip_create). */
 int bce_hip_create_sized(bce_hip_ctx **out, int device, uint64_t expected_input_bytes);
 void bce_hip_destroy(bce_hip_ctx *ctx);
 const char *bce_hip_strerror(int status);
