@@ -124,13 +124,32 @@ void RangeCoder::encode_run(const uint64_t *out, uint64_t begin, uint64_t end) {
       R <<= 16;                                         /* ((r << 16) | 0xFFFF) + 1 */                    \
     }                                                                                                     \
   } while (0)
+  // one uniform bit, set(s & 1, 2) of the k > 31 escape (bce.cpp:507-510): BCE_STEP(bit, 1, 2) with the division by two as a
+  // shift and no multiplication at all -- step = (R - 1) >> 1 (R = 0, the full range: 2^63 - 1, as (2^64 - 1) / 2), l += step
+  // or nothing, R = step.  3.7 % of text's symbols carry ~3 such bits each: a tenth of the coder's chain steps.
+#define BCE_BIT(bit)                                                                                      \
+  do {                                                                                                    \
+    if (__builtin_expect(R - 1 < 2u, 0)) {              /* :541-546 */                                    \
+      for (int i_ = 0; i_ < 4; ++i_) BCE_EMIT(l >> (48 - 16 * i_));                                       \
+      l = 0; R = 0;                                                                                       \
+    }                                                                                                     \
+    const uint64_t step_ = (R - 1) >> 1;                                                                  \
+    l += step_ & (0ull - (uint64_t)(bit));                                                                \
+    R = step_;                                                                                            \
+    while (__builtin_expect(!(((l + R - 1) ^ l) >> 48), 0)) {                                             \
+      BCE_EMIT((l + R - 1) >> 48);                                                                        \
+      l <<= 16;                                                                                           \
+      R <<= 16;                                                                                           \
+    }                                                                                                     \
+  } while (0)
   for (uint64_t i = begin; i < end; ++i) {
     const uint64_t o = out[i];
     uint32_t es = out_esc_sentinel(o);                  // escape bits below a sentinel bit; 1 = none
     if (__builtin_expect(es != 1u, 0))                  // k > 31 escape, bce.cpp:507-510: uniform bits, LSB first
-      for (; es > 1u; es >>= 1) BCE_STEP(es & 1u, 1u, 2u);
+      for (; es > 1u; es >>= 1) BCE_BIT(es & 1u);
     BCE_STEP(out_cum(o), out_freq(o), out_total(o));
   }
+#undef BCE_BIT
 #undef BCE_STEP
 #undef BCE_EMIT
   data_.insert(data_.end(), stage, stage + ns);
