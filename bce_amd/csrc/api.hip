@@ -3,6 +3,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <utility>
 
@@ -14,6 +15,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -41,6 +43,45 @@ struct RoctxApi {
 };
 const RoctxApi &roctx() { static const RoctxApi api; return api; }
 }  // namespace
+void *big_host_alloc(size_t bytes, int device, bool *registered) {
+  *registered = false;
+  void *q = nullptr;
+  const size_t two_mb = (size_t)2 << 20;
+  if (!getenv("BCE_DEC_NO_HUGE") && posix_memalign(&q, two_mb, (bytes + two_mb - 1) & ~(two_mb - 1)) == 0 && q) {
+    (void)madvise(q, bytes, MADV_HUGEPAGE);
+    // first touch (the kernel hands out and clears 2 MB at a time), on a few threads when there is much of it
+    const unsigned nt = bytes >= ((size_t)256 << 20) ? 4 : 1;
+    auto touch = [q, bytes, nt](unsigned t) {
+      const size_t lo = bytes / nt * t, hi = t + 1 == nt ? bytes : bytes / nt * (t + 1);
+      for (size_t o = lo; o < hi; o += 4096) static_cast<volatile uint8_t *>(q)[o] = 0;
+    };
+    std::vector<std::thread> th;
+    try {
+      for (unsigned t = 1; t < nt; ++t) th.emplace_back(touch, t);
+    } catch (...) {}
+    const unsigned started = (unsigned)th.size() + 1;
+    touch(0);
+    for (unsigned t = started; t < nt; ++t) touch(t);            // (threads that did not start)
+    for (auto &x : th) x.join();
+    // registered memory is mapped and host-coherent; the kernels are handed the host address, so it must be the device's too
+    void *dp = nullptr;
+    if (hipSetDevice(device) == hipSuccess && hipHostRegister(q, bytes, hipHostRegisterMapped) == hipSuccess) {
+      if (hipHostGetDevicePointer(&dp, q, 0) == hipSuccess && dp == q) { *registered = true; return q; }
+      (void)hipHostUnregister(q);
+    }
+    (void)hipGetLastError();
+    free(q);
+    q = nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&q, bytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return q;
+}
+void big_host_free(void *p, bool registered) {
+  if (!p) return;
+  if (registered) { (void)hipHostUnregister(p); free(p); }
+  else (void)hipHostFree(p);
+}
+
 RoctxRange::RoctxRange(const char *name) : on_(roctx().push != nullptr) { if (on_) roctx().push(name); }
 RoctxRange::~RoctxRange() { if (on_) roctx().pop(); }
 }  // namespace bce
@@ -266,8 +307,8 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   k4_prepin_join(c, true);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   if (c->h_small) (void)hipHostFree(c->h_small);
-  if (c->h_big) (void)hipHostFree(c->h_big);
-  for (void *q : c->dec_pin) if (q) (void)hipHostFree(q);
+  if (c->h_big) big_host_free(c->h_big, c->h_big_registered);
+  for (int i = 0; i < 3; ++i) if (c->dec_pin[i]) big_host_free(c->dec_pin[i], c->dec_pin_reg[i]);
   if (c->h_runs) (void)hipHostFree(c->h_runs);
   if (c->h_truns) (void)hipHostFree(c->h_truns);
   if (c->coder) c->coder->drain();

@@ -146,8 +146,10 @@ struct bce_hip_ctx {
   void *h_small = nullptr;                       // 4 KB of pinned host memory for read_back()
   void *h_big = nullptr;                         // pinned host memory for the decoder's host tail (the boundary ranks: 32 (n + 1) bytes), grow-only
   size_t h_big_cap = 0;
+  bool h_big_registered = false;                 // h_big came from big_host_alloc's malloc + hipHostRegister
   void *dec_pin[3] = {nullptr, nullptr, nullptr};  // the decoder's pinned query / escape-record / answer buffers, kept from one decode to the next (grow-only)
   size_t dec_pin_cap[3] = {0, 0, 0};
+  bool dec_pin_reg[3] = {false, false, false};   // (which kind: big_host_alloc)
   bce::FlushSlot slot[3];                        // flushes in flight: GPU fills one while the coders drain the others
   int slot_next = 0;
 
@@ -174,6 +176,15 @@ namespace bce {
 inline double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+
+// Pinned host memory of the decoder (the boundary ranks of the host tail, which the host reads at random; the query / answer
+// buffers the kernels and the host coders exchange): plain memory aligned to 2 MB with transparent huge pages asked for,
+// touched, then registered with the runtime (hipHostRegister, mapped: the device address is the host's, or the buffer is given
+// up).  Measured: 3.2 GB this way take 0.04 s beside running kernels; hipHostMalloc of the same takes
+// 0.55-0.7 s and holds the kernels queued meanwhile up.  BCE_DEC_NO_HUGE=1: hipHostMalloc (coherent, mapped) as before.
+// big_host_free gives either kind back.
+void *big_host_alloc(size_t bytes, int device, bool *registered);
+void big_host_free(void *p, bool registered);
 
 inline int set_err(bce_hip_ctx *c, hipError_t e, const char *what, int line) {
   snprintf(c->err, sizeof c->err, "%s:%d: %s", what, line, hipGetErrorString(e));

@@ -1314,25 +1314,30 @@ struct QueryPool {
 struct Pinned {
   void *p = nullptr;
   size_t cap = 0;
+  bool registered = false;      // big_host_alloc's malloc + hipHostRegister (else hipHostMalloc)
   void **keep_p = nullptr;      // where the buffer lives on after this object (a slot of the context), if anywhere
   size_t *keep_cap = nullptr;
+  bool *keep_reg = nullptr;
   Pinned() = default;
-  Pinned(void **kp, size_t *kc) : p(*kp), cap(*kc), keep_p(kp), keep_cap(kc) {}
+  Pinned(void **kp, size_t *kc, bool *kr) : p(*kp), cap(*kc), registered(*kr), keep_p(kp), keep_cap(kc), keep_reg(kr) {}
   Pinned(const Pinned &) = delete;
   Pinned &operator=(const Pinned &) = delete;
   int ensure(bce_hip_ctx *c, size_t bytes, size_t least = (size_t)16 << 20) {
     if (bytes <= cap) return BCE_HIP_OK;
-    size_t want = 2 * cap > bytes ? 2 * cap : bytes;          // pinning is slow (~0.15 s per GB): grow geometrically
-    if (p) (void)hipHostFree(p);
+    size_t want = 2 * cap > bytes ? 2 * cap : bytes;          // pinning is not free: grow geometrically
+    if (p) big_host_free(p, registered);
     p = nullptr; cap = 0;
     if (want < least) want = least;
-    BCE_HIP_TRY(c, hipHostMalloc(&p, want, hipHostMallocCoherent | hipHostMallocMapped));   // the wave tail kernel reads answers written while it runs
+    const double t0 = now_s();
+    p = big_host_alloc(want, c->device, &registered);         // host-coherent and mapped: the wave tail kernel reads answers written while it runs
+    if (!p) { snprintf(c->err, sizeof c->err, "decode: no pinned memory (%zu bytes)", want); return BCE_HIP_E_NOMEM; }
+    c->pin_s += now_s() - t0; c->pin_bytes += want; c->pin_calls++;
     cap = want;
     return BCE_HIP_OK;
   }
   ~Pinned() {
-    if (keep_p) { *keep_p = p; *keep_cap = cap; }
-    else if (p) (void)hipHostFree(p);
+    if (keep_p) { *keep_p = p; *keep_cap = cap; *keep_reg = registered; }
+    else if (p) big_host_free(p, registered);
   }
 };
 
@@ -1392,7 +1397,7 @@ struct BigPin {
   std::thread th;
   void *p = nullptr;
   size_t bytes = 0;
-  hipError_t err = hipSuccess;
+  bool registered = false;
   bool running = false;
   double t_start = 0, t_done = 0;
   void start(bce_hip_ctx *ctx, size_t want) {
@@ -1401,7 +1406,7 @@ struct BigPin {
     const int dev = ctx->device;
     try {
       t_start = now_s();
-      th = std::thread([this, dev] { err = hipSetDevice(dev); if (err == hipSuccess) err = hipHostMalloc(&p, bytes, hipHostMallocDefault); t_done = now_s(); });
+      th = std::thread([this, dev] { p = big_host_alloc(bytes, dev, &registered); t_done = now_s(); });
       running = true;
     } catch (...) { running = false; }                        // (no thread: dec_host_tail allocates as before)
   }
@@ -1411,9 +1416,9 @@ struct BigPin {
     th.join();
     running = false;
     if (getenv("BCE_DEC_TIMING")) fprintf(stderr, "gpu decode: pinned %.1f GB beside the rounds: %.3f s, the tail waited %.3f s of them\n", bytes / 1e9, t_done - t_start, now_s() - t0);
-    if (err == hipSuccess && p) {
-      if (c->h_big) (void)hipHostFree(c->h_big);
-      c->h_big = p; c->h_big_cap = bytes; p = nullptr;
+    if (p) {
+      if (c->h_big) big_host_free(c->h_big, c->h_big_registered);
+      c->h_big = p; c->h_big_cap = bytes; c->h_big_registered = registered; p = nullptr;
     }
   }
   ~BigPin() { settle(); }
@@ -1441,8 +1446,9 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
   // 3.2 GB at 10^8 bytes: into pinned memory the context keeps (a copy into fresh pageable memory ran at a fifth of the bus)
   const double tcp0 = now_s();
   if (c->h_big_cap < 8 * stride * 4) {
-    if (c->h_big) { (void)hipHostFree(c->h_big); c->h_big = nullptr; c->h_big_cap = 0; }
-    BCE_HIP_TRY(c, hipHostMalloc(&c->h_big, 8 * stride * 4, hipHostMallocDefault));
+    if (c->h_big) { big_host_free(c->h_big, c->h_big_registered); c->h_big = nullptr; c->h_big_cap = 0; }
+    c->h_big = big_host_alloc(8 * stride * 4, c->device, &c->h_big_registered);
+    if (!c->h_big) { snprintf(c->err, sizeof c->err, "host tail: no pinned memory for the boundary ranks"); return BCE_HIP_E_NOMEM; }
     c->h_big_cap = 8 * stride * 4;
   }
   uint32_t *Rh = static_cast<uint32_t *>(c->h_big);
@@ -1707,7 +1713,8 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   BCE_HIP_TRY(c, hipMemcpyAsync(c->ctl.p, &ctl, sizeof ctl, hipMemcpyHostToDevice, c->stream));
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
   // (query, escape-record and answer buffers stay with the context: pinning their ~150 MB anew was 0.05 s of every decode)
-  Pinned pin_info, pin_q(&c->dec_pin[0], &c->dec_pin_cap[0]), pin_e(&c->dec_pin[1], &c->dec_pin_cap[1]), pin_res(&c->dec_pin[2], &c->dec_pin_cap[2]);
+  Pinned pin_info, pin_q(&c->dec_pin[0], &c->dec_pin_cap[0], &c->dec_pin_reg[0]), pin_e(&c->dec_pin[1], &c->dec_pin_cap[1], &c->dec_pin_reg[1]),
+         pin_res(&c->dec_pin[2], &c->dec_pin_cap[2], &c->dec_pin_reg[2]);
   struct Events {
     hipEvent_t e[8] = {};
     ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
@@ -2270,5 +2277,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
   BCE_HIP_TRY(c, hipGetLastError());
   if (timing) fprintf(stderr, "gpu decode: inverse BWT (%s, %u walkers) %.3f s\n", single_cycle ? "one cycle" : "periodic", m, now_s() - tp0);
+  if (timing) fprintf(stderr, "gpu decode: this context so far: device allocations %u calls %.1f MB %.3f s, pinned (query / answer buffers) %u calls %.1f MB %.3f s\n",
+                      c->alloc_calls, c->alloc_bytes / 1e6, c->alloc_s, c->pin_calls, c->pin_bytes / 1e6, c->pin_s);
   return BCE_HIP_OK;
 }

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -19,6 +20,8 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <memory>
+#include <new>
 #include <vector>
 
 #include "../../include/bce_hip.h"
@@ -254,6 +257,11 @@ int main(int argc, char **argv) {
     bce_hip_ctx *ctx0 = nullptr;
     int rc0 = use_gpu ? bce_hip_create(&ctx0, 0) : 0;
     reader.join();
+    const bool cli_timing = getenv("BCE_CLI_TIMING") != nullptr;
+    auto lap = [&](const char *what) {
+      if (cli_timing) fprintf(stderr, "cli: %-10s %.3f s\n", what, std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - start).count());
+    };
+    lap("create");
     if (adata.status == -1) { printf("Archive not found.\n"); if (ctx0) bce_hip_destroy(ctx0); return -1; }
     if (adata.status != 0 || adata.size() == 0) { printf("Could not read Archive.\n"); if (ctx0) bce_hip_destroy(ctx0); return -2; }
     // -d: GPU-assisted decoder (kd_decode.hip), needs the GPU like -c.  -ds (the reference's low-memory unbwt variant,
@@ -274,7 +282,26 @@ int main(int argc, char **argv) {
       blocks.emplace_back(0, adata.size());
     }
     int rc = 0;
-    std::vector<uint8_t> out;
+    // the output: plain memory, not value-initialised (a vector would write 10^8 zeroes first that the decoder overwrites)
+    // (2 MB-aligned with huge pages asked for, and its pages faulted in by the kernel -- MADV_POPULATE_WRITE leaves the
+    // contents alone -- on a thread beside the decoding: the last device-to-host copy lands in mapped memory)
+    struct FreeDeleter { void operator()(uint8_t *q) const { free(q); } };
+    std::unique_ptr<uint8_t, FreeDeleter> out;
+    std::thread prefault;
+    auto alloc_out = [&](size_t bytes) {
+      void *q = nullptr;
+      const size_t two_mb = (size_t)2 << 20, len = ((bytes ? bytes : 1) + two_mb - 1) & ~(two_mb - 1);
+      if (posix_memalign(&q, two_mb, len) != 0) q = nullptr;
+      out.reset(static_cast<uint8_t *>(q));
+      if (q) {
+        (void)madvise(q, len, MADV_HUGEPAGE);
+        try { prefault = std::thread([q, len] { (void)madvise(q, len, 23 /* MADV_POPULATE_WRITE */); }); } catch (...) {}
+      }
+      return q != nullptr;
+    };
+    struct JoinOnExit { std::thread &t; ~JoinOnExit() { if (t.joinable()) t.join(); } } join_prefault{prefault};
+    size_t out_size = 0;
+    bce_hip_ctx *keep = nullptr;                                   // the one-block context: given back after the file is written
     if (blocks.size() == 1) {
       uint64_t prog = 0;
       bce_hip_ctx *ctx = ctx0;
@@ -289,14 +316,16 @@ int main(int argc, char **argv) {
       size_t n = 0;
       rc = ctx ? bce_hip_decompress_device(ctx, ap, blocks[0].second, nullptr, 0, &n) : bce_hip_decompress(ap, blocks[0].second, nullptr, 0, &n);
       if (rc == 0) {
-        out.resize(n);
-        rc = ctx ? bce_hip_decompress_device(ctx, ap, blocks[0].second, out.data(), n, &n) : bce_hip_decompress(ap, blocks[0].second, out.data(), n, &n);
+        if (!alloc_out(n)) { printf("Could not read Archive.\n"); if (ctx) bce_hip_destroy(ctx); return -2; }
+        out_size = n;
+        rc = ctx ? bce_hip_decompress_device(ctx, ap, blocks[0].second, out.get(), n, &n) : bce_hip_decompress(ap, blocks[0].second, out.get(), n, &n);
       }
       if (ctx) {
         progress_end();
-        if (rc != 0) printf("%s\n", bce_hip_last_error(ctx));
-        bce_hip_destroy(ctx);
+        if (rc != 0) { printf("%s\n", bce_hip_last_error(ctx)); bce_hip_destroy(ctx); }
+        else keep = ctx;
       }
+      lap("decoded");
     } else {
       // a container: the blocks are independent, their sizes are in the table -- decoded side by side, two contexts per GPU
       // (a block's decoding is mostly its eight sequential range decoders on the host) or, for -ds, up to 8 host threads
@@ -314,12 +343,8 @@ int main(int argc, char **argv) {
         }
         at[b + 1] = at[b] + (size_t)raw;
       }
-      try {
-        out.resize(at.back());
-      } catch (const std::exception &) {
-        printf("Could not read Archive.\n");
-        return -2;
-      }
+      if (!alloc_out(at.back())) { printf("Could not read Archive.\n"); return -2; }
+      out_size = at.back();
       std::vector<bce_hip_ctx *> ctxs;
       if (use_gpu) {
         int ndev = 0;
@@ -349,8 +374,8 @@ int main(int argc, char **argv) {
             const uint8_t *ap = adata.data() + blocks[b].first;
             size_t n = 0;
             const size_t want = at[b + 1] - at[b];
-            int r = c ? bce_hip_decompress_device(c, ap, blocks[b].second, out.data() + at[b], want, &n)
-                      : bce_hip_decompress(ap, blocks[b].second, out.data() + at[b], want, &n);
+            int r = c ? bce_hip_decompress_device(c, ap, blocks[b].second, out.get() + at[b], want, &n)
+                      : bce_hip_decompress(ap, blocks[b].second, out.get() + at[b], want, &n);
             if (r == 0 && n != want) r = BCE_HIP_E_INTERNAL;       // the table and the block's own header disagree
             if (r != 0) { int z = 0; first_rc.compare_exchange_strong(z, r); }
           }
@@ -362,11 +387,14 @@ int main(int argc, char **argv) {
     if (rc != 0) { printf("Decompression failed: %s\n", bce_hip_strerror(rc)); return -4; }
     auto end = std::chrono::high_resolution_clock::now();
     std::chrono::duration<double> duration = end - start;
-    printf("Decompressed from %zu B -> %zu B in %.1f s\n", adata.size(), out.size(), duration.count());
+    printf("Decompressed from %zu B -> %zu B in %.1f s\n", adata.size(), out_size, duration.count());
     std::ofstream file(std::string(argv[2]), std::ios::binary | std::ios::trunc);
-    file.write(reinterpret_cast<const char *>(out.data()), (std::streamsize)out.size());
+    file.write(reinterpret_cast<const char *>(out.get()), (std::streamsize)out_size);
     file.close();
+    lap("written");
+    if (prefault.joinable()) prefault.join();
     fast_exit(0);
+    if (keep) bce_hip_destroy(keep);
     return 0;
   } else if (argc == 4 && argv[1][0] == '-' && argv[1][1] == 's') {
     // Scan (bce.cpp:1384-1402): enumeration on the GPU, ScanCoder optimisation on the host, 288-byte config out
