@@ -106,7 +106,7 @@ int check_stage(bce_hip_ctx *c, int need) {
 // Between PROCESSES (two `bce -c` on one GPU, a pool beside another program's context) the same rule is kept by an
 // advisory file lock per device, keyed by the PCI address (/dev/shm/bce_hip_gate_<bdf>, flock): taken after the
 // in-process gate, given back with it.  A box without /dev/shm (or without permission) runs without the file lock.
-struct DeviceGate { std::mutex mu; std::condition_variable cv; bool busy = false; int fd = -2; };
+struct DeviceGate { std::mutex mu; std::condition_variable cv; bool busy = false; int waiting = 0; int fd = -2; };
 DeviceGate &device_gate(int device) {
   static DeviceGate gates[64];
   return gates[device >= 0 && device < 64 ? device : 0];
@@ -128,14 +128,19 @@ int gate_file(DeviceGate &g, int device) {          // (called with the in-proce
 void gate_acquire(bce_hip_ctx *c) {
   if (!c->gated || c->gate_held) return;
   DeviceGate &g = device_gate(c->device);
+  const double tw0 = now_s();
   {
     std::unique_lock<std::mutex> lk(g.mu);
+    ++g.waiting;
     g.cv.wait(lk, [&] { return !g.busy; });
+    --g.waiting;
     g.busy = true;
   }
   const int fd = gate_file(g, c->device);
   if (fd >= 0) while (flock(fd, LOCK_EX) != 0 && errno == EINTR) {}
   c->gate_held = true;
+  c->gate_t0 = now_s();
+  c->gate_wait_s += c->gate_t0 - tw0;
 }
 void gate_release(bce_hip_ctx *c) {
   if (!c->gate_held) return;
@@ -143,7 +148,34 @@ void gate_release(bce_hip_ctx *c) {
   if (g.fd >= 0) (void)flock(g.fd, LOCK_UN);
   { std::lock_guard<std::mutex> lk(g.mu); g.busy = false; }
   c->gate_held = false;
+  c->gate_held_s += now_s() - c->gate_t0;
   g.cv.notify_one();
+}
+// Another context of this process waits for the gate (contexts of other processes, behind the file lock, are not seen).
+bool gate_contended(bce_hip_ctx *c) {
+  DeviceGate &g = device_gate(c->device);
+  std::lock_guard<std::mutex> lk(g.mu);
+  return g.waiting > 0;
+}
+// The gate is for the enumeration's kernels (the one-launch rounds spin on tiles of their own grid); the model's kernels wait
+// for nothing, so a context whose rounds have all ended (every batch ends with a sync on the control block) and whose model
+// flush is queued LENDS the gate to a context that waits for it, and takes it back -- once its flush's kernels are through,
+// so that it does not hold the gate over kernels that do not need it -- before it queues its next round (gate_regain).
+// Measured, three contexts on text: the gate was held 42-71 ms per input (K3 13-20 ms + the flushes' 18 ms of kernels + what the
+// contexts cost each other) and the step of the stream was 60 ms.  BCE_HIP_NO_GATE_LEND=1: as before.
+void gate_lend(bce_hip_ctx *c) {
+  static const bool no_lend = getenv("BCE_HIP_NO_GATE_LEND") != nullptr;
+  if (no_lend || !c->gate_held || !gate_contended(c)) return;
+  gate_release(c);
+  c->gate_lent = true;
+}
+int gate_regain(bce_hip_ctx *c) {
+  if (!c->gate_lent) return BCE_HIP_OK;
+  c->gate_lent = false;
+  BCE_HIP_TRY(c, hipEventSynchronize(c->ev_k4));
+  gate_acquire(c);
+  BCE_HIP_TRY(c, hipSetDevice(c->device));
+  return BCE_HIP_OK;
 }
 // a stage that failed gives the gate back: the caller will not get to the point where encode does
 int gate_on_error(bce_hip_ctx *c, int status) {
@@ -224,6 +256,7 @@ int flush_symbols(bce_hip_ctx *c, uint64_t nsym) {
     c->coder->submit(&slot.batch);
     c->stats.flushes++;
     c->stats.symbols += nsym;
+    gate_lend(c);
   }
   return k3_reset_symbols(c);
 }
@@ -557,6 +590,8 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
 int bce_hip_encode(bce_hip_ctx *c) { return gate_on_error(c, bce_guarded(c, [&] { return encode_body(c); })); }
 static int encode_body(bce_hip_ctx *c) {
   BCE_TRY(check_stage(c, 3));
+  c->gate_wait_s = 0; c->gate_held_s = 0; c->gate_lent = false;
+  const double t_enc0 = now_s();
   gate_acquire(c);
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t n = c->n;
@@ -571,6 +606,9 @@ static int encode_body(bce_hip_ctx *c) {
   EnumCtl ctl;
   BCE_TRY(enumerate_body(c, ctl, [&](uint64_t nsym) { return flush_symbols(c, nsym); }));
   gate_release(c);                               // the GPU phase is over (the last flush and its copy are queued): next context
+  c->gate_lent = false;
+  static const bool gate_timing = getenv("BCE_HIP_GATE_TIMING") != nullptr;
+  const double t_gpu_done = now_s();
   {
     const double tw = now_s();
     c->coder->drain();                           // coding of the last batches (the exposed part)
@@ -585,6 +623,10 @@ static int encode_body(bce_hip_ctx *c) {
   c->enum_active = false;
   c->stage = 4;
   c->stats.t_enum = c->stats.k3_ms * 1e-3;      // GPU time of the enumeration; K4, copies and coding overlap it and each other
+  if (gate_timing)
+    fprintf(stderr, "gate: ctx %p waited %.1f ms, held %.1f ms of %.1f ms from encode's start to its last flush queued (K3 %.1f ms, model %.1f ms, %llu flushes); coders' tail %.1f ms\n",
+            (void *)c, c->gate_wait_s * 1e3, c->gate_held_s * 1e3, (t_gpu_done - t_enc0) * 1e3, c->stats.k3_ms, c->stats.t_model * 1e3,
+            (unsigned long long)c->stats.flushes, (now_s() - t_gpu_done) * 1e3);
   return BCE_HIP_OK;
 }
 
@@ -624,12 +666,14 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
     return fit;
   };
   for (;;) {
+    BCE_TRY(gate_regain(c));                       // (lent to another context behind the last model flush)
     if (have_ctl && decaying && !ctl.need_flush && ctl.done_round == 0xFFFFFFFFu) {
       // few live nodes and almost everything visited: finish depth-first (k3_dfs.hip).  The walkers' symbols
       // come after everything emitted so far, so flush that first.
       const uint64_t all = 8ull * (n - 1);
       if (dfs_try < 2 && ctl.next_nodes && ctl.next_nodes <= kDfsEnter[dfs_try] && (ctl.nodes_total >= all / 8 || c->round >= 1024u || c->dbg_tail_round)) {
         BCE_TRY(sink(ctl.sym_total));
+        BCE_TRY(gate_regain(c));
         ctl.sym_total = 0;
         bool dfs_done = false;
         BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));

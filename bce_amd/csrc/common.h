@@ -93,6 +93,8 @@ struct bce_hip_ctx {
   bool overlap = false;
   bool gated = true;                             // bce_hip_set_gated: the enumerations of one device's contexts take turns (default on)
   bool gate_held = false;
+  bool gate_lent = false;                        // given to a waiting context behind a model flush (api.hip: gate_lend / gate_regain)
+  double gate_t0 = 0, gate_wait_s = 0, gate_held_s = 0;   // (BCE_HIP_GATE_TIMING: seconds this compression waited for / held the device gate)
   uint32_t flush_seq = 0;                        // flushes issued by this context (parity selects ev_k4_done)
   hipEvent_t copy_busy = nullptr;                // last copy out of `sout` (the next K4 must not overwrite it earlier)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_k4 = nullptr;

@@ -87,7 +87,7 @@ static void put_u32(std::vector<uint8_t> &v, uint32_t x) { for (int i = 0; i < 4
 static void put_u64(std::vector<uint8_t> &v, uint64_t x) { for (int i = 0; i < 8; ++i) v.push_back((uint8_t)(x >> (8 * i))); }
 static uint64_t get_le(const uint8_t *p, int bytes) { uint64_t x = 0; for (int i = 0; i < bytes; ++i) x |= (uint64_t)p[i] << (8 * i); return x; }
 
-// `bce -cN`: N contiguous blocks over the GPUs of the node.  With more blocks than GPUs every device gets up to three
+// `bce -cN`: N contiguous blocks over the GPUs of the node.  With more blocks than GPUs every device gets up to four
 // gated contexts (bce_hip_set_gated), one host thread each: their GPU phases take turns while the coder threads of the
 // context that has just left the GPU finish its block.  Blocks are handed out in order to whichever context is free.
 static int compress_blocks(const HostFile &data, uint32_t nblocks, const uint8_t *config, std::vector<uint8_t> &out) {
@@ -101,7 +101,7 @@ static int compress_blocks(const HostFile &data, uint32_t nblocks, const uint8_t
     if (ctx.size() >= nblocks) break;
   }
   if (ctx.empty()) return -3;
-  const size_t per_dev = std::min<size_t>(3, (nblocks + (size_t)ndev - 1) / (size_t)ndev);
+  const size_t per_dev = std::min<size_t>(4, (nblocks + (size_t)ndev - 1) / (size_t)ndev);
   for (size_t extra = 1; extra < per_dev; ++extra)
     for (int dev = 0; dev < ndev && ctx.size() < nblocks; ++dev) {
       bce_hip_ctx *c = nullptr;

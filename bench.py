@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=48 << 20, help="bytes of the workload the CPU baseline compresses")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-stream", action="store_true", help="skip the two-context stream leg (N=1 only)")
-    ap.add_argument("--stream-contexts", type=int, default=3, help="contexts of the stream leg")
+    ap.add_argument("--stream-contexts", type=int, default=4, help="contexts of the stream leg")
     ap.add_argument("--stream-steps", type=int, default=0, help="inputs of the stream leg (default: max(12, --steps); 12 for the extra workloads)")
     ap.add_argument("--no-decode", action="store_true", help="skip the untimed decode-and-compare leg (N=1 only)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (H2D inside) leg")
