@@ -775,6 +775,14 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
       else est_syms = recent_syms[(recent_at - 1u) & 7u];
     }
     if (c->progress) c->progress(ctl.nodes_total, 8ull * n, c->progress_user);
+    {
+      static const bool plane_trace = getenv("BCE_HIP_PLANE_TRACE") != nullptr;
+      if (plane_trace) {
+        fprintf(stderr, "round %u: %u nodes next, k3 %.2f ms so far; per plane:", c->round, ctl.next_nodes, c->stats.k3_ms);
+        for (int p = 0; p < 8; ++p) fprintf(stderr, " %u", ctl.cnt[c->round & 1u][p][0] + ctl.cnt[c->round & 1u][p][1]);
+        fprintf(stderr, "\n");
+      }
+    }
     decaying = ctl.next_nodes <= cur_nodes && c->round > 16;   // past the ramp-up: the node count no longer doubles
     if (c->dbg_tail_round && c->round >= c->dbg_tail_round) decaying = true;   // test knob 10: the tail starts while the count still grows
     have_ctl = true;

@@ -1586,11 +1586,16 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
   const bool tail_timing = getenv("BCE_DEC_TIMING") != nullptr;
   uint32_t rounds = 0, serial_run = 0;
   auto unpark = [&] { { std::lock_guard<std::mutex> lk(pool.mu); pool.parked.store(false); } pool.cv.notify_all(); };
-  for (bool again = true; again && !bad_flag.load();) {
+  // `live`: the planes that have nodes this round.  The chains of the deep tail are a node or two in one or two planes for
+  // hundreds of thousands of rounds: such a round touches those planes' lists only (a round over all eight planes' sixteen
+  // lists, empty or not, cost more than its two nodes).
+  uint32_t live = 0;
+  for (uint32_t i = 0; i < 8; ++i) if (!cur[i][0].empty() || !cur[i][1].empty()) live |= 1u << i;
+  while (live && !bad_flag.load(std::memory_order_relaxed)) {
     size_t tot = 0;
-    for (int i = 0; i < 8; ++i) tot += cur[i][0].size() + cur[i][1].size();
-    const double tr0 = tail_timing ? now_s() : 0.0;
+    for (uint32_t m = live; m; m &= m - 1) { const int i = __builtin_ctz(m); tot += cur[i][0].size() + cur[i][1].size(); }
     const bool par_round = threaded && tot >= kParMin;
+    const double tr0 = tail_timing && (par_round || (rounds & 63u) == 0) ? now_s() : 0.0;
     if (par_round) {
       if (pool.parked.load(std::memory_order_relaxed)) unpark();
       serial_run = 0;
@@ -1600,18 +1605,26 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
       while (pool.done.load(std::memory_order_acquire) < 7u) __builtin_ia32_pause();
       ++par_rounds;
     } else {
-      for (uint32_t i = 0; i < 8 && !bad_flag.load(std::memory_order_relaxed); ++i) do_plane(i);
+      for (uint32_t m = live; m && !bad_flag.load(std::memory_order_relaxed); m &= m - 1) do_plane((uint32_t)__builtin_ctz(m));
       if (threaded && ++serial_run == kParkAfter) pool.parked.store(true, std::memory_order_release);
     }
-    if (tail_timing) { const double d = now_s() - tr0; if (par_round) { par_time += d; par_nodes += tot; } else { ser_time += d; ser_nodes += tot; } }
+    if (tail_timing) {                                                     // (serial rounds: one in 64 is timed -- the clock costs as much as the round)
+      if (par_round) { par_time += now_s() - tr0; par_nodes += tot; }
+      else { if ((rounds & 63u) == 0) ser_time += 64.0 * (now_s() - tr0); ser_nodes += tot; }
+    }
     ++rounds;
-    again = false;
-    for (int i = 0; i < 8; ++i) {                                          // plane i's children are plane i + 1's nodes
-      const int q = (i + 1) & 7;
+    uint32_t next_live = 0;
+    for (uint32_t m = live; m; m &= m - 1) {                               // plane i's children are plane i + 1's nodes
+      const int i = __builtin_ctz(m), q = (i + 1) & 7;
       cur[q][0].swap(po[i].o0); po[i].o0.clear();
       cur[q][1].swap(po[i].o1); po[i].o1.clear();
-      if (!cur[q][0].empty() || !cur[q][1].empty()) again = true;
+      if (!cur[q][0].empty() || !cur[q][1].empty()) next_live |= 1u << q;
     }
+    for (uint32_t m = live; m; m &= m - 1) {                               // a plane that was worked on and got nothing new
+      const int q = __builtin_ctz(m);
+      if (!((live >> ((q + 7) & 7)) & 1u)) { cur[q][0].clear(); cur[q][1].clear(); }
+    }
+    live = next_live;
   }
   { std::lock_guard<std::mutex> lk(pool.mu); pool.quit.store(true, std::memory_order_release); }
   pool.cv.notify_all();
