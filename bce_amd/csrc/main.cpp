@@ -21,6 +21,7 @@
 #include <atomic>
 #include <thread>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -122,6 +123,13 @@ static int compress_blocks(const HostFile &data, uint32_t nblocks, const uint8_t
   std::vector<int> rcs(ctx.size(), 0);
   std::atomic<uint32_t> next_block{0};
   std::atomic<bool> failed{false};
+  // A context that runs out of device memory (four contexts of a device and blocks of hundreds of MB: a context needs ~180
+  // bytes per input byte) gives its memory back and leaves its block for later: what is left over is compressed at the end by
+  // one context that has the device to itself.  Only a block that does not fit even then fails.
+  std::mutex deferred_mu;
+  std::vector<uint32_t> deferred;
+  const char *test_nomem = getenv("BCE_CLI_TEST_NOMEM_BLOCK");      // (test hook: this block's first attempt "runs out of memory")
+  const long test_block = test_nomem ? atol(test_nomem) : -1;
   std::vector<std::thread> th;
   for (size_t d = 0; d < ctx.size(); ++d)
     th.emplace_back([&, d] {
@@ -129,15 +137,40 @@ static int compress_blocks(const HostFile &data, uint32_t nblocks, const uint8_t
         const uint32_t b = next_block.fetch_add(1);
         if (b >= nblocks) break;
         size_t alen = 0;
-        int rc = bce_hip_compress(ctx[d], data.data() + lo[b], (uint32_t)(lo[b + 1] - lo[b]), nullptr, 0, &alen);
+        int rc = ((long)b == test_block) ? BCE_HIP_E_NOMEM
+                                         : bce_hip_compress(ctx[d], data.data() + lo[b], (uint32_t)(lo[b + 1] - lo[b]), nullptr, 0, &alen);
         if (rc == 0) { arch[b].resize(alen); rc = bce_hip_archive_copy(ctx[d], arch[b].data(), alen); }
+        if (rc == BCE_HIP_E_NOMEM) {
+          { std::lock_guard<std::mutex> lk(deferred_mu); deferred.push_back(b); }
+          bce_hip_destroy(ctx[d]);
+          ctx[d] = nullptr;
+          return;
+        }
         if (rc) { rcs[d] = rc; failed.store(true); break; }
       }
       (void)bce_hip_set_gated(ctx[d], 1);                           // (gives the gate back if a failed stage left it held)
     });
   for (auto &t : th) t.join();
   int rc = 0;
-  for (size_t d = 0; d < ctx.size(); ++d) { if (rcs[d] && !rc) { rc = rcs[d]; printf("%s\n", bce_hip_last_error(ctx[d])); } bce_hip_destroy(ctx[d]); }
+  for (size_t d = 0; d < ctx.size(); ++d) {
+    if (!ctx[d]) continue;
+    if (rcs[d] && !rc) { rc = rcs[d]; printf("%s\n", bce_hip_last_error(ctx[d])); }
+    bce_hip_destroy(ctx[d]);
+  }
+  if (!rc && !deferred.empty()) {
+    std::sort(deferred.begin(), deferred.end());
+    bce_hip_ctx *c = nullptr;
+    rc = bce_hip_create(&c, 0);
+    if (rc == 0 && config) rc = bce_hip_set_config(c, config);
+    for (size_t i = 0; rc == 0 && i < deferred.size(); ++i) {
+      const uint32_t b = deferred[i];
+      size_t alen = 0;
+      rc = bce_hip_compress(c, data.data() + lo[b], (uint32_t)(lo[b + 1] - lo[b]), nullptr, 0, &alen);
+      if (rc == 0) { arch[b].resize(alen); rc = bce_hip_archive_copy(c, arch[b].data(), alen); }
+    }
+    if (rc && c) printf("%s\n", bce_hip_last_error(c));
+    if (c) bce_hip_destroy(c);
+  }
   if (rc) return rc;
   out.clear();
   out.insert(out.end(), {'B', 'C', 'E', 'M'});

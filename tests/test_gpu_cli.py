@@ -81,8 +81,24 @@ def test_cli_block_container(tmp_path):
         assert r.returncode == 0 and out.read_bytes() == data
 
 
+def test_cli_block_that_ran_out_of_memory_is_compressed_at_the_end(tmp_path):
+    """A context of `bce -cN` that runs out of device memory gives its memory back and leaves its block to one context that
+    has the device to itself at the end (main.cpp compress_blocks; BCE_CLI_TEST_NOMEM_BLOCK makes block 2's first attempt
+    fail that way): the container is the one an undisturbed run writes."""
+    import os
+    data = oracle.synth_text(17, 700003)
+    src, a1, a2 = tmp_path / "in.txt", tmp_path / "a1.bcem", tmp_path / "a2.bcem"
+    src.write_bytes(data)
+    r = subprocess.run([EXE, "-c5", str(a1), str(src)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([EXE, "-c5", str(a2), str(src)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, BCE_CLI_TEST_NOMEM_BLOCK="2"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert a1.read_bytes() == a2.read_bytes()
+
+
 def test_cli_many_blocks_on_few_gpus(tmp_path):
-    """`bce -c11` on a box with fewer GPUs than blocks: up to three gated contexts per device take the blocks in turn
+    """`bce -c11` on a box with fewer GPUs than blocks: up to four gated contexts per device take the blocks in turn
     (main.cpp compress_blocks); every block is still exactly `bce -c` of its bytes, whichever context coded it."""
     from bce_amd import container, sharding
     data = oracle.synth_text(16, 1300003)
