@@ -97,8 +97,11 @@ def test_old_sorter_agrees(monkeypatch):
     assert new == old
 
 
-def test_rank_scatters_as_sorts_on_small_inputs():
-    """Above 2^27 elements K1 writes its ranks by SORTING the (destination, value) pairs instead of scattering them (10^9-byte
+@pytest.mark.parametrize("knob", [{"BCE_K1_PART_MIN": "0"}, {"BCE_K1_KEYBITS": "16"}, {"BCE_K1_KEYBITS": "24", "BCE_K1_PART_MIN": "0"}],
+                         ids=["sorted-scatters", "narrow-first-key", "both"])
+def test_rank_scatters_as_sorts_on_small_inputs(knob):
+    """(BCE_K1_KEYBITS: a first key of 16 / 24 bits instead of 64 leaves most of the order to the segmented and active rounds:
+    the same checks with many more of those.)  Above 2^27 elements K1 writes its ranks by SORTING the (destination, value) pairs instead of scattering them (10^9-byte
     inputs; k1_bwt.hip).  BCE_K1_PART_MIN=0 takes that form at every size: the same inputs as above -- alphabets, groups around
     the LDS limit (the deferred path's buffers are reused by the sort), periodic inputs -- and the libdivsufsort seam (T$: a
     sentinel as one more symbol) in a child process, each against the oracle."""
@@ -132,7 +135,7 @@ for t in (b"abracadabra", oracle.synth_text(6, 700001), b"ab" * 4000):
     assert pidx == wp and u.tobytes() == bytes(wu), len(t)
 print("SORTED_SCATTERS_OK")
 ''' % (os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."), os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-    env = dict(os.environ, BCE_K1_PART_MIN="0")
+    env = dict(os.environ, **knob)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env,
                        cwd=os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     assert r.returncode == 0 and "SORTED_SCATTERS_OK" in r.stdout, r.stderr[-3000:]
