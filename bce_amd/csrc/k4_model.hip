@@ -103,6 +103,9 @@ __device__ __forceinline__ uint64_t k4_replay(const K4Args &a, uint64_t pos, uin
                                               uint32_t k, uint32_t &C, volatile uint32_t *cb, uint32_t lane,
                                               uint64_t ltm) {
   if (limit > a.nsym) limit = a.nsym;
+  // the escape word of a record is looked up (a random 4-byte read per record: 38 B fetched per record when every record did
+  // it) only where there can be one: an escape halves k until it is <= 31 (pack_symbol), so what is left is >= 16
+  const bool esc_possible = k >= 16u;
   uint64_t j = pos + lane;
   uint32_t kk = j < limit ? a.keys[j] : 0xFFFFFFFFu;
   for (;;) {
@@ -133,7 +136,7 @@ __device__ __forceinline__ uint64_t k4_replay(const K4Args &a, uint64_t pos, uin
     const bool commit = lane < nc;
     if (commit) {
       const uint32_t cum = Ps + ltb + s, total = T + lane + k, freq = before + 1u;
-      a.out[idx] = pack_model_out(cum, freq, total, a.esc[idx]);
+      a.out[idx] = pack_model_out(cum, freq, total, esc_possible ? a.esc[idx] : 0u);
     }
     const uint64_t cm = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);
     C += k4_symbol_counts(s, eq, cm, commit, cb, lane);
