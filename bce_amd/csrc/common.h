@@ -218,6 +218,7 @@ inline int ensure(bce_hip_ctx *c, DevBuf &b, size_t bytes) {
   const double t0 = now_s();
   BCE_HIP_TRY(c, hipMalloc(&b.p, bytes));
   c->alloc_s += now_s() - t0; c->alloc_bytes += bytes; c->alloc_calls++;
+  if (now_s() - t0 > 0.02 && getenv("BCE_ALLOC_TRACE")) fprintf(stderr, "alloc: hipMalloc of %.1f MB took %.3f s\n", bytes / 1e6, now_s() - t0);
   b.cap = bytes;
   return BCE_HIP_OK;
 }
