@@ -32,7 +32,8 @@ class Stats(C.Structure):
                 ("sort_rounds", C.c_uint32), ("flushes", C.c_uint32), ("spine_levels", C.c_uint32),
                 ("t_load", C.c_double), ("t_bwt", C.c_double), ("t_planes", C.c_double), ("t_enum", C.c_double),
                 ("t_model", C.c_double), ("t_coder", C.c_double), ("t_total", C.c_double),
-                ("k3_ms", C.c_double), ("k3_launches", C.c_double), ("t_coder_busy", C.c_double)]
+                ("k3_ms", C.c_double), ("k3_launches", C.c_double), ("t_coder_busy", C.c_double),
+                ("list_grows", C.c_double), ("list_nodes", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -405,6 +405,7 @@ int bce_hip_debug_set(bce_hip_ctx *c, int knob, uint32_t value) {
     case 9: c->dbg_local_budget = value; break;
     case 10: c->dbg_tail_round = value; break;
     case 11: c->overlap = value != 0; break;
+    case 12: c->dbg_capp_div = value; break;
     case 2: c->dbg_no_tail = value; break;
     case 3: c->dbg_no_skip = value; break;
     default: return BCE_HIP_E_ARG;
@@ -540,7 +541,13 @@ int bce_hip_enum_round(bce_hip_ctx *c, uint64_t *next_nodes) {
   EnumCtl ctl;
   BCE_TRY(k3_sync_ctl(c, &ctl));
   if (ctl.stalled) { snprintf(c->err, sizeof c->err, "k3: a single-launch round waited too long for a predecessor tile (dispatch order not as assumed)"); return BCE_HIP_E_INTERNAL; }
-  if (ctl.overflow) return BCE_HIP_E_OVERFLOW;
+  if (ctl.overflow) {                              // larger lists, the same round again (as bce_hip_encode does)
+    BCE_TRY(k3_grow_lists(c, ctl));
+    if (c->dbg_step_small) BCE_TRY(k3_rounds_small(c, 1, K3_SMALL_NODES, false));
+    else BCE_TRY(k3_rounds(c, 1, 0));
+    BCE_TRY(k3_sync_ctl(c, &ctl));
+    if (ctl.overflow) return BCE_HIP_E_OVERFLOW;
+  }
   if (ctl.need_flush) return BCE_HIP_E_OVERFLOW;   // the stepping interface never flushes
   BCE_TRY(k3_fetch_runs(c, first, 1));
   c->round = first + 1;
@@ -727,7 +734,7 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
       BCE_TRY(k3_rounds_small(c, batch, cur_nodes, !decaying));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
       BCE_TRY(k3_sync_ctl(c, &ctl));
-      executed = (ctl.need_flush || ctl.small_bail) ? ctl.skip_round - first : batch;
+      executed = (ctl.need_flush || ctl.small_bail || ctl.overflow) ? ctl.skip_round - first : batch;
       BCE_TRY(k3_fetch_runs(c, first, executed));
       runs_fetched = true;
       if (ctl.small_bail) { BCE_TRY(k3_clear_small_bail(c)); wide_once = true; }
@@ -752,13 +759,12 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
       BCE_TRY(k3_rounds(c, batch, decaying ? cur_nodes : 0));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
       BCE_TRY(k3_sync_ctl(c, &ctl));
-      executed = ctl.need_flush ? ctl.skip_round - first : batch;
+      executed = (ctl.need_flush || ctl.overflow) ? ctl.skip_round - first : batch;
       BCE_TRY(k3_fetch_runs(c, first, executed));
       runs_fetched = true;
     }
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms; }
     if (ctl.stalled) { snprintf(c->err, sizeof c->err, "k3: a single-launch round waited too long for a predecessor tile (dispatch order not as assumed)"); return BCE_HIP_E_INTERNAL; }
-    if (ctl.overflow) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
     c->round = first + executed;
     if (executed && runs_fetched) {
       // what the last eight rounds emitted, each (h_runs holds this batch's run table: one entry per round and plane): the
@@ -773,6 +779,15 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
       est_syms = 0;
       if (decaying) { for (uint64_t v : recent_syms) est_syms = v > est_syms ? v : est_syms; }
       else est_syms = recent_syms[(recent_at - 1u) & 7u];
+    }
+    if (ctl.overflow && !ctl.stalled) {
+      // the round c->round does not fit the node lists (nothing of it was written): larger lists, the same round again
+      BCE_TRY(k3_grow_lists(c, ctl));
+      ctl.overflow = 0;
+      have_ctl = true;
+      cur_nodes = 0;
+      for (int p = 0; p < 8; ++p) cur_nodes += (uint64_t)ctl.cnt[c->round & 1u][p][0] + ctl.cnt[c->round & 1u][p][1];
+      continue;
     }
     if (c->progress) c->progress(ctl.nodes_total, 8ull * n, c->progress_user);
     {

@@ -110,7 +110,7 @@ struct bce_hip_ctx {
   bool k1_valid = false;                         // sa[sa_res] / rank hold this input's suffix order (K1 ran; no injected BWT)
   int sa_res = 0;
   // debug knobs (bce_hip_debug_set): 0 = default
-  uint32_t dbg_dfs_budget = 0, dbg_no_dfs = 0, dbg_no_tail = 0, dbg_no_skip = 0, dbg_no_small = 0, dbg_step_small = 0, dbg_no_fused = 0, dbg_no_local = 0, dbg_local_from = 0, dbg_local_budget = 0, dbg_tail_round = 0;
+  uint32_t dbg_dfs_budget = 0, dbg_no_dfs = 0, dbg_no_tail = 0, dbg_no_skip = 0, dbg_no_small = 0, dbg_step_small = 0, dbg_no_fused = 0, dbg_no_local = 0, dbg_capp_div = 0, dbg_local_from = 0, dbg_local_budget = 0, dbg_tail_round = 0;
   uint64_t sym_cap_user = 0;
   bool sync_flush = false;                       // BCE_HIP_SYNC_FLUSH: flushes wait for their copy (profiling)
   bce_hip_progress_fn progress = nullptr;        // bce_hip_set_progress
@@ -299,6 +299,7 @@ int k3_get_nodes(bce_hip_ctx *c, int plane, uint32_t *out, uint32_t cap, uint32_
 int k3_reset_symbols(bce_hip_ctx *c);               // after a flush: sym_total = 0, need_flush = 0
 int k3_grow_symbols(bce_hip_ctx *c, uint64_t cap);  // enlarge the (empty) symbol buffer, clear need_flush
 int k4_prepare(bce_hip_ctx *c);                     // k4_model.hip: counters to zero, cfg upload
+int k3_grow_lists(bce_hip_ctx *c, const EnumCtl &ctl);
 uint64_t k3_symbol_capacity(const bce_hip_ctx *c, uint32_t n);   // records between two model flushes for an input of n bytes
 void k4_prepin(bce_hip_ctx *c, uint32_t n);         // start pinning the flush slots' host staging for an input of n bytes (threads)
 void k4_prepin_join(bce_hip_ctx *c, bool drop);     // wait for those threads (drop: free what they pinned and nobody adopted)

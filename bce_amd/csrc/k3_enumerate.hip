@@ -304,7 +304,7 @@ __global__ __launch_bounds__(1024) void k3_scan_kernel(K3Args a) {
     curn += (uint64_t)s_cnt[q][0] + s_cnt[q][1];
     if ((uint64_t)pt[q][0] + pt[q][1] > a.capP) ovf = true;
   }
-  if (ovf) { ctl->overflow = 1; return; }
+  if (ovf) { ctl->overflow = 1; ctl->skip_round = a.round; return; }       // (the host grows the lists and runs the round again: k3_grow_lists)
   if (s_sym[0] + symsum > s_sym[1]) { ctl->need_flush = 1; ctl->skip_round = a.round; ctl->want_syms = symsum; return; }
   uint64_t acc = s_sym[0];
   for (uint32_t q = 0; q < 8; ++q) {
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(K3_T) void k3_count2_kernel(K3Args a) {
             if ((uint64_t)s_pt[q][0] + s_pt[q][1] > a.capP) ovf = true;
           }
           const uint64_t sym0 = ctl->sym_total;
-          if (ovf) ctl->overflow = 1;
+          if (ovf) { ctl->overflow = 1; ctl->skip_round = a.round; }
           else if (sym0 + symsum > ctl->sym_cap) { ctl->need_flush = 1; ctl->skip_round = a.round; ctl->want_syms = symsum; }
           else {
             uint64_t acc = sym0;
@@ -906,11 +906,12 @@ K3Args k3_make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot) {
   return a;
 }
 
-static uint32_t default_capP(bce_hip_ctx *c, uint32_t n) {
+// The largest lists this context may have for an input of n bytes.
+static uint32_t full_capP(bce_hip_ctx *c, uint32_t n) {
   // worst case is n/2 nodes per plane-round (disjoint intervals of width >= 2): text peaks at 0.06-0.09 n, random
-  // bytes at ~0.3 n.  All 16 lists (2 parities x 8 planes) get the worst case when it fits in 60 % of the HBM that is
+  // bytes at ~0.3 n.  All 16 lists (2 parities x 8 planes) can have the worst case when it fits in 60 % of the HBM that is
   // free now (K1's and K2's buffers are already allocated), at least 192 M nodes per list (36.9 GB) otherwise.  A round
-  // that overflows the lists ends the compression with BCE_HIP_E_OVERFLOW (loud, never a wrong archive): see the
+  // that overflows even those ends the compression with BCE_HIP_E_OVERFLOW (loud, never a wrong archive): see the
   // capacity note in include/bce_hip.h.
   const uint64_t worst = (uint64_t)n / 2 + 2;
   uint64_t soft = (uint64_t)192 << 20;
@@ -928,6 +929,67 @@ static uint32_t default_capP(bce_hip_ctx *c, uint32_t n) {
   return (uint32_t)(worst < soft ? worst : soft);
 }
 
+// What a compression STARTS with: n / 8 nodes per list (at n / 2 + 2, the worst case, the lists were 55 % of a context's 17.6 GB at
+// 10^8 bytes, twenty times what text ever fills; memory the driver has to clear before it hands it out -- 27 ms per GB whenever an earlier process has used
+// it), or whatever a buffer the context has already holds.  A round that does not fit is not run (the epilogue checks before
+// anything is written); the host doubles the lists, moves the current round's lists over and runs it again (k3_grow_lists).
+// BCE_HIP_CAPP_DIV=d / test knob 12: start with n / d + 4096 nodes per list.
+static uint32_t initial_capP(bce_hip_ctx *c, uint32_t n, uint32_t full) {
+  uint64_t div = 8;
+  bool forced = false;                                         // (a test asks for small lists: also in a context that holds larger ones)
+  if (c->dbg_capp_div) { div = c->dbg_capp_div; forced = true; }
+  if (const char *e = getenv("BCE_HIP_CAPP_DIV")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1) { div = v; forced = true; } }
+  uint64_t cap = (uint64_t)n / div + 4096;
+  const uint64_t held = c->nodes.cap / (16 * sizeof(Node));
+  if (held > cap && !forced) cap = held;
+  return (uint32_t)(cap < full ? cap : full);
+}
+
+// everything that is sized by the lists' capacity, for the capacity c->capP
+static int k3_size_tile_arrays(bce_hip_ctx *c) {
+  const size_t tiles = (size_t)8 * ((c->capP + K3_TILE - 1) / K3_TILE) + 8;
+  BCE_TRY(ensure(c, c->tilecnt, tiles * 16));
+  BCE_TRY(ensure(c, c->tileoff, tiles * 16));
+  // two-launch rounds: a count word per tile; per group of 256 tiles: two words and four offsets (32 B)
+  c->k3_groups = tiles / 256 + 16;
+  BCE_TRY(ensure(c, c->k3tw, tiles * 8));
+  BCE_TRY(ensure(c, c->k3grp, c->k3_groups * 32 + 64));
+  BCE_HIP_TRY(c, hipMemsetAsync(c->k3tw.p, 0, tiles * 8, c->stream));               // round tags of an earlier compression (or of whoever had the memory)
+  BCE_HIP_TRY(c, hipMemsetAsync(c->k3grp.p, 0, c->k3_groups * 32 + 64, c->stream));
+  return BCE_HIP_OK;
+}
+
+// A round found its children would not fit the lists (ctl.overflow, ctl.skip_round = c->round: nothing of it was written).
+// Twice the room (at most full_capP), the lists of the round's parity moved over -- child0 lists from the front, child1 lists
+// from the back --, the flag cleared: the caller queues the round again.  BCE_HIP_E_OVERFLOW when the lists are at their largest.
+int k3_grow_lists(bce_hip_ctx *c, const EnumCtl &ctl) {
+  const uint32_t full = full_capP(c, c->n);
+  if (c->capP >= full) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
+  const uint64_t want = (uint64_t)c->capP * 2;
+  const uint32_t ncap = (uint32_t)(want < full ? want : full);
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  DevBuf fresh;
+  BCE_TRY(ensure(c, fresh, (size_t)16 * ncap * sizeof(Node)));
+  const uint32_t par = c->round & 1u;
+  for (uint32_t p = 0; p < 8; ++p) {
+    const uint32_t c0 = ctl.cnt[par][p][0], c1 = ctl.cnt[par][p][1];
+    const Node *src = c->nodes.as<Node>() + (size_t)(par * 8u + p) * c->capP;
+    Node *dst = fresh.as<Node>() + (size_t)(par * 8u + p) * ncap;
+    if (c0) BCE_HIP_TRY(c, hipMemcpyAsync(dst, src, (size_t)c0 * sizeof(Node), hipMemcpyDeviceToDevice, c->stream));
+    if (c1) BCE_HIP_TRY(c, hipMemcpyAsync(dst + (ncap - c1), src + (c->capP - c1), (size_t)c1 * sizeof(Node), hipMemcpyDeviceToDevice, c->stream));
+  }
+  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  release(c->nodes);
+  c->nodes = fresh;
+  c->capP = ncap;
+  c->stats.list_grows += 1.0;
+  c->stats.list_nodes = ncap;
+  if (getenv("BCE_ALLOC_TRACE")) fprintf(stderr, "k3: round %u does not fit the node lists: %u -> %u nodes per list (n = %u)\n", c->round, (uint32_t)(want / 2), ncap, c->n);
+  BCE_TRY(k3_size_tile_arrays(c));
+  BCE_HIP_TRY(c, hipMemsetAsync(&c->ctl.as<EnumCtl>()->overflow, 0, sizeof(uint32_t), c->stream));
+  return BCE_HIP_OK;
+}
+
 uint64_t k3_symbol_capacity(const bce_hip_ctx *c, uint32_t n) {
   uint64_t cap = c->sym_cap_user;
   if (!cap) {
@@ -942,17 +1004,10 @@ uint64_t k3_symbol_capacity(const bce_hip_ctx *c, uint32_t n) {
 
 int k3_begin(bce_hip_ctx *c) {
   const uint32_t n = c->n;
-  c->capP = default_capP(c, n);
+  c->capP = initial_capP(c, n, full_capP(c, n));
+  c->stats.list_grows = 0; c->stats.list_nodes = c->capP;
   BCE_TRY(ensure(c, c->nodes, (size_t)16 * c->capP * sizeof(Node)));
-  const size_t tiles = (size_t)8 * ((c->capP + K3_TILE - 1) / K3_TILE) + 8;
-  BCE_TRY(ensure(c, c->tilecnt, tiles * 16));
-  BCE_TRY(ensure(c, c->tileoff, tiles * 16));
-  // two-launch rounds: a count word per tile; per group of 256 tiles: two words and four offsets (32 B)
-  c->k3_groups = tiles / 256 + 16;
-  BCE_TRY(ensure(c, c->k3tw, tiles * 8));
-  BCE_TRY(ensure(c, c->k3grp, c->k3_groups * 32 + 64));
-  BCE_HIP_TRY(c, hipMemsetAsync(c->k3tw.p, 0, tiles * 8, c->stream));               // round tags of an earlier compression
-  BCE_HIP_TRY(c, hipMemsetAsync(c->k3grp.p, 0, c->k3_groups * 32 + 64, c->stream));
+  BCE_TRY(k3_size_tile_arrays(c));
   BCE_TRY(ensure(c, c->ctl, sizeof(EnumCtl)));
   BCE_TRY(ensure(c, c->runs, (size_t)K3_MAXBATCH * 8 * sizeof(RunEntry)));
   if (!c->h_ctl) BCE_TRY(pin_alloc(c, &c->h_ctl, sizeof(EnumCtl)));

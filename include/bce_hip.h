@@ -73,18 +73,20 @@ int bce_hip_set_progress(bce_hip_ctx *ctx, bce_hip_progress_fn fn, void *user);
  * classifies per pass, 1 = disable the depth-first tail, 2 = disable the persistent LDS tail kernel, 3 = disable chain skipping, 4 = disable the one-launch kernel for narrow rounds, 6 = three launches per wide round (separate scan kernel) instead of two, 7 = disable the workgroup-local rounds before the depth-first tail,
  * 8 = live nodes below which the walkers take over from the workgroup-local rounds (default 16 384; the tail itself starts at 1 M live nodes with the local rounds, at 65 536 without them: BCE_HIP_DFS_ENTER), 9 = rounds a workgroup runs per pass before it hands on (default 192),
  * 10 = round from which the tail may start although the node count still grows (exercises the spill path),
- * 11 = model flushes (K4) on a stream of their own beside the next K3 rounds, double-buffered symbol records (also BCE_HIP_OVERLAP=1).
+ * 11 = model flushes (K4) on a stream of their own beside the next K3 rounds, double-buffered symbol records (also BCE_HIP_OVERLAP=1),
+ * 12 = d: the node lists start with n / d + 4096 nodes instead of n / 8 + 4096 (also BCE_HIP_CAPP_DIV=d; large d: the lists grow many times).
  * The archive never depends on them. */
 int bce_hip_debug_set(bce_hip_ctx *ctx, int knob, uint32_t value);
 
 /* ---- stage 0: input ---------------------------------------------------------------------------- */
 /* File::File (bce.cpp:842-856): take the n input bytes.  _host copies host->HBM, _device copies
  * HBM->HBM from a device pointer of the same GPU (input already resident). 1 <= n < 2^31.
- * Capacity: device memory is ~45 n bytes for the suffix sort and planes plus the enumeration's node lists, which hold
- * n/2 + 2 nodes per plane (the worst case) whenever 16 such lists fit in 60 % of the free HBM and a list stays below 4 GB
- * (357 M nodes) -- n <= ~7 * 10^8 on an otherwise idle 288 GB MI355X -- and 192 M to 357 M nodes per plane beyond that.  Text needs ~0.09 n nodes per plane,
- * random bytes ~0.3 n: a high-entropy input of more than ~1.3 GB can exceed the lists, and bce_hip_encode then fails
- * with BCE_HIP_E_OVERFLOW after the BWT has been built (never with a wrong archive). */
+ * Capacity: device memory is ~45 n bytes for the suffix sort and planes plus the enumeration's node lists: 16 lists that start
+ * with n/8 nodes each (text fills 0.02-0.03 n, random bytes 0.15-0.3 n) and are doubled when a round does not fit (the round is
+ * not run before: bce_hip_stats.list_grows), up to n/2 + 2 nodes -- the worst case -- whenever 16 such lists fit in 60 % of the
+ * free HBM and a list stays below 4 GB (357 M nodes) -- n <= ~7 * 10^8 on an otherwise idle 288 GB MI355X -- and up to 192 M to
+ * 357 M nodes beyond that: a high-entropy input of more than ~1.3 GB can exceed even those, and bce_hip_encode then fails with
+ * BCE_HIP_E_OVERFLOW after the BWT has been built (never with a wrong archive). */
 int bce_hip_load_host(bce_hip_ctx *ctx, const uint8_t *in, uint32_t n);
 int bce_hip_load_device(bce_hip_ctx *ctx, const void *d_in, uint32_t n);
 
@@ -188,6 +190,8 @@ typedef struct bce_hip_stats {
   double t_load, t_bwt, t_planes, t_enum, t_model, t_coder, t_total;
   double k3_ms, k3_launches;   /* HIP-event time and launch count of the interval-count kernels */
   double t_coder_busy;         /* busiest host coder thread (t_coder is only the part not hidden behind GPU work) */
+  double list_grows;           /* times a round did not fit the node lists and they were doubled (k3_grow_lists) */
+  double list_nodes;           /* nodes per list at the end */
 } bce_hip_stats;
 int bce_hip_get_stats(const bce_hip_ctx *ctx, bce_hip_stats *out);
 

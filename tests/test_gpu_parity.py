@@ -185,6 +185,55 @@ def test_rejects_bad_arguments():
         rf.close()
 
 
+def test_node_lists_grow_when_a_round_does_not_fit():
+    """The node lists start with n / 8 (+ 4096) nodes each; a round whose children would not fit is not run, the lists are
+    doubled, the round's lists moved over, and it runs again (k3_grow_lists; test knob 12 = the divisor).  Lists of 4096 nodes
+    on inputs that need tens of thousands (rounds only, knob 1: the depth-first tail would take inputs this small over before
+    the lists fill): several doublings, on the way up and in the stepping interface, the same archive."""
+    for data in (oracle.synth_rand(2, 300000), oracle.synth_text(9, 2_000_000), oracle.synth_rand(5, 70000) + oracle.synth_text(5, 500000)):
+        ctx = bce_amd.api._Ctx(0)
+        try:
+            ctx.check(ctx.lib.bce_hip_debug_set(ctx.h, 12, 1 << 30), "bce_hip_debug_set")
+            ctx.check(ctx.lib.bce_hip_debug_set(ctx.h, 1, 1), "bce_hip_debug_set")     # (no depth-first tail: it would take small inputs over before the lists fill)
+            rf = bce_amd.RankFile(data, ctx=ctx)
+            assert bce_amd.BCE().encode(rf) == oracle.compress(data)
+            st = bce_amd.stats(rf)
+            assert st["list_grows"] >= 2 and st["list_nodes"] >= 4096 * 4, st
+            # the same context again without the knob: the lists it has are kept, nothing grows
+            ctx.check(ctx.lib.bce_hip_debug_set(ctx.h, 12, 0), "bce_hip_debug_set")
+            rf2 = bce_amd.RankFile(data, ctx=ctx)
+            assert bce_amd.BCE().encode(rf2) == oracle.compress(data)
+            assert bce_amd.stats(rf2)["list_grows"] == 0
+        finally:
+            ctx.close()
+    # the default: n / 8 is room enough for text (no growth), random bytes may take one doubling
+    rf = bce_amd.RankFile(oracle.synth_text(9, 2_000_000))
+    try:
+        bce_amd.BCE().encode(rf)
+        assert bce_amd.stats(rf)["list_grows"] == 0
+    finally:
+        rf.close()
+    # stepping (bce_hip_enum_round): every round's node lists against the oracle's trace, lists growing under it
+    data = oracle.synth_rand(3, 60000)
+    bwt, off = oracle.bwt_stage(data)
+    nodes = oracle.trace_encode_from_bwt(bwt, off)["nodes"]
+    ctx = bce_amd.api._Ctx(0)
+    try:
+        ctx.check(ctx.lib.bce_hip_debug_set(ctx.h, 12, 1 << 30), "bce_hip_debug_set")
+        rf = bce_amd.RankFile(bwt=bwt, offset=off, ctx=ctx)
+        bce = bce_amd.BCE()
+        bce.code_begin(rf)
+        for r in range(int(nodes[:, 0].max()) + 1):
+            sel = nodes[nodes[:, 0] == r]
+            for p in range(8):
+                exp = sel[sel[:, 1] == p][:, 2:5]
+                got = bce.code_nodes(rf, p)
+                assert got.shape == exp.shape and (got == exp).all(), "round %d plane %d" % (r, p)
+            assert bce.code_round(rf) == int((nodes[:, 0] == r + 1).sum())
+    finally:
+        ctx.close()
+
+
 def test_symbol_buffer_grows_when_one_round_exceeds_it():
     """A round that emits more symbols than the whole buffer makes the driver enlarge it (k3_grow_symbols)."""
     data = oracle.synth_rand(1, 65536)

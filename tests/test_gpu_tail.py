@@ -64,9 +64,11 @@ def _encode_with_knobs(data, knobs):
         ctx.close()
 
 
-@pytest.mark.parametrize("knobs", [{}, {1: 1}, {1: 1, 2: 1}, {3: 1}, {0: 50}, {0: 50, 2: 1}, {4: 1}, {1: 1, 4: 1}, {1: 1, 2: 1, 4: 1}, {6: 1}, {1: 1, 2: 1, 4: 1, 6: 1}],
+@pytest.mark.parametrize("knobs", [{}, {1: 1}, {1: 1, 2: 1}, {3: 1}, {0: 50}, {0: 50, 2: 1}, {4: 1}, {1: 1, 4: 1}, {1: 1, 2: 1, 4: 1}, {6: 1}, {1: 1, 2: 1, 4: 1, 6: 1},
+                                   {12: 1 << 30}, {12: 1 << 30, 1: 1}, {12: 1 << 30, 1: 1, 4: 1}, {12: 1 << 30, 1: 1, 4: 1, 6: 1}],
                          ids=["default", "no-dfs", "rounds-only", "no-skip", "dfs-short-passes", "dfs-short-passes-no-tail", "no-small", "no-dfs-no-small",
-                              "wide-rounds-only", "three-launch-rounds", "three-launch-wide-rounds-only"])
+                              "wide-rounds-only", "three-launch-rounds", "three-launch-wide-rounds-only",
+                              "small-lists", "lists-grow-no-dfs", "lists-grow-no-dfs-no-small", "lists-grow-three-launch-rounds"])
 def test_every_enumeration_path_gives_the_same_archive(knobs):
     """Wide rounds, LDS tail, depth-first walkers (with / without chain skips, and giving up half way) are
     interchangeable: the archive and the node count never depend on which of them ran."""
