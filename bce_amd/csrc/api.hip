@@ -46,12 +46,16 @@ const RoctxApi &roctx() { static const RoctxApi api; return api; }
 void *big_host_alloc(size_t bytes, int device, bool *registered) {
   *registered = false;
   void *q = nullptr;
-  const size_t two_mb = (size_t)2 << 20;
-  if (!getenv("BCE_DEC_NO_HUGE") && posix_memalign(&q, two_mb, (bytes + two_mb - 1) & ~(two_mb - 1)) == 0 && q) {
-    (void)madvise(q, bytes, MADV_HUGEPAGE);
-    // first touch (the kernel hands out and clears 2 MB at a time), on a few threads when there is much of it
-    const unsigned nt = bytes >= ((size_t)256 << 20) ? 4 : 1;
-    auto touch = [q, bytes, nt](unsigned t) {
+  // (only for the one large buffer: small ones would come out of the C library's heap, and a registered range in the middle of
+  //  the heap shares its pages' fate with everything around it)
+  if (!getenv("BCE_DEC_NO_HUGE") && bytes >= ((size_t)256 << 20)) {
+    q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (q == MAP_FAILED) q = nullptr;
+  }
+  if (q) {
+    // first touch on a few threads, then the pages are registered where they are
+    constexpr unsigned nt = 4;
+    auto touch = [q, bytes](unsigned t) {
       const size_t lo = bytes / nt * t, hi = t + 1 == nt ? bytes : bytes / nt * (t + 1);
       for (size_t o = lo; o < hi; o += 4096) static_cast<volatile uint8_t *>(q)[o] = 0;
     };
@@ -63,23 +67,27 @@ void *big_host_alloc(size_t bytes, int device, bool *registered) {
     touch(0);
     for (unsigned t = started; t < nt; ++t) touch(t);            // (threads that did not start)
     for (auto &x : th) x.join();
-    // registered memory is mapped and host-coherent; the kernels are handed the host address, so it must be the device's too
+    // registered memory is mapped and host-coherent; the device address must be the host's (the copies are given either)
     void *dp = nullptr;
     if (hipSetDevice(device) == hipSuccess && hipHostRegister(q, bytes, hipHostRegisterMapped) == hipSuccess) {
       if (hipHostGetDevicePointer(&dp, q, 0) == hipSuccess && dp == q) { *registered = true; return q; }
       (void)hipHostUnregister(q);
     }
     (void)hipGetLastError();
-    free(q);
+    (void)munmap(q, bytes);
     q = nullptr;
   }
   if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&q, bytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   return q;
 }
-void big_host_free(void *p, bool registered) {
+void big_host_free(void *p, size_t bytes, bool registered) {
   if (!p) return;
-  if (registered) { (void)hipHostUnregister(p); free(p); }
-  else (void)hipHostFree(p);
+  if (registered) {
+    // hipHostFree waits for the device before it lets go of the memory; unregistering does not.  The same guarantee, then.
+    (void)hipDeviceSynchronize();
+    (void)hipHostUnregister(p);
+    (void)munmap(p, bytes);
+  } else (void)hipHostFree(p);
 }
 
 RoctxRange::RoctxRange(const char *name) : on_(roctx().push != nullptr) { if (on_) roctx().push(name); }
@@ -340,8 +348,8 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   k4_prepin_join(c, true);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   if (c->h_small) (void)hipHostFree(c->h_small);
-  if (c->h_big) big_host_free(c->h_big, c->h_big_registered);
-  for (int i = 0; i < 3; ++i) if (c->dec_pin[i]) big_host_free(c->dec_pin[i], c->dec_pin_reg[i]);
+  if (c->h_big) big_host_free(c->h_big, c->h_big_cap, c->h_big_registered);
+  for (void *q : c->dec_pin) if (q) (void)hipHostFree(q);
   if (c->h_runs) (void)hipHostFree(c->h_runs);
   if (c->h_truns) (void)hipHostFree(c->h_truns);
   if (c->coder) c->coder->drain();

@@ -14,6 +14,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/mman.h>
+
 #include "../../include/bce_hip.h"
 #include "bce_core.h"
 #include "host_coder.h"
@@ -68,9 +70,11 @@ struct FlushSlot {
 };
 
 // free a slot's host staging, whichever way it was pinned
+// bytes of the anonymous mapping k4_prepin makes for a slot of `cap` records
+inline size_t slot_map_bytes(size_t cap) { return (cap * 8 + 16 + 4095) & ~(size_t)4095; }
 inline void slot_free_host(FlushSlot &s) {
   if (s.h_out) {
-    if (s.registered) { (void)hipHostUnregister(s.h_out); free(s.h_out); }
+    if (s.registered) { (void)hipDeviceSynchronize(); (void)hipHostUnregister(s.h_out); (void)munmap(s.h_out, slot_map_bytes(s.cap)); }   // (hipHostFree waits for the device; so does this)
     else (void)hipHostFree(s.h_out);
   }
   s.h_out = nullptr; s.cap = 0; s.registered = false;
@@ -151,7 +155,6 @@ struct bce_hip_ctx {
   bool h_big_registered = false;                 // h_big came from big_host_alloc's malloc + hipHostRegister
   void *dec_pin[3] = {nullptr, nullptr, nullptr};  // the decoder's pinned query / escape-record / answer buffers, kept from one decode to the next (grow-only)
   size_t dec_pin_cap[3] = {0, 0, 0};
-  bool dec_pin_reg[3] = {false, false, false};   // (which kind: big_host_alloc)
   bce::FlushSlot slot[3];                        // flushes in flight: GPU fills one while the coders drain the others
   int slot_next = 0;
 
@@ -179,14 +182,14 @@ inline double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// Pinned host memory of the decoder (the boundary ranks of the host tail, which the host reads at random; the query / answer
-// buffers the kernels and the host coders exchange): plain memory aligned to 2 MB with transparent huge pages asked for,
-// touched, then registered with the runtime (hipHostRegister, mapped: the device address is the host's, or the buffer is given
-// up).  Measured: 3.2 GB this way take 0.04 s beside running kernels; hipHostMalloc of the same takes
-// 0.55-0.7 s and holds the kernels queued meanwhile up.  BCE_DEC_NO_HUGE=1: hipHostMalloc (coherent, mapped) as before.
-// big_host_free gives either kind back.
+// The decoder's large pinned host buffer (the boundary ranks of the host tail: 32 (n + 1) bytes, 3.2 GB at 10^8): from 256 MB on,
+// anonymous memory of its own mapping, touched by four threads, then registered with the runtime (hipHostRegister, mapped: the
+// device address is the host's, or the buffer is given up).  Measured: 3.2 GB take a fraction of hipHostMalloc's
+// 0.55-0.7 s, which also holds the kernels queued meanwhile up.  Only the copy engine and the host touch this buffer.  The
+// buffers KERNELS write (queries, answers) stay hipHostMalloc's: registered heap memory under them gave, once in two or three
+// runs of the test suite, "memory access fault: write access to a read-only page".  BCE_DEC_NO_HUGE=1: hipHostMalloc for all.
 void *big_host_alloc(size_t bytes, int device, bool *registered);
-void big_host_free(void *p, bool registered);
+void big_host_free(void *p, size_t bytes, bool registered);
 
 inline int set_err(bce_hip_ctx *c, hipError_t e, const char *what, int line) {
   snprintf(c->err, sizeof c->err, "%s:%d: %s", what, line, hipGetErrorString(e));

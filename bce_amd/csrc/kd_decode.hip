@@ -1314,30 +1314,28 @@ struct QueryPool {
 struct Pinned {
   void *p = nullptr;
   size_t cap = 0;
-  bool registered = false;      // big_host_alloc's malloc + hipHostRegister (else hipHostMalloc)
   void **keep_p = nullptr;      // where the buffer lives on after this object (a slot of the context), if anywhere
   size_t *keep_cap = nullptr;
-  bool *keep_reg = nullptr;
   Pinned() = default;
-  Pinned(void **kp, size_t *kc, bool *kr) : p(*kp), cap(*kc), registered(*kr), keep_p(kp), keep_cap(kc), keep_reg(kr) {}
+  Pinned(void **kp, size_t *kc) : p(*kp), cap(*kc), keep_p(kp), keep_cap(kc) {}
   Pinned(const Pinned &) = delete;
   Pinned &operator=(const Pinned &) = delete;
   int ensure(bce_hip_ctx *c, size_t bytes, size_t least = (size_t)16 << 20) {
     if (bytes <= cap) return BCE_HIP_OK;
-    size_t want = 2 * cap > bytes ? 2 * cap : bytes;          // pinning is not free: grow geometrically
-    if (p) big_host_free(p, registered);
+    size_t want = 2 * cap > bytes ? 2 * cap : bytes;          // pinning is slow (~0.15 s per GB): grow geometrically
+    if (p) (void)hipHostFree(p);
     p = nullptr; cap = 0;
     if (want < least) want = least;
     const double t0 = now_s();
-    p = big_host_alloc(want, c->device, &registered);         // host-coherent and mapped: the wave tail kernel reads answers written while it runs
-    if (!p) { snprintf(c->err, sizeof c->err, "decode: no pinned memory (%zu bytes)", want); return BCE_HIP_E_NOMEM; }
+    // (the runtime's own pinned memory: kernels write here while the host reads -- see big_host_alloc in common.h)
+    BCE_HIP_TRY(c, hipHostMalloc(&p, want, hipHostMallocCoherent | hipHostMallocMapped));   // the wave tail kernel reads answers written while it runs
     c->pin_s += now_s() - t0; c->pin_bytes += want; c->pin_calls++;
     cap = want;
     return BCE_HIP_OK;
   }
   ~Pinned() {
-    if (keep_p) { *keep_p = p; *keep_cap = cap; *keep_reg = registered; }
-    else if (p) big_host_free(p, registered);
+    if (keep_p) { *keep_p = p; *keep_cap = cap; }
+    else if (p) (void)hipHostFree(p);
   }
 };
 
@@ -1417,7 +1415,7 @@ struct BigPin {
     running = false;
     if (getenv("BCE_DEC_TIMING")) fprintf(stderr, "gpu decode: pinned %.1f GB beside the rounds: %.3f s, the tail waited %.3f s of them\n", bytes / 1e9, t_done - t_start, now_s() - t0);
     if (p) {
-      if (c->h_big) big_host_free(c->h_big, c->h_big_registered);
+      if (c->h_big) big_host_free(c->h_big, c->h_big_cap, c->h_big_registered);
       c->h_big = p; c->h_big_cap = bytes; c->h_big_registered = registered; p = nullptr;
     }
   }
@@ -1446,7 +1444,7 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
   // 3.2 GB at 10^8 bytes: into pinned memory the context keeps (a copy into fresh pageable memory ran at a fifth of the bus)
   const double tcp0 = now_s();
   if (c->h_big_cap < 8 * stride * 4) {
-    if (c->h_big) { big_host_free(c->h_big, c->h_big_registered); c->h_big = nullptr; c->h_big_cap = 0; }
+    if (c->h_big) { big_host_free(c->h_big, c->h_big_cap, c->h_big_registered); c->h_big = nullptr; c->h_big_cap = 0; }
     c->h_big = big_host_alloc(8 * stride * 4, c->device, &c->h_big_registered);
     if (!c->h_big) { snprintf(c->err, sizeof c->err, "host tail: no pinned memory for the boundary ranks"); return BCE_HIP_E_NOMEM; }
     c->h_big_cap = 8 * stride * 4;
@@ -1726,8 +1724,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
   BCE_HIP_TRY(c, hipMemcpyAsync(c->ctl.p, &ctl, sizeof ctl, hipMemcpyHostToDevice, c->stream));
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
   // (query, escape-record and answer buffers stay with the context: pinning their ~150 MB anew was 0.05 s of every decode)
-  Pinned pin_info, pin_q(&c->dec_pin[0], &c->dec_pin_cap[0], &c->dec_pin_reg[0]), pin_e(&c->dec_pin[1], &c->dec_pin_cap[1], &c->dec_pin_reg[1]),
-         pin_res(&c->dec_pin[2], &c->dec_pin_cap[2], &c->dec_pin_reg[2]);
+  Pinned pin_info, pin_q(&c->dec_pin[0], &c->dec_pin_cap[0]), pin_e(&c->dec_pin[1], &c->dec_pin_cap[1]), pin_res(&c->dec_pin[2], &c->dec_pin_cap[2]);
   struct Events {
     hipEvent_t e[8] = {};
     ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }

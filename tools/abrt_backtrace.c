@@ -1,0 +1,20 @@
+#define _GNU_SOURCE
+#include <execinfo.h>
+#include <signal.h>
+#include <string.h>
+#include <unistd.h>
+static void on_abort(int sig) {
+  void *frames[64];
+  const char msg[] = "\n==== SIGABRT backtrace (tools/_build/abrt.c) ====\n";
+  (void)!write(2, msg, sizeof msg - 1);
+  int n = backtrace(frames, 64);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+__attribute__((constructor)) static void init(void) {
+  struct sigaction sa;
+  memset(&sa, 0, sizeof sa);
+  sa.sa_handler = on_abort;
+  sigaction(SIGABRT, &sa, 0);
+}
