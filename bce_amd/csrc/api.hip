@@ -49,8 +49,7 @@ void *big_host_alloc(size_t bytes, int device, bool *registered) {
   // (only for the one large buffer: small ones would come out of the C library's heap, and a registered range in the middle of
   //  the heap shares its pages' fate with everything around it)
   if (!getenv("BCE_DEC_NO_HUGE") && bytes >= ((size_t)256 << 20)) {
-    q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-    if (q == MAP_FAILED) q = nullptr;
+    q = huge_map(bytes);
   }
   if (q) {
     // first touch on a few threads, then the pages are registered where they are
@@ -74,7 +73,7 @@ void *big_host_alloc(size_t bytes, int device, bool *registered) {
       (void)hipHostUnregister(q);
     }
     (void)hipGetLastError();
-    (void)munmap(q, bytes);
+    huge_unmap(q, bytes);
     q = nullptr;
   }
   if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&q, bytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -86,7 +85,7 @@ void big_host_free(void *p, size_t bytes, bool registered) {
     // hipHostFree waits for the device before it lets go of the memory; unregistering does not.  The same guarantee, then.
     (void)hipDeviceSynchronize();
     (void)hipHostUnregister(p);
-    (void)munmap(p, bytes);
+    huge_unmap(p, bytes);
   } else (void)hipHostFree(p);
 }
 

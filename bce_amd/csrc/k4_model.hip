@@ -404,7 +404,7 @@ int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
       slot.h_out = slot.pin_p; slot.cap = slot.pin_cap; slot.registered = true;
       c->pin_s += slot.pin_s; c->pin_bytes += slot.pin_cap * 8 + 16; c->pin_calls++;
     } else {
-      (void)hipHostUnregister(slot.pin_p); (void)munmap(slot.pin_p, slot_map_bytes(slot.pin_cap));
+      (void)hipHostUnregister(slot.pin_p); huge_unmap(slot.pin_p, slot_map_bytes(slot.pin_cap));
     }
     slot.pin_p = nullptr; slot.pin_cap = 0;
   }
@@ -519,15 +519,14 @@ void k4_prepin(bce_hip_ctx *c, uint32_t n) {
         const double t0 = now_s();
         // (a mapping of its own, not the C library's heap: a registered range shares its pages' fate with nothing else)
         const size_t bytes = slot_map_bytes(sp->pin_cap);
-        void *q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-        if (q == MAP_FAILED) q = nullptr;
+        void *q = huge_map(bytes);
         if (q)
           for (size_t o = 0; o < bytes; o += 4096) static_cast<volatile uint8_t *>(q)[o] = 0;
         int go;
         { std::unique_lock<std::mutex> lk(c->stage_mu); c->stage_cv.wait(lk, [c] { return c->stage_state != 0; }); go = c->stage_state; }
         if (q && (go != 1 || hipSetDevice(dev) != hipSuccess || hipHostRegister(q, bytes, hipHostRegisterDefault) != hipSuccess)) {
           (void)hipGetLastError();
-          (void)munmap(q, bytes); q = nullptr;
+          huge_unmap(q, bytes); q = nullptr;
         }
         sp->pin_p = static_cast<uint64_t *>(q);
         sp->pin_s = now_s() - t0;
@@ -539,7 +538,7 @@ void k4_prepin(bce_hip_ctx *c, uint32_t n) {
 void k4_prepin_join(bce_hip_ctx *c, bool drop) {
   for (FlushSlot &slot : c->slot) {
     if (slot.pin_th.joinable()) slot.pin_th.join();
-    if (drop && slot.pin_p) { (void)hipHostUnregister(slot.pin_p); (void)munmap(slot.pin_p, slot_map_bytes(slot.pin_cap)); slot.pin_p = nullptr; slot.pin_cap = 0; }
+    if (drop && slot.pin_p) { (void)hipHostUnregister(slot.pin_p); huge_unmap(slot.pin_p, slot_map_bytes(slot.pin_cap)); slot.pin_p = nullptr; slot.pin_cap = 0; }
   }
 }
 

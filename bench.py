@@ -601,10 +601,13 @@ def main():
                     pool.close()
                 pool = None
         if n_gpus == 1 and not args.no_decode and n <= 1_000_000_000:
-            # untimed: the archive of the last step through the GPU-assisted decoder (`bce -d`), compared with the input
+            # untimed: the archive of the last step through the GPU-assisted decoder (`bce -d`), compared with the input.
+            # (One decode first to warm the context's decoder buffers up, as the compression steps have their warm-up: on a
+            # card whose memory an earlier process has just given back the driver clears it first, 27 ms per GB.)
+            timed_decode(arch, ctx, data)
             td, same = timed_decode(arch, ctx, data)
             out["decode"] = {"value": round(n / td / 1e6, 3), "unit": "MB/s", "seconds": round(td, 3), "roundtrip_identical": same,
-                             "note": "bce_hip_decompress_device(archive -> caller's buffer): GPU passes + 8 host range decoders; not part of `value`"}
+                             "note": "bce_hip_decompress_device(archive -> caller's buffer) in a warm context: GPU passes + 8 host range decoders; not part of `value`"}
         if n_gpus == 1 and not args.no_workloads and not args.file and args.workload == "synth-text":
             out["workloads"] = extra_workloads(ctx, dev, table, pool, args.stream_steps or 12, decode=not args.no_decode)
             if pool is not None:
