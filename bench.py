@@ -203,6 +203,7 @@ def extra_workloads(ctx, dev, table, pool=None, stream_steps=12, decode=True):
             dec = None
             if decode:
                 try:
+                    timed_decode(arch, ctx, data)               # (warm-up: this workload's decoder buffers, as for the headline)
                     td, same = timed_decode(arch, ctx, data)
                     dec = {"seconds": round(td, 3), "value": round(n / td / 1e6, 2), "unit": "MB/s", "roundtrip_identical": same}
                 except Exception as e:
