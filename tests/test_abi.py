@@ -26,6 +26,19 @@ def test_library_exports_every_declared_symbol():
     assert bound == set(names)
 
 
+def test_stats_struct_of_the_binding_is_the_headers():
+    """bce_hip_stats (include/bce_hip.h) field by field == the ctypes structure the binding reads it with: names, order, C types."""
+    src = open(os.path.join(ROOT, "include", "bce_hip.h")).read()
+    body = src[src.index("typedef struct bce_hip_stats {"):src.index("} bce_hip_stats;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    want = []
+    for ctype, names in re.findall(r"\b(uint64_t|uint32_t|double)\s+([^;]+);", body):
+        for name in names.split(","):
+            want.append((name.strip(), {"uint64_t": C.c_uint64, "uint32_t": C.c_uint32, "double": C.c_double}[ctype]))
+    assert len(want) >= 19
+    assert [(n, t) for n, t in api.Stats._fields_] == want
+
+
 def test_divsufsort_seam_library_exports_the_two_reference_calls():
     """include/divsufsort_hip.h: the libdivsufsort entry points bce.cpp:901 / :1091 call, under their original names."""
     src = open(os.path.join(ROOT, "include", "divsufsort_hip.h")).read()
