@@ -167,6 +167,9 @@ struct bce_hip_ctx {
   void *h_small = nullptr;                       // 4 KB of pinned host memory for read_back()
   void *h_big = nullptr;                         // pinned host memory for the decoder's host tail (the boundary ranks: 32 (n + 1) bytes), grow-only
   size_t h_big_cap = 0;
+  uint64_t dec_cap_next = 0;                     // a decode that ran out of list room starts again with this many nodes per list
+  bool dec_list_overflow = false;
+  uint32_t dec_restarts = 0;
   bool h_big_registered = false;                 // h_big came from big_host_alloc's malloc + hipHostRegister
   void *dec_pin[3] = {nullptr, nullptr, nullptr};  // the decoder's pinned query / escape-record / answer buffers, kept from one decode to the next (grow-only)
   size_t dec_pin_cap[3] = {0, 0, 0};

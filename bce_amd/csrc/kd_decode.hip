@@ -1662,9 +1662,26 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
   return BCE_HIP_OK;
 }
 
-uint32_t dec_capP(uint32_t n) {
+// The node lists of a decode: at most n / 2 + 2 nodes each (the worst case; 192 M beyond 4 * 10^8 bytes), and to begin with an
+// eighth of n (what k3_begin starts the encoder with: text fills 0.02-0.03 n, random bytes 0.15-0.3 n) or what the context's
+// buffer already holds.  A round whose children would not fit stops the decode before it writes them (the scan of the
+// children pass checks; the one-launch kernel, which checks afterwards, is only used where twice the round's nodes fit) and
+// the decode starts again with twice the room (decompress_device_body).  Test knob 12 / BCE_HIP_CAPP_DIV as for the encoder.
+uint32_t dec_full_capP(uint32_t n) {
   const uint64_t worst = (uint64_t)n / 2 + 2, soft = (uint64_t)192 << 20;
   return (uint32_t)(worst < soft ? worst : soft);
+}
+uint32_t dec_capP(const bce_hip_ctx *c, uint32_t n) {
+  const uint64_t full = dec_full_capP(n);
+  uint64_t div = 8;
+  bool forced = false;
+  if (c->dbg_capp_div) { div = c->dbg_capp_div; forced = true; }
+  if (const char *e = getenv("BCE_HIP_CAPP_DIV")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1) { div = v; forced = true; } }
+  uint64_t cap = (uint64_t)n / div + 4096;
+  const uint64_t held = c->nodes.cap / (16 * sizeof(Node));
+  if (held > cap && !forced) cap = held;
+  if (c->dec_cap_next > cap) cap = c->dec_cap_next;             // (a decode that ran out of room: this much the next time)
+  return (uint32_t)(cap < full ? cap : full);
 }
 
 }  // namespace
@@ -1680,7 +1697,25 @@ extern "C" int bce_hip_decompress_device(bce_hip_ctx *c, const uint8_t *archive,
                                          size_t *out_len) {
   return bce_guarded(c, [&] { return decompress_device_body(c, archive, len, out, cap, out_len); });
 }
+static int decompress_device_once(bce_hip_ctx *c, const uint8_t *archive, size_t len, uint8_t *out, size_t cap, size_t *out_len);
 static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t len, uint8_t *out, size_t cap, size_t *out_len) {
+  if (!c) return BCE_HIP_E_ARG;
+  c->dec_cap_next = 0;
+  for (;;) {
+    c->dec_list_overflow = false;
+    const int rc = decompress_device_once(c, archive, len, out, cap, out_len);
+    if (rc != BCE_HIP_E_OVERFLOW || !c->dec_list_overflow) { c->dec_cap_next = 0; return rc; }
+    // a round did not fit the node lists (nothing of it was written): the same decode again with twice the room
+    const uint32_t full = dec_full_capP((uint32_t)*out_len);
+    if (c->capP >= full) { c->dec_cap_next = 0; return rc; }
+    c->dec_cap_next = (uint64_t)c->capP * 2 < full ? (uint64_t)c->capP * 2 : full;
+    c->dec_restarts++;
+    if (getenv("BCE_DEC_TIMING") || getenv("BCE_ALLOC_TRACE")) fprintf(stderr, "gpu decode: a round does not fit the node lists of %u nodes: once more with %llu\n", c->capP, (unsigned long long)c->dec_cap_next);
+    (void)hipDeviceSynchronize();
+    c->err[0] = 0;
+  }
+}
+static int decompress_device_once(bce_hip_ctx *c, const uint8_t *archive, size_t len, uint8_t *out, size_t cap, size_t *out_len) {
   if (!c || !archive || !out_len) return BCE_HIP_E_ARG;
   ArchiveHead hd;
   if (parse_archive(archive, len, hd, /*header_only=*/true) != 0) return BCE_HIP_E_ARG;
@@ -1697,7 +1732,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
 
   // ---- buffers ----
   const size_t rstride = (size_t)n + 1;
-  c->capP = dec_capP(n);
+  c->capP = dec_capP(c, n);
   BCE_TRY(ensure(c, c->nodes, (size_t)16 * c->capP * sizeof(Node)));
   BCE_TRY(ensure(c, c->ctl, sizeof(DecCtl) > sizeof(EnumCtl) ? sizeof(DecCtl) : sizeof(EnumCtl)));
   const size_t max_tiles = (size_t)8 * ((c->capP + K3_TILE - 1) / K3_TILE + 1);
@@ -1956,7 +1991,8 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
     }
     // Rounds of up to kDirectNodes nodes exchange their queries and answers through pinned host memory (as the tail kernels do):
     // the kernels write / read it over the bus, and the round is two launches and two syncs with no copy in between.
-    const bool small_round = cur_nodes <= DS_MAXNODES && !no_small;
+    // (dec_small_kernel writes the children before it knows their number: only where twice the round's nodes fit a list)
+    const bool small_round = cur_nodes <= DS_MAXNODES && !no_small && 2ull * cur_nodes <= c->capP;
     const bool direct = small_round && cur_nodes <= kDirectNodes && !answered_pending;
     if (direct) {
       BCE_TRY(pin_q.ensure(c, (size_t)(cur_nodes + 16) * 4));
@@ -2039,6 +2075,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
         BCE_HIP_TRY(c, hipEventSynchronize(ev.e[i]));
         if (i == 0) ts_first += now_s() - tsa;
         const DecInfo in = *info;                                  // (plane p's fields and those of the planes before it; the rest are being written)
+        if (in.err == 2) { snprintf(c->err, sizeof c->err, "decode: node list overflow (capP=%u)", c->capP); c->dec_list_overflow = true; return BCE_HIP_E_OVERFLOW; }
         if (in.err) { snprintf(c->err, sizeof c->err, "decode: inconsistent archive (round %u)", round); return BCE_HIP_E_INTERNAL; }
         const uint32_t qn = in.qtot[p], en = in.etot[p], qb = in.qbase[p], eb = in.ebase[p];
         new_qtot[p] = qn;
@@ -2086,6 +2123,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
       BCE_HIP_TRY(c, hipGetLastError());
       if (ctl.err) {
         snprintf(c->err, sizeof c->err, ctl.err == 2 ? "decode: node list overflow (capP=%u)" : "decode: inconsistent archive (round %u)", ctl.err == 2 ? c->capP : round);
+        c->dec_list_overflow = ctl.err == 2;
         return ctl.err == 2 ? BCE_HIP_E_OVERFLOW : BCE_HIP_E_INTERNAL;
       }
       for (int q = 0; q < 8; ++q) prev_qtot[q] = new_qtot[q];
@@ -2111,6 +2149,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
     BCE_HIP_TRY(c, hipGetLastError());
     const DecInfo in = *info;
     { const double t1 = now_s(); t_q += t1 - t0; t0 = t1; }
+    if (in.err == 2) { snprintf(c->err, sizeof c->err, "decode: node list overflow (capP=%u)", c->capP); c->dec_list_overflow = true; return BCE_HIP_E_OVERFLOW; }
     if (in.err) { snprintf(c->err, sizeof c->err, "decode: inconsistent archive (round %u)", round); return BCE_HIP_E_INTERNAL; }
     uint64_t qtotal = 0, etotal = 0;
     for (int p = 0; p < 8; ++p) { qtotal += in.qtot[p]; etotal += in.etot[p]; prev_qtot[p] = in.qtot[p]; }
@@ -2153,6 +2192,7 @@ static int decompress_device_body(bce_hip_ctx *c, const uint8_t *archive, size_t
       if (ctl.err == 4) snprintf(c->err, sizeof c->err, "decode: a two-launch round waited too long for a predecessor tile (round %u)", round);
       else snprintf(c->err, sizeof c->err, ctl.err == 2 ? "decode: node list overflow (capP=%u)" : "decode: inconsistent archive (round %u)",
                     ctl.err == 2 ? c->capP : round);
+      c->dec_list_overflow = ctl.err == 2;
       return ctl.err == 2 ? BCE_HIP_E_OVERFLOW : BCE_HIP_E_INTERNAL;
     }
     t_c += now_s() - t0;

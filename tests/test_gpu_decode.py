@@ -165,3 +165,25 @@ def test_decode_into_a_callers_buffer():
         bce_amd.decompress_device(arch, out=np.zeros(len(data) - 1, dtype=np.uint8))      # too small: refused, nothing written past it
     with pytest.raises(ValueError):
         bce_amd.decompress_device(arch, out=np.zeros(len(data), dtype=np.uint16))
+
+
+def test_node_lists_of_the_decoder_grow_by_starting_again(capfd, monkeypatch):
+    """The decoder's node lists start with n / 8 (+ 4096) nodes per plane; a round whose children would not fit stops the decode
+    before it writes them, and the decode starts again with twice the room (kd_decode.hip: decompress_device_body).  Lists of
+    4096 nodes (test knob 12) on inputs whose rounds hold tens of thousands of nodes per plane: several restarts, the right
+    bytes; then the same context without the knob decodes in one go (its lists are large by now)."""
+    monkeypatch.setenv("BCE_ALLOC_TRACE", "1")
+    for data in (oracle.synth_rand(12, 400000), oracle.synth_text(12, 3_000_000), bytes(_with_long_tail(1_500_000, 7))):
+        arch = oracle.compress(data)
+        ctx = bce_amd.api._Ctx(0)
+        try:
+            ctx.check(ctx.lib.bce_hip_debug_set(ctx.h, 12, 1 << 30), "bce_hip_debug_set")
+            capfd.readouterr()
+            assert bce_amd.decompress_device(arch, ctx=ctx) == data
+            err = capfd.readouterr().err
+            assert err.count("does not fit the node lists") >= 2, err[-2000:]
+            ctx.check(ctx.lib.bce_hip_debug_set(ctx.h, 12, 0), "bce_hip_debug_set")
+            assert bce_amd.decompress_device(arch, ctx=ctx) == data
+            assert "does not fit the node lists" not in capfd.readouterr().err
+        finally:
+            ctx.close()
