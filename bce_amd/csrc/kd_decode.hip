@@ -1678,6 +1678,9 @@ uint32_t dec_capP(const bce_hip_ctx *c, uint32_t n) {
   if (c->dbg_capp_div) { div = c->dbg_capp_div; forced = true; }
   if (const char *e = getenv("BCE_HIP_CAPP_DIV")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1) { div = v; forced = true; } }
   uint64_t cap = (uint64_t)n / div + 4096;
+  // (the one-launch rounds need twice a round's nodes to fit: 4 M nodes per list at least, i.e. the worst case up to 8 MB of
+  //  input -- with n / 8 a 1 MB input left them for its widest rounds and decoded in 32 ms instead of 16)
+  if (!forced && cap < ((uint64_t)4 << 20)) cap = (uint64_t)4 << 20;
   const uint64_t held = c->nodes.cap / (16 * sizeof(Node));
   if (held > cap && !forced) cap = held;
   if (c->dec_cap_next > cap) cap = c->dec_cap_next;             // (a decode that ran out of room: this much the next time)
