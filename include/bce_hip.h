@@ -54,8 +54,9 @@ int bce_hip_set_config(bce_hip_ctx *ctx, const uint8_t *config288);
  * one host thread each overlap one's coding -- and one's rotation sort -- with the other's enumeration.  Gated contexts
  * of a device take turns for the ENUMERATION (its single-launch rounds must not run beside another context's):
  * bce_hip_encode / bce_hip_scan take the device's gate, give it back when the last model flush is queued or when they
- * fail, and lend it to the next context while they wait for their own coder threads; bce_hip_destroy and this call (with
- * either value) give it back too.  Every context is gated by default (an uncontended gate costs nothing); contexts of
+ * fail, and lend it to the next context while they wait for their own coder threads and -- since round 4 -- behind every model
+ * flush they queue (the model's kernels wait for nothing; the gate comes back before the next round is queued);
+ * bce_hip_destroy and this call (with either value) give it back too.  Every context is gated by default (an uncontended gate costs nothing); contexts of
  * other PROCESSES on the same device are kept apart by an advisory file lock keyed by the device's PCI address
  * (/dev/shm/bce_hip_gate_<bdf>; BCE_HIP_NO_FILE_GATE=1 switches that part off).  on = 0 opts a context out: only for
  * a context that is alone on its device. */
