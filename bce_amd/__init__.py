@@ -8,5 +8,5 @@ There is no CPU fallback: every compute call goes through the HIP library and fa
 when it is missing or when no GPU is present.
 """
 from .api import (BCE, BceError, ContextPool, RankFile, compress, compress_device, compress_many, decompress, decompress_device,  # noqa: F401
-                  library_path, load_library, scan, synth_rand, synth_text, stats, archive_of, plane_stream, set_plane_mask, set_plane_stream)
+                  library_path, load_library, scan, synth_rand, synth_text, stats, stats_of, archive_of, plane_stream, set_plane_mask, set_plane_stream)
 from .build import build as build_native  # noqa: F401

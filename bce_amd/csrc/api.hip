@@ -46,9 +46,8 @@ const RoctxApi &roctx() { static const RoctxApi api; return api; }
 void *big_host_alloc(size_t bytes, int device, bool *registered) {
   *registered = false;
   void *q = nullptr;
-  // (only for the one large buffer: small ones would come out of the C library's heap, and a registered range in the middle of
-  //  the heap shares its pages' fate with everything around it)
-  if (!getenv("BCE_DEC_NO_HUGE") && bytes >= ((size_t)256 << 20)) {
+  // (only for the one large buffer; always a mapping of its own: common.h, "host memory registered with the runtime")
+  if (!getenv("BCE_DEC_NO_HUGE") && bytes >= reg_min_bytes((size_t)256 << 20)) {
     q = huge_map(bytes);
   }
   if (q) {
@@ -66,6 +65,7 @@ void *big_host_alloc(size_t bytes, int device, bool *registered) {
     touch(0);
     for (unsigned t = started; t < nt; ++t) touch(t);            // (threads that did not start)
     for (auto &x : th) x.join();
+    reg_map_settle(q, bytes);
     // registered memory is mapped and host-coherent; the device address must be the host's (the copies are given either)
     void *dp = nullptr;
     if (hipSetDevice(device) == hipSuccess && hipHostRegister(q, bytes, hipHostRegisterMapped) == hipSuccess) {
@@ -79,13 +79,18 @@ void *big_host_alloc(size_t bytes, int device, bool *registered) {
   if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&q, bytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   return q;
 }
-void big_host_free(void *p, size_t bytes, bool registered) {
+void big_host_free(bce_hip_ctx *c, void *p, size_t bytes, bool registered) {
   if (!p) return;
   if (registered) {
-    // hipHostFree waits for the device before it lets go of the memory; unregistering does not.  The same guarantee, then.
-    (void)hipDeviceSynchronize();
+    // hipHostFree waits for the device before it lets go of the memory; unregistering does not.  The only work that touches
+    // this buffer are copies on its context's own streams: those are waited for, no other context is stalled.
+    if (c) {
+      (void)hipSetDevice(c->device);
+      for (hipStream_t st : {c->stream, c->k4_stream, c->copy_stream}) if (st) (void)hipStreamSynchronize(st);
+    } else (void)hipDeviceSynchronize();
     (void)hipHostUnregister(p);
     huge_unmap(p, bytes);
+    if (c) c->reg_unmaps++;
   } else (void)hipHostFree(p);
 }
 
@@ -188,6 +193,18 @@ int gate_regain(bce_hip_ctx *c) {
 int gate_on_error(bce_hip_ctx *c, int status) {
   if (c && status != BCE_HIP_OK) gate_release(c);
   return status;
+}
+
+// A bounded wait for a tagged word ran out (wait_word, k3_enumerate.hip): the round is void, later kernels no-op.  Reported
+// before anything of the control block is used -- a stalled round sets overflow (so that later launches return at once) but
+// not skip_round, and "rounds executed" computed from a stale skip_round once sized a copy out of the run table.
+int k3_stalled(bce_hip_ctx *c) {
+  snprintf(c->err, sizeof c->err, "k3: a single-launch round waited too long for a predecessor tile (dispatch order not as assumed)");
+  return BCE_HIP_E_INTERNAL;
+}
+int k3_bad_skip(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t first, uint32_t batch) {
+  snprintf(c->err, sizeof c->err, "k3: control block names round %u as skipped, outside the batch %u..%u", ctl.skip_round, first, first + batch);
+  return BCE_HIP_E_INTERNAL;
 }
 
 int set_input_body(bce_hip_ctx *c, const void *src, uint32_t n, hipMemcpyKind kind);
@@ -347,13 +364,13 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   k4_prepin_join(c, true);
   if (c->h_ctl) (void)hipHostFree(c->h_ctl);
   if (c->h_small) (void)hipHostFree(c->h_small);
-  if (c->h_big) big_host_free(c->h_big, c->h_big_cap, c->h_big_registered);
+  if (c->h_big) big_host_free(c, c->h_big, c->h_big_cap, c->h_big_registered);
   for (void *q : c->dec_pin) if (q) (void)hipHostFree(q);
   if (c->h_runs) (void)hipHostFree(c->h_runs);
   if (c->h_truns) (void)hipHostFree(c->h_truns);
   if (c->coder) c->coder->drain();
   for (FlushSlot &sl : c->slot) {
-    slot_free_host(sl);
+    slot_free_host(sl, &c->reg_unmaps);
     if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
     if (sl.ev_copy) (void)hipEventDestroy(sl.ev_copy);
   }
@@ -547,7 +564,7 @@ int bce_hip_enum_round(bce_hip_ctx *c, uint64_t *next_nodes) {
   else BCE_TRY(k3_rounds(c, 1, 0));
   EnumCtl ctl;
   BCE_TRY(k3_sync_ctl(c, &ctl));
-  if (ctl.stalled) { snprintf(c->err, sizeof c->err, "k3: a single-launch round waited too long for a predecessor tile (dispatch order not as assumed)"); return BCE_HIP_E_INTERNAL; }
+  if (ctl.stalled) return k3_stalled(c);
   if (ctl.overflow) {                              // larger lists, the same round again (as bce_hip_encode does)
     BCE_TRY(k3_grow_lists(c, ctl));
     if (c->dbg_step_small) BCE_TRY(k3_rounds_small(c, 1, K3_SMALL_NODES, false));
@@ -716,6 +733,7 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
       BCE_TRY(k3_tail(c, (dfs_try < 2 && !c->dbg_no_dfs) ? 1024u : K3_TAIL_MAXROUNDS));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
       BCE_TRY(k3_sync_ctl(c, &ctl));
+      if (ctl.stalled) return k3_stalled(c);        // (before skip_round is read: a stalled round does not set it)
       executed = ctl.tail_rounds;
       BCE_TRY(k3_fetch_tail_runs(c, executed));
     } else if (!c->dbg_no_small && !wide_once && cur_nodes <= K3_SMALL_NODES) {
@@ -741,7 +759,9 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
       BCE_TRY(k3_rounds_small(c, batch, cur_nodes, !decaying));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
       BCE_TRY(k3_sync_ctl(c, &ctl));
+      if (ctl.stalled) return k3_stalled(c);        // (before skip_round is read: a stalled round does not set it)
       executed = (ctl.need_flush || ctl.small_bail || ctl.overflow) ? ctl.skip_round - first : batch;
+      if (executed > batch) return k3_bad_skip(c, ctl, first, batch);
       BCE_TRY(k3_fetch_runs(c, first, executed));
       runs_fetched = true;
       if (ctl.small_bail) { BCE_TRY(k3_clear_small_bail(c)); wide_once = true; }
@@ -766,12 +786,13 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
       BCE_TRY(k3_rounds(c, batch, decaying ? cur_nodes : 0));
       BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
       BCE_TRY(k3_sync_ctl(c, &ctl));
+      if (ctl.stalled) return k3_stalled(c);        // (before skip_round is read: a stalled round does not set it)
       executed = (ctl.need_flush || ctl.overflow) ? ctl.skip_round - first : batch;
+      if (executed > batch) return k3_bad_skip(c, ctl, first, batch);
       BCE_TRY(k3_fetch_runs(c, first, executed));
       runs_fetched = true;
     }
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms; }
-    if (ctl.stalled) { snprintf(c->err, sizeof c->err, "k3: a single-launch round waited too long for a predecessor tile (dispatch order not as assumed)"); return BCE_HIP_E_INTERNAL; }
     c->round = first + executed;
     if (executed && runs_fetched) {
       // what the last eight rounds emitted, each (h_runs holds this batch's run table: one entry per round and plane): the
@@ -787,7 +808,7 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
       if (decaying) { for (uint64_t v : recent_syms) est_syms = v > est_syms ? v : est_syms; }
       else est_syms = recent_syms[(recent_at - 1u) & 7u];
     }
-    if (ctl.overflow && !ctl.stalled) {
+    if (ctl.overflow) {
       // the round c->round does not fit the node lists (nothing of it was written): larger lists, the same round again
       BCE_TRY(k3_grow_lists(c, ctl));
       ctl.overflow = 0;
@@ -992,6 +1013,7 @@ int bce_hip_compress_device(bce_hip_ctx *c, const void *d_in, uint32_t n, uint8_
 int bce_hip_get_stats(const bce_hip_ctx *c, bce_hip_stats *out) {
   if (!c || !out) return BCE_HIP_E_ARG;
   *out = c->stats;
+  out->reg_maps = c->reg_maps; out->reg_unmaps = c->reg_unmaps; out->dec_restarts = c->dec_restarts;
   return BCE_HIP_OK;
 }
 

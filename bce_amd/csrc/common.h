@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -61,7 +62,7 @@ struct FlushSlot {
   hipEvent_t ev_start = nullptr, ev_copy = nullptr;   // K4 start (compute stream), outputs in h_out (copy stream)
   bool timed = false;            // the events of the last flush have not been added to stats.t_model yet
   std::shared_ptr<std::once_flag> once;   // the first coder thread to arrive waits for ev_copy, the others for it
-  bool registered = false;       // h_out is malloc'ed memory under hipHostRegister (k4_prepin), not hipHostMalloc's
+  bool registered = false;       // h_out is a private mapping under hipHostRegister (k4_prepin), not hipHostMalloc's
   // staged ahead of its first use, on a thread of its own (k4_prepin): the buffer it prepares, adopted by the next flush
   std::thread pin_th;
   uint64_t *pin_p = nullptr;
@@ -69,10 +70,28 @@ struct FlushSlot {
   double pin_s = 0;
 };
 
-// free a slot's host staging, whichever way it was pinned
+// ---- host memory registered with the runtime (hipHostRegister) ------------------------------------------------------------
+// Rules, each closing one way in which a registered range can lose its pages under the GPU (round 4's
+// "memory access fault ... write access to a read-only page" at an address inside the C library's heap):
+//  1. A registered range is ALWAYS an anonymous private mapping of its own (huge_map) -- never memory carved out of the C
+//     library's heap, whose pages go back to the kernel (brk trim), to other callers and to khugepaged as malloc sees fit.
+//  2. MADV_DONTFORK: a fork() of the host program (Python's subprocess, system()) does not turn the pages copy-on-write under
+//     the device's mapping (what the runtime's own pinned memory has).
+//  3. Huge pages are taken at the FIRST TOUCH only: the caller touches every page (reg_map_settle), then the mapping is
+//     MADV_NOHUGEPAGE -- the huge pages it got stay, but khugepaged never collapses 4 KB pages into a new huge page (= other
+//     physical pages) while the range is registered.
+//  4. hipHostUnregister does not wait for the device (hipHostFree does): before it, the owner waits for exactly the events /
+//     streams whose work touches the range (the slot's copy event; the context's three streams) -- not hipDeviceSynchronize,
+//     which would stall the other contexts of a pool.
+// BCE_HIP_REG_MIN=bytes lowers the sizes from which buffers take this route (defaults: 8 MB for a flush slot, 256 MB for the
+// decoder's boundary ranks) so that tests reach it with small inputs.
+inline size_t reg_min_bytes(size_t dflt) {
+  const char *e = getenv("BCE_HIP_REG_MIN");                          // (read per allocation: a test sets it for one context)
+  return e ? (size_t)strtoull(e, nullptr, 10) : dflt;
+}
 // An anonymous mapping of its own, 2 MB-aligned, with huge pages asked for (3.2 GB are touched in a tenth of the time; the coder
 // threads that read the staging buffers gain 1-2 %): `bytes` usable at the returned
-// address; huge_unmap gives it back.  (The mapping is 2 MB longer than asked; the unaligned head and tail stay unused.)
+// address; huge_unmap gives it back.  (The mapping is 2 MB longer than asked; the unaligned head and tail go back at once.)
 inline void *huge_map(size_t bytes) {
   const size_t two_mb = (size_t)2 << 20, used = (bytes + 4095) & ~(size_t)4095;
   void *base = mmap(nullptr, used + two_mb, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
@@ -81,17 +100,26 @@ inline void *huge_map(size_t bytes) {
   const size_t head = (size_t)(q - static_cast<char *>(base));          // (a multiple of the page size, below 2 MB)
   if (head) (void)munmap(base, head);                                    // what lies in front of the aligned address ...
   if (two_mb - head) (void)munmap(q + used, two_mb - head);              // ... and behind the end goes back at once
+  (void)madvise(q, used, MADV_DONTFORK);                                 // rule 2
   static const bool no_thp = getenv("BCE_HIP_NO_THP") != nullptr;     // (diagnostic: what a host without free huge pages gives)
   if (!no_thp) (void)madvise(q, used, MADV_HUGEPAGE);
   return q;
 }
+// every page of the mapping has been touched: from here on its physical pages stay what they are (rule 3)
+inline void reg_map_settle(void *q, size_t bytes) { (void)madvise(q, (bytes + 4095) & ~(size_t)4095, MADV_NOHUGEPAGE); }
 inline void huge_unmap(void *q, size_t bytes) { if (q) (void)munmap(q, (bytes + 4095) & ~(size_t)4095); }
 // bytes of the mapping k4_prepin makes for a slot of `cap` records
 inline size_t slot_map_bytes(size_t cap) { return (cap * 8 + 16 + 4095) & ~(size_t)4095; }
-inline void slot_free_host(FlushSlot &s) {
+// free a slot's host staging, whichever way it was pinned.  The only device work that touches a slot's staging is the
+// device-to-host copy of its last flush, which ev_copy follows (rule 4; an event never recorded is complete).
+inline void slot_free_host(FlushSlot &s, uint32_t *unmaps = nullptr) {
   if (s.h_out) {
-    if (s.registered) { (void)hipDeviceSynchronize(); (void)hipHostUnregister(s.h_out); huge_unmap(s.h_out, slot_map_bytes(s.cap)); }   // (hipHostFree waits for the device; so does this)
-    else (void)hipHostFree(s.h_out);
+    if (s.registered) {
+      if (s.ev_copy) (void)hipEventSynchronize(s.ev_copy);
+      (void)hipHostUnregister(s.h_out);
+      huge_unmap(s.h_out, slot_map_bytes(s.cap));
+      if (unmaps) ++*unmaps;
+    } else (void)hipHostFree(s.h_out);
   }
   s.h_out = nullptr; s.cap = 0; s.registered = false;
 }
@@ -171,7 +199,8 @@ struct bce_hip_ctx {
   uint64_t dec_cap_next = 0;                     // a decode that ran out of list room starts again with this many nodes per list
   bool dec_list_overflow = false;
   uint32_t dec_restarts = 0;
-  bool h_big_registered = false;                 // h_big came from big_host_alloc's malloc + hipHostRegister
+  uint32_t reg_maps = 0, reg_unmaps = 0;         // registered host mappings made / given back since the context was created
+  bool h_big_registered = false;                 // h_big is big_host_alloc's private mapping under hipHostRegister
   void *dec_pin[3] = {nullptr, nullptr, nullptr};  // the decoder's pinned query / escape-record / answer buffers, kept from one decode to the next (grow-only)
   size_t dec_pin_cap[3] = {0, 0, 0};
   bce::FlushSlot slot[3];                        // flushes in flight: GPU fills one while the coders drain the others
@@ -201,14 +230,14 @@ inline double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// The decoder's large pinned host buffer (the boundary ranks of the host tail: 32 (n + 1) bytes, 3.2 GB at 10^8): from 256 MB on,
-// a private mapping (huge_map), touched by four threads, then registered with the runtime (hipHostRegister, mapped: the
-// device address is the host's, or the buffer is given up).  Measured: 3.2 GB in 0.04 s against hipHostMalloc's
-// 0.55-0.7 s, which also holds the kernels queued meanwhile up.  Only the copy engine and the host touch this buffer.  The
-// buffers KERNELS write (queries, answers) stay hipHostMalloc's: registered ranges of the C library's heap under them gave, in two
-// of five runs of the test suite, "memory access fault: write access to a read-only page".  BCE_DEC_NO_HUGE=1: hipHostMalloc for all.
+// The decoder's large pinned host buffer (the boundary ranks of the host tail: 32 (n + 1) bytes, 3.2 GB at 10^8): from 256 MB on
+// (reg_min_bytes), a private mapping (huge_map), touched by four threads, then registered with the runtime (hipHostRegister,
+// mapped: the device address is the host's, or the buffer is given up).  Measured: 3.2 GB in 0.04 s against
+// hipHostMalloc's 0.55-0.7 s, which also holds the kernels queued meanwhile up.  Only the copy engine and the host touch this
+// buffer.  The small buffers KERNELS write while the host reads (queries, answers, the mailbox) are hipHostMalloc's.
+// BCE_DEC_NO_HUGE=1: hipHostMalloc for all.  big_host_free waits for the owning context's streams first (rule 4 above).
 void *big_host_alloc(size_t bytes, int device, bool *registered);
-void big_host_free(void *p, size_t bytes, bool registered);
+void big_host_free(bce_hip_ctx *c, void *p, size_t bytes, bool registered);
 
 inline int set_err(bce_hip_ctx *c, hipError_t e, const char *what, int line) {
   snprintf(c->err, sizeof c->err, "%s:%d: %s", what, line, hipGetErrorString(e));

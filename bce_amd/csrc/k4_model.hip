@@ -400,8 +400,9 @@ int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   if (slot.pin_th.joinable()) slot.pin_th.join();                    // pinned ahead (k4_prepin): adopt it
   if (slot.pin_p) {
     if (slot.pin_cap > slot.cap) {
-      slot_free_host(slot);
+      slot_free_host(slot, &c->reg_unmaps);
       slot.h_out = slot.pin_p; slot.cap = slot.pin_cap; slot.registered = true;
+      c->reg_maps++;
       c->pin_s += slot.pin_s; c->pin_bytes += slot.pin_cap * 8 + 16; c->pin_calls++;
     } else {
       (void)hipHostUnregister(slot.pin_p); huge_unmap(slot.pin_p, slot_map_bytes(slot.pin_cap));
@@ -409,7 +410,7 @@ int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
     slot.pin_p = nullptr; slot.pin_cap = 0;
   }
   if (slot.cap < nsym) {
-    slot_free_host(slot);
+    slot_free_host(slot, &c->reg_unmaps);
     size_t cap = (size_t)c->sym_cap > nsym ? (size_t)c->sym_cap : nsym;
     BCE_TRY(pin_alloc(c, (void **)&slot.h_out, cap * 8 + 16));
     slot.cap = cap;
@@ -508,7 +509,7 @@ int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
 // the spot as before.
 void k4_prepin(bce_hip_ctx *c, uint32_t n) {
   const size_t cap = (size_t)k3_symbol_capacity(c, n);
-  if (cap * 8 < ((size_t)8 << 20) || c->scan_mode) return;
+  if (cap * 8 < reg_min_bytes((size_t)8 << 20) || c->scan_mode) return;
   for (FlushSlot &slot : c->slot) {
     if (slot.cap >= cap || slot.pin_th.joinable() || slot.pin_p) continue;
     slot.pin_cap = cap;
@@ -517,11 +518,13 @@ void k4_prepin(bce_hip_ctx *c, uint32_t n) {
     try {
       slot.pin_th = std::thread([sp, dev, c] {
         const double t0 = now_s();
-        // (a mapping of its own, not the C library's heap: a registered range shares its pages' fate with nothing else)
+        // (a mapping of its own, never the C library's heap: common.h, "host memory registered with the runtime")
         const size_t bytes = slot_map_bytes(sp->pin_cap);
         void *q = huge_map(bytes);
-        if (q)
+        if (q) {
           for (size_t o = 0; o < bytes; o += 4096) static_cast<volatile uint8_t *>(q)[o] = 0;
+          reg_map_settle(q, bytes);                                     // (its pages are there: they stay what they are)
+        }
         int go;
         { std::unique_lock<std::mutex> lk(c->stage_mu); c->stage_cv.wait(lk, [c] { return c->stage_state != 0; }); go = c->stage_state; }
         if (q && (go != 1 || hipSetDevice(dev) != hipSuccess || hipHostRegister(q, bytes, hipHostRegisterDefault) != hipSuccess)) {

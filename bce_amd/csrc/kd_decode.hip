@@ -1415,8 +1415,9 @@ struct BigPin {
     running = false;
     if (getenv("BCE_DEC_TIMING")) fprintf(stderr, "gpu decode: pinned %.1f GB beside the rounds: %.3f s, the tail waited %.3f s of them\n", bytes / 1e9, t_done - t_start, now_s() - t0);
     if (p) {
-      if (c->h_big) big_host_free(c->h_big, c->h_big_cap, c->h_big_registered);
+      if (c->h_big) big_host_free(c, c->h_big, c->h_big_cap, c->h_big_registered);
       c->h_big = p; c->h_big_cap = bytes; c->h_big_registered = registered; p = nullptr;
+      if (registered) c->reg_maps++;
     }
   }
   ~BigPin() { settle(); }
@@ -1444,8 +1445,9 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
   // 3.2 GB at 10^8 bytes: into pinned memory the context keeps (a copy into fresh pageable memory ran at a fifth of the bus)
   const double tcp0 = now_s();
   if (c->h_big_cap < 8 * stride * 4) {
-    if (c->h_big) { big_host_free(c->h_big, c->h_big_cap, c->h_big_registered); c->h_big = nullptr; c->h_big_cap = 0; }
+    if (c->h_big) { big_host_free(c, c->h_big, c->h_big_cap, c->h_big_registered); c->h_big = nullptr; c->h_big_cap = 0; }
     c->h_big = big_host_alloc(8 * stride * 4, c->device, &c->h_big_registered);
+    if (c->h_big && c->h_big_registered) c->reg_maps++;
     if (!c->h_big) { snprintf(c->err, sizeof c->err, "host tail: no pinned memory for the boundary ranks"); return BCE_HIP_E_NOMEM; }
     c->h_big_cap = 8 * stride * 4;
   }

@@ -45,17 +45,18 @@ static void progress_end() { printf("                    \r"); }
 struct HostFile {
   uint8_t *p = nullptr;
   size_t n = 0;
-  int status = -1;            // 0 ok, -1 not found / unreadable, -2 short read
+  int status = -1;            // 0 ok, -1 not found / unreadable, -2 short read, -3 at or above the caller's size limit (nothing read)
   ~HostFile() { free(p); }
   const uint8_t *data() const { return p; }
   size_t size() const { return n; }
 };
-static void read_whole_file(const char *path, HostFile *f) {
+static void read_whole_file(const char *path, HostFile *f, size_t limit) {
   const int fd = open(path, O_RDONLY | O_CLOEXEC);
   if (fd < 0) return;
   struct stat st;
   if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 0) { close(fd); return; }
   const size_t n = (size_t)st.st_size;
+  if (limit && n >= limit) { close(fd); f->n = n; f->status = -3; return; }   // too large for the caller: not read at all
   f->p = static_cast<uint8_t *>(malloc(n ? n : 1));
   if (!f->p) { close(fd); return; }
   size_t got = 0;
@@ -67,6 +68,19 @@ static void read_whole_file(const char *path, HostFile *f) {
   close(fd);
   f->n = got;
   f->status = got == n ? 0 : -2;
+}
+
+// n < 2^31: saidx_t / the 31-bit getv of the header (bce.cpp:173,374,901)
+static const size_t kMaxInput = (size_t)0x80000000ull;
+
+// Writes the whole output and says whether it arrived: a short or failed write (ENOSPC, EIO) must not end in the success
+// line and exit code 0 -- after fast_exit nothing later could report it.
+static bool write_file(const char *path, const void *p, size_t bytes) {
+  std::ofstream f(std::string(path), std::ios::binary | std::ios::trunc);
+  if (!f) return false;
+  f.write(static_cast<const char *>(p), (std::streamsize)bytes);
+  f.close();
+  return f.good();
 }
 
 // The output is on disk and stdout is flushed: leave without the tear-down of 20 GB of device buffers, 400 MB of pinned
@@ -128,8 +142,10 @@ static int compress_blocks(const HostFile &data, uint32_t nblocks, const uint8_t
   // one context that has the device to itself.  Only a block that does not fit even then fails.
   std::mutex deferred_mu;
   std::vector<uint32_t> deferred;
-  const char *test_nomem = getenv("BCE_CLI_TEST_NOMEM_BLOCK");      // (test hook: this block's first attempt "runs out of memory")
-  const long test_block = test_nomem ? atol(test_nomem) : -1;
+  const char *test_nomem = getenv("BCE_CLI_TEST_NOMEM_BLOCK");      // (test hook: this block's first attempt "runs out of memory"; "all": every block's)
+  const bool test_all = test_nomem && strcmp(test_nomem, "all") == 0;
+  const long test_block = test_nomem && !test_all ? atol(test_nomem) : -1;
+  std::vector<char> done(nblocks, 0);                               // block b's archive is in arch[b]
   std::vector<std::thread> th;
   for (size_t d = 0; d < ctx.size(); ++d)
     th.emplace_back([&, d] {
@@ -137,9 +153,10 @@ static int compress_blocks(const HostFile &data, uint32_t nblocks, const uint8_t
         const uint32_t b = next_block.fetch_add(1);
         if (b >= nblocks) break;
         size_t alen = 0;
-        int rc = ((long)b == test_block) ? BCE_HIP_E_NOMEM
+        int rc = (test_all || (long)b == test_block) ? BCE_HIP_E_NOMEM
                                          : bce_hip_compress(ctx[d], data.data() + lo[b], (uint32_t)(lo[b + 1] - lo[b]), nullptr, 0, &alen);
         if (rc == 0) { arch[b].resize(alen); rc = bce_hip_archive_copy(ctx[d], arch[b].data(), alen); }
+        if (rc == 0) done[b] = 1;
         if (rc == BCE_HIP_E_NOMEM) {
           { std::lock_guard<std::mutex> lk(deferred_mu); deferred.push_back(b); }
           bce_hip_destroy(ctx[d]);
@@ -157,8 +174,13 @@ static int compress_blocks(const HostFile &data, uint32_t nblocks, const uint8_t
     if (rcs[d] && !rc) { rc = rcs[d]; printf("%s\n", bce_hip_last_error(ctx[d])); }
     bce_hip_destroy(ctx[d]);
   }
+  // Every worker may have left that way (another tenant on the device, blocks too large for four contexts side by side):
+  // the blocks nobody took are then in no list.  Whatever has no archive yet is compressed here, one block at a time.
+  if (!rc) {
+    deferred.clear();
+    for (uint32_t b = 0; b < nblocks; ++b) if (!done[b]) deferred.push_back(b);
+  }
   if (!rc && !deferred.empty()) {
-    std::sort(deferred.begin(), deferred.end());
     bce_hip_ctx *c = nullptr;
     rc = bce_hip_create(&c, 0);
     if (rc == 0 && config) rc = bce_hip_set_config(c, config);
@@ -167,11 +189,14 @@ static int compress_blocks(const HostFile &data, uint32_t nblocks, const uint8_t
       size_t alen = 0;
       rc = bce_hip_compress(c, data.data() + lo[b], (uint32_t)(lo[b + 1] - lo[b]), nullptr, 0, &alen);
       if (rc == 0) { arch[b].resize(alen); rc = bce_hip_archive_copy(c, arch[b].data(), alen); }
+      if (rc == 0) done[b] = 1;
     }
     if (rc && c) printf("%s\n", bce_hip_last_error(c));
     if (c) bce_hip_destroy(c);
   }
   if (rc) return rc;
+  for (uint32_t b = 0; b < nblocks; ++b)
+    if (!done[b] || arch[b].empty()) return BCE_HIP_E_INTERNAL;     // a container never goes out with a block missing
   out.clear();
   out.insert(out.end(), {'B', 'C', 'E', 'M'});
   put_u32(out, 1);
@@ -204,7 +229,7 @@ int main(int argc, char **argv) {
   if ((argc == 4 || argc == 5) && argv[1][0] == '-' && argv[1][1] == 'c') {
     auto start = std::chrono::high_resolution_clock::now();
     HostFile data;
-    std::thread reader(read_whole_file, argv[3], &data);           // File::File, bce.cpp:842-856 -- beside the runtime's start-up
+    std::thread reader(read_whole_file, argv[3], &data, kMaxInput);  // File::File, bce.cpp:842-856 -- beside the runtime's start-up
     bce_hip_ctx *ctx = nullptr;
     uint64_t expect = 0;                                          // the file's size, if it says: what the context prepares for
     { struct stat st; if (stat(argv[3], &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) expect = (uint64_t)st.st_size; }
@@ -236,7 +261,7 @@ int main(int argc, char **argv) {
       }
     }
     reader.join();
-    if (data.status != 0 || data.size() == 0 || data.size() >= (size_t)0x80000000ull) {   // also covers the empty file, on which the reference crashes
+    if (data.status != 0 || data.size() == 0 || data.size() >= kMaxInput) {   // also covers the empty file, on which the reference crashes
       printf("Error loading file\n");
       bce_hip_destroy(ctx);
       return -1;
@@ -250,10 +275,8 @@ int main(int argc, char **argv) {
       rc = compress_blocks(data, nblocks, cfgbuf.empty() ? nullptr : cfgbuf.data(), blob);
       if (rc != 0) { printf("Compression failed: %s\n", bce_hip_strerror(rc)); return -4; }
       std::chrono::duration<double> duration = std::chrono::high_resolution_clock::now() - start;
+      if (!write_file(argv[2], blob.data(), blob.size())) { printf("Could not write Archive.\n"); return -5; }
       printf("Compressed from %zu B -> %zu B in %.1f s\n", data.size(), blob.size(), duration.count());
-      std::ofstream archive(std::string(argv[2]), std::ios::binary | std::ios::trunc);
-      archive.write(reinterpret_cast<const char *>(blob.data()), (std::streamsize)blob.size());
-      archive.close();
       fast_exit(0);
       return 0;
     }
@@ -272,10 +295,8 @@ int main(int argc, char **argv) {
     bce_hip_archive_copy(ctx, arch.data(), arch.size());
     auto end = std::chrono::high_resolution_clock::now();
     std::chrono::duration<double> duration = end - start;
+    if (!write_file(argv[2], arch.data(), arch.size())) { printf("Could not write Archive.\n"); bce_hip_destroy(ctx); return -5; }
     printf("Compressed from %zu B -> %zu B in %.1f s\n", data.size(), arch.size(), duration.count());
-    std::ofstream archive(std::string(argv[2]), std::ios::binary | std::ios::trunc);
-    archive.write(reinterpret_cast<const char *>(arch.data()), (std::streamsize)arch.size());
-    archive.close();
     lap("written");
     fast_exit(0);
     bce_hip_destroy(ctx);
@@ -286,7 +307,7 @@ int main(int argc, char **argv) {
     auto start = std::chrono::high_resolution_clock::now();
     HostFile adata;
     const bool use_gpu = argv[1][2] != 's';
-    std::thread reader(read_whole_file, argv[3], &adata);          // beside the runtime's start-up (-d)
+    std::thread reader(read_whole_file, argv[3], &adata, (size_t)0); // beside the runtime's start-up (-d)
     bce_hip_ctx *ctx0 = nullptr;
     int rc0 = use_gpu ? bce_hip_create(&ctx0, 0) : 0;
     reader.join();
@@ -420,12 +441,10 @@ int main(int argc, char **argv) {
     if (rc != 0) { printf("Decompression failed: %s\n", bce_hip_strerror(rc)); return -4; }
     auto end = std::chrono::high_resolution_clock::now();
     std::chrono::duration<double> duration = end - start;
-    printf("Decompressed from %zu B -> %zu B in %.1f s\n", adata.size(), out_size, duration.count());
-    std::ofstream file(std::string(argv[2]), std::ios::binary | std::ios::trunc);
-    file.write(reinterpret_cast<const char *>(out.get()), (std::streamsize)out_size);
-    file.close();
-    lap("written");
     if (prefault.joinable()) prefault.join();
+    if (!write_file(argv[2], out.get(), out_size)) { printf("Could not write file.\n"); if (keep) bce_hip_destroy(keep); return -5; }
+    printf("Decompressed from %zu B -> %zu B in %.1f s\n", adata.size(), out_size, duration.count());
+    lap("written");
     fast_exit(0);
     if (keep) bce_hip_destroy(keep);
     return 0;
@@ -433,12 +452,12 @@ int main(int argc, char **argv) {
     // Scan (bce.cpp:1384-1402): enumeration on the GPU, ScanCoder optimisation on the host, 288-byte config out
     auto start = std::chrono::high_resolution_clock::now();
     HostFile data;
-    std::thread reader(read_whole_file, argv[3], &data);
+    std::thread reader(read_whole_file, argv[3], &data, kMaxInput);
     bce_hip_ctx *ctx = nullptr;
     int rc = bce_hip_create(&ctx, 0);
     reader.join();
     if (rc != 0) { printf("No usable HIP device: %s\n", bce_hip_strerror(rc)); return -3; }
-    if (data.status != 0 || data.size() == 0 || data.size() >= (size_t)0x80000000ull) { printf("Error loading file\n"); bce_hip_destroy(ctx); return -1; }
+    if (data.status != 0 || data.size() == 0 || data.size() >= kMaxInput) { printf("Error loading file\n"); bce_hip_destroy(ctx); return -1; }
     uint8_t cfg[BCE_HIP_CONFIG_BYTES];
     double res[9];
     rc = bce_hip_load_host(ctx, data.data(), (uint32_t)data.size());
@@ -450,12 +469,10 @@ int main(int argc, char **argv) {
     progress_end();
     if (rc != 0) { printf("Scan failed: %s (%s)\n", bce_hip_strerror(rc), bce_hip_last_error(ctx)); bce_hip_destroy(ctx); return -4; }
     for (int i = 0; i < 9; ++i) printf("Result size: %.1f B\n", res[i]);            // ScanCoder::flush, :799
-    std::ofstream f(std::string(argv[2]), std::ios::binary | std::ios::trunc);     // save_config, :810-813
-    f.write(reinterpret_cast<const char *>(cfg), BCE_HIP_CONFIG_BYTES);
+    if (!write_file(argv[2], cfg, BCE_HIP_CONFIG_BYTES)) { printf("Could not write Config.\n"); bce_hip_destroy(ctx); return -5; }   // save_config, :810-813
     auto end = std::chrono::high_resolution_clock::now();
     std::chrono::duration<double> duration = end - start;
     printf("Scanned %zu B in %.1f s\n", data.size(), duration.count());
-    f.close();
     fast_exit(0);
     bce_hip_destroy(ctx);
     return 0;

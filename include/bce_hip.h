@@ -193,6 +193,10 @@ typedef struct bce_hip_stats {
   double t_coder_busy;         /* busiest host coder thread (t_coder is only the part not hidden behind GPU work) */
   double list_grows;           /* times a round did not fit the node lists and they were doubled (k3_grow_lists) */
   double list_nodes;           /* nodes per list at the end */
+  /* since the context was created (not reset by a load): */
+  double reg_maps;             /* host mappings registered with the runtime (flush slots, the decoder's boundary ranks) */
+  double reg_unmaps;           /* ... and given back (after waiting for the work that touches them) */
+  double dec_restarts;         /* GPU-assisted decodes started again with larger node lists (kd_decode.hip) */
 } bce_hip_stats;
 int bce_hip_get_stats(const bce_hip_ctx *ctx, bce_hip_stats *out);
 

@@ -97,6 +97,43 @@ def test_cli_block_that_ran_out_of_memory_is_compressed_at_the_end(tmp_path):
     assert a1.read_bytes() == a2.read_bytes()
 
 
+def test_cli_every_context_runs_out_of_memory_and_no_block_is_lost(tmp_path):
+    """Round-4 advice: when EVERY worker of `bce -cN` leaves with "out of memory" (another tenant on the device), the blocks
+    nobody had taken yet were in no list and the container went out with 0-byte archives, exit code 0.  With
+    BCE_CLI_TEST_NOMEM_BLOCK=all every first attempt fails; nine blocks on one GPU means four workers and five blocks that no
+    worker ever draws.  The container must still be the undisturbed one -- or the exit code non-zero, never a hollow file."""
+    from bce_amd import container, sharding
+    data = oracle.synth_text(18, 900007)
+    src, a1, a2 = tmp_path / "in.txt", tmp_path / "a1.bcem", tmp_path / "a2.bcem"
+    src.write_bytes(data)
+    r = subprocess.run([EXE, "-c9", str(a1), str(src)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([EXE, "-c9", str(a2), str(src)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, BCE_CLI_TEST_NOMEM_BLOCK="all"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert a1.read_bytes() == a2.read_bytes()
+    archives, sizes = container.unpack_blocks(a2.read_bytes())
+    assert len(archives) == 9 and all(len(a) > 0 for a in archives)
+    for b in range(9):
+        lo, hi = sharding.block_range(len(data), 9, b)
+        assert archives[b] == oracle.compress(data[lo:hi])
+
+
+def test_cli_failed_write_is_not_a_success(tmp_path):
+    """The output cannot be written (the directory does not exist): no success line, non-zero exit code -- the fast exit
+    right behind the write must not hide it (-c, -cN, -d, -s)."""
+    data = oracle.synth_text(19, 50000)
+    src, arc = tmp_path / "in.txt", tmp_path / "a.bce"
+    src.write_bytes(data)
+    arc.write_bytes(oracle.compress(data))
+    nowhere = str(tmp_path / "no_such_dir" / "x")
+    for args in (["-c", nowhere, str(src)], ["-c2", nowhere, str(src)], ["-d", nowhere, str(arc)], ["-ds", nowhere, str(arc)],
+                 ["-s", nowhere, str(src)]):
+        r = subprocess.run([EXE] + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 251, (args, r.returncode, r.stdout, r.stderr)
+        assert "Could not write" in r.stdout and "Compressed from" not in r.stdout and "Decompressed from" not in r.stdout
+
+
 def test_cli_many_blocks_on_few_gpus(tmp_path):
     """`bce -c11` on a box with fewer GPUs than blocks: up to four gated contexts per device take the blocks in turn
     (main.cpp compress_blocks); every block is still exactly `bce -c` of its bytes, whichever context coded it."""

@@ -97,3 +97,58 @@ def test_scanned_table_at_silesia_size_equals_the_oracles():
     torch.cuda.empty_cache()
     assert st["nodes"] == 8 * v["n"] - 8
     assert len(arch) == v["archive_bytes"] and hashlib.sha256(arch).hexdigest() == v["archive_sha256"]
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("world", [8, 4])
+def test_config4_blocks_of_the_1e9_input_equal_the_oracles(world, tmp_path):
+    """BASELINE configs[3] in its stated form, as far as ONE GPU can run it: synth-text v1 seed 1, 10^9 B, cut into `world`
+    contiguous blocks by sharding.block_range (what rank r of bench.py --gpus N compresses), every block compressed on the HIP
+    path -- through a ContextPool of four contexts, then once more by `bce -cN` on the file -- and compared with the
+    oracle-made archive of that block alone (tests/golden/oracle_fullsize.json, synth-text-1e9-bRofN; one block per archive,
+    bce.cpp:1151-1157).  The container `bce -cN` writes must be exactly those archives behind the block table, and decode
+    back to the input.  What is left for hardware to show is RCCL with more than one rank."""
+    import os
+    import subprocess
+
+    import numpy as np
+    from bce_amd import container, sharding
+    from conftest import ROOT
+    whole = GOLD["synth-text-1e9"]
+    data = fullsize_input(whole)
+    assert data is not None and len(data) == 1_000_000_000
+    ranges = [sharding.block_range(len(data), world, r) for r in range(world)]
+    gold = [GOLD["synth-text-1e9-b%dof%d" % (r, world)] for r in range(world)]
+    for (lo, hi), v in zip(ranges, gold):
+        assert hi - lo == v["n"] and hashlib.sha256(data[lo:hi].tobytes()).hexdigest() == v["input_sha256"]
+    with bce_amd.ContextPool(4, 0) as pool:
+        res = pool.compress_many([data[lo:hi] for lo, hi in ranges], with_stats=True)
+    for r, ((arch, st), v) in enumerate(zip(res, gold)):
+        assert st["nodes"] == 8 * v["n"] - 8, r
+        assert len(arch) == v["archive_bytes"] and hashlib.sha256(arch).hexdigest() == v["archive_sha256"], "block %d of %d" % (r, world)
+    want_container = container.pack_blocks([bytes(a) for a, _ in res], [hi - lo for lo, hi in ranges])
+    del res
+    # the command line on the same bytes: `bce -cN` (main.cpp compress_blocks: up to four gated contexts on the one device)
+    exe = os.path.join(ROOT, "bce_amd", "bin", "bce")
+    src, arc, back = tmp_path / "in.bin", tmp_path / "a.bcem", tmp_path / "back.bin"
+    data.tofile(str(src))
+    r_ = subprocess.run([exe, "-c%d" % world, str(arc), str(src)], capture_output=True, text=True, timeout=900)
+    assert r_.returncode == 0, r_.stdout + r_.stderr
+    blob = arc.read_bytes()
+    assert blob == want_container
+    del want_container
+    archives, raws = container.unpack_blocks(blob)
+    assert raws == [hi - lo for lo, hi in ranges]
+    assert [hashlib.sha256(a).hexdigest() for a in archives] == [v["archive_sha256"] for v in gold]
+    del archives, blob
+    if world == 8:                                              # and back: the blocks decoded side by side, the file put together
+        r_ = subprocess.run([exe, "-d", str(back), str(arc)], capture_output=True, text=True, timeout=900)
+        assert r_.returncode == 0, r_.stdout + r_.stderr
+        h = hashlib.sha256()
+        with open(back, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 24), b""):
+                h.update(chunk)
+        assert h.hexdigest() == whole["input_sha256"]
+    for p in (src, arc, back):
+        if p.exists():
+            p.unlink()
