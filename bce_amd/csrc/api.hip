@@ -94,6 +94,35 @@ void big_host_free(bce_hip_ctx *c, void *p, size_t bytes, bool registered) {
   } else (void)hipHostFree(p);
 }
 
+// Out of device memory while phase `c->phase` runs: what only OTHER phases use goes back (the context keeps every stage's buffers
+// from one input to the next -- K1's ~45 n bytes of sort scratch beside node lists of up to 72 n bytes do not fit at n ~ 2^31).
+// Nothing that is given back can be in use: K1 and K2 end with their work complete, the enumeration starts after them, and a
+// decode owns the whole context.
+size_t ctx_trim(bce_hip_ctx *c) {
+  std::vector<DevBuf *> give;
+  if (c->phase == 3) {
+    // the enumeration and the model keep the text, the BWT, the suffix array and its inverse (the depth-first tail), the planes
+    give = {&c->sa[c->sa_res ^ 1], &c->key[0], &c->key[1], &c->k2, &c->nrk, &c->act[0], &c->act[1], &c->khi[0], &c->khi[1],
+            &c->dl[0], &c->dl[1], &c->dl[2], &c->dl[3], &c->kflag, &c->actv[0], &c->actv[1], &c->ptmp[0], &c->ptmp[1]};
+  } else if (c->phase == 1 || c->phase == 2) {
+    give = {&c->nlist[0], &c->nlist[1], &c->dfs, &c->tilecnt, &c->tileoff, &c->k3tw, &c->k3grp, &c->skey[0], &c->skey[1], &c->sval[0],
+            &c->sval[1], &c->sout, &c->sesc, &c->skey_alt, &c->sesc_alt, &c->scanrec, &c->k4w};
+    if (c->phase == 1) give.push_back(&c->gran);
+  } else if (c->phase == 4) {
+    give = {&c->nlist[1], &c->sout, &c->k4w, &c->scanrec, &c->skey_alt, &c->sesc_alt};
+  }
+  size_t freed = 0;
+  bool synced = false;
+  for (DevBuf *b : give) {
+    if (!b->p) continue;
+    if (!synced) { for (hipStream_t st : {c->stream, c->k4_stream, c->copy_stream}) if (st) (void)hipStreamSynchronize(st); synced = true; }
+    freed += b->cap;
+    release(*b);
+  }
+  if (freed && getenv("BCE_ALLOC_TRACE")) fprintf(stderr, "alloc: out of device memory in phase %d: %.1f GB of other phases' buffers given back\n", c->phase, freed / 1e9);
+  return freed;
+}
+
 RoctxRange::RoctxRange(const char *name) : on_(roctx().push != nullptr) { if (on_) roctx().push(name); }
 RoctxRange::~RoctxRange() { if (on_) roctx().pop(); }
 }  // namespace bce
@@ -357,7 +386,7 @@ void bce_hip_destroy(bce_hip_ctx *c) {
   if (c->k4_stream) (void)hipStreamSynchronize(c->k4_stream);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   DevBuf *bufs[] = {&c->text, &c->bwt, &c->sa[0], &c->sa[1], &c->key[0], &c->key[1], &c->rank, &c->k2, &c->nrk, &c->act[0], &c->act[1], &c->khi[0], &c->khi[1], &c->dl[0], &c->dl[1], &c->dl[2], &c->dl[3], &c->kflag, &c->actv[0], &c->actv[1],
-                    &c->rs_hist, &c->blk, &c->ptmp[0], &c->ptmp[1], &c->gran, &c->nodes, &c->ctl, &c->tilecnt,
+                    &c->rs_hist, &c->blk, &c->ptmp[0], &c->ptmp[1], &c->gran, &c->nlist[0], &c->nlist[1], &c->ctl, &c->tilecnt,
                     &c->tileoff, &c->runs, &c->smwords, &c->k3tw, &c->k3grp, &c->truns, &c->skey[0], &c->skey[1], &c->sval[0], &c->sval[1], &c->sout,
                     &c->sesc, &c->stat, &c->dcfg, &c->k4w, &c->scanrec, &c->dfs, &c->skey_alt, &c->sesc_alt, &c->rs_hist_k4};
   for (DevBuf *b : bufs) release(*b);
@@ -467,6 +496,8 @@ static int bwt_body(bce_hip_ctx *c, uint32_t *offset) {
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   const double t0 = now_s();
   RoctxRange range("bce K1 rotation sort + BWT");
+  c->phase = 1;
+  struct PhaseEnd { bce_hip_ctx *c; ~PhaseEnd() { c->phase = 0; } } phase_end{c};
   BCE_TRY(k1_bwt(c));
   c->stats.t_bwt = now_s() - t0;
   c->stage = 2;
@@ -499,6 +530,8 @@ int bce_hip_divbwt(bce_hip_ctx *c, const uint8_t *in, uint8_t *out, uint32_t n, 
   return bce_guarded(c, [&]() -> int {
     BCE_HIP_TRY(c, hipSetDevice(c->device));
     c->coder->drain();
+    c->phase = 1;
+    struct PhaseEnd { bce_hip_ctx *c; ~PhaseEnd() { c->phase = 0; } } phase_end{c};
     return k1_divbwt(c, in, out, n, primary);
   });
 }
@@ -519,6 +552,8 @@ static int planes_body(bce_hip_ctx *c, uint32_t zeros[8]) {
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   const double t0 = now_s();
   RoctxRange range("bce K2 planes + rank directory");
+  c->phase = 2;
+  struct PhaseEnd { bce_hip_ctx *c; ~PhaseEnd() { c->phase = 0; } } phase_end{c};
   BCE_TRY(k2_build_planes(c));
   c->stats.t_planes = now_s() - t0;
   c->stage = 3;
@@ -544,6 +579,7 @@ int bce_hip_rank1(bce_hip_ctx *c, int plane, const uint32_t *idx, uint32_t count
 // ---- stepping interface ---------------------------------------------------------------------------
 int bce_hip_enum_begin(bce_hip_ctx *c) {
   BCE_TRY(check_stage(c, 3));
+  c->phase = 3;
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   BCE_TRY(k4_prepare(c));
   BCE_TRY(k3_begin(c));
@@ -618,9 +654,12 @@ int bce_hip_enum_model(bce_hip_ctx *c, uint32_t *out, uint64_t cap_records, uint
 // ---- BCE::encode ------------------------------------------------------------------------------------
 static int encode_body(bce_hip_ctx *c);
 static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(uint64_t)> &sink);
+static int split_round(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(uint64_t)> &sink, bool *executed);
 int bce_hip_encode(bce_hip_ctx *c) { return gate_on_error(c, bce_guarded(c, [&] { return encode_body(c); })); }
 static int encode_body(bce_hip_ctx *c) {
   BCE_TRY(check_stage(c, 3));
+  c->phase = 3;
+  struct PhaseEnd { bce_hip_ctx *c; ~PhaseEnd() { c->phase = 0; } } phase_end{c};
   c->gate_wait_s = 0; c->gate_held_s = 0; c->gate_lent = false;
   const double t_enc0 = now_s();
   gate_acquire(c);
@@ -664,8 +703,56 @@ static int encode_body(bce_hip_ctx *c) {
 // The round loop of BCE::code (bce.cpp:1246-1371) as the host drives it: wide rounds in batches, one-launch rounds, the
 // LDS tail kernel, the depth-first tail.  `sink(nsym)` takes the symbol records buffered so far (the model flush of -c,
 // the ScanCoders of -s) and leaves the buffer empty.
+// A round whose symbols do not fit ONE model flush (K4 takes fewer than 2^31 records; BCE_HIP_SPLIT_SYMS lowers the limit for
+// tests).  The planes' streams are independent, so the round is run once per GROUP of planes -- every pass classifies all
+// nodes and writes all children (the same values to the same places: the parents' lists are not touched), records only its
+// group's symbols (K3Args::pmask) and is flushed on its own; a plane's records of one round never exceed n/2 < 2^30.
+// *executed: the round is done (ctl = the control block after its last pass, its symbols flushed); false: its lists were too
+// small, they have been grown and the caller runs the round again.
+static int split_round(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(uint64_t)> &sink, bool *executed) {
+  *executed = false;
+  // pass 0, all planes, three launches: either the round fits after all (the one-launch rounds only know an upper bound), or
+  // the per-plane counts are in the control block afterwards
+  BCE_TRY(k3_clear_need_flush(c));
+  BCE_TRY(k3_round_masked(c, 0xFFu, false));
+  BCE_TRY(k3_sync_ctl(c, &ctl));
+  if (ctl.stalled) return k3_stalled(c);
+  if (ctl.overflow) { BCE_TRY(k3_grow_lists(c, ctl)); ctl.overflow = 0; return BCE_HIP_OK; }
+  if (!ctl.need_flush) {
+    BCE_TRY(k3_fetch_runs(c, c->round, 1));
+    BCE_TRY(sink(ctl.sym_total));
+    ctl.sym_total = 0;
+    *executed = true;
+    return BCE_HIP_OK;
+  }
+  uint64_t cnt[8], maxp = 0;
+  for (int q = 0; q < 8; ++q) { cnt[q] = ctl.ptot[q][2]; if (cnt[q] > maxp) maxp = cnt[q]; }
+  if (maxp + 1024 > c->sym_cap) BCE_TRY(k3_grow_symbols(c, maxp + 1024));      // (< 2^30 + 1025)
+  bool first = true;
+  for (int q = 0; q < 8;) {
+    uint32_t mask = 0;
+    uint64_t acc = 0;
+    while (q < 8 && (mask == 0 || acc + cnt[q] <= c->sym_cap)) { mask |= 1u << q; acc += cnt[q]; ++q; }
+    BCE_TRY(k3_clear_need_flush(c));
+    BCE_TRY(k3_round_masked(c, mask, !first));
+    BCE_TRY(k3_sync_ctl(c, &ctl));
+    if (ctl.stalled) return k3_stalled(c);
+    if (ctl.need_flush || ctl.overflow) { snprintf(c->err, sizeof c->err, "k3: pass of planes %#x of round %u does not fit (%llu symbols, room for %llu)", mask, c->round, (unsigned long long)acc, (unsigned long long)c->sym_cap); return BCE_HIP_E_INTERNAL; }
+    BCE_TRY(k3_fetch_runs(c, c->round, 1));
+    BCE_TRY(sink(ctl.sym_total));
+    BCE_TRY(gate_regain(c));
+    ctl.sym_total = 0;
+    first = false;
+  }
+  c->stats.split_rounds += 1.0;
+  *executed = true;
+  return BCE_HIP_OK;
+}
+
 static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(uint64_t)> &sink) {
   const uint32_t n = c->n;
+  uint64_t split_limit = 1ull << 31;
+  if (const char *e = getenv("BCE_HIP_SPLIT_SYMS")) { const uint64_t v = strtoull(e, nullptr, 10); if (v && v < split_limit) split_limit = v; }
   uint64_t cur_nodes = 0;
   for (int i = 0; i < 8; ++i) { const uint32_t Ci = c->zeros[(i + 7) & 7]; cur_nodes += (Ci && n - Ci) ? 1 : 0; }
   bool decaying = false;
@@ -821,7 +908,7 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
     {
       static const bool plane_trace = getenv("BCE_HIP_PLANE_TRACE") != nullptr;
       if (plane_trace) {
-        fprintf(stderr, "round %u: %u nodes next, k3 %.2f ms so far; per plane:", c->round, ctl.next_nodes, c->stats.k3_ms);
+        fprintf(stderr, "round %u: %llu nodes next, k3 %.2f ms so far; per plane:", c->round, (unsigned long long)ctl.next_nodes, c->stats.k3_ms);
         for (int p = 0; p < 8; ++p) fprintf(stderr, " %u", ctl.cnt[c->round & 1u][p][0] + ctl.cnt[c->round & 1u][p][1]);
         fprintf(stderr, "\n");
       }
@@ -833,9 +920,25 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
     const bool done = ctl.done_round != 0xFFFFFFFFu;
     if (ctl.need_flush) {
       if (ctl.sym_total == 0) {
-        // one round alone exceeds the symbol buffer: enlarge it and run the round again
+        // one round alone exceeds the symbol buffer: enlarge it and run the round again -- or, when the round emits more than
+        // one model flush can take (2^31 records: a high-entropy input of more than ~10^9 bytes), plane group by plane group
         uint64_t want = ctl.want_syms + (ctl.want_syms >> 3) + 1024;
-        if (want >= (1ull << 31)) { snprintf(c->err, sizeof c->err, "one round emits %llu symbols (> 2^31)", (unsigned long long)ctl.want_syms); return BCE_HIP_E_OVERFLOW; }
+        if (want >= split_limit) {
+          bool executed_round = false;
+          BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+          BCE_TRY(split_round(c, ctl, sink, &executed_round));
+          BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+          BCE_HIP_TRY(c, hipEventSynchronize(c->ev1));
+          { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms; }
+          if (!executed_round) continue;           // (the lists were too small for it: grown, the round comes again)
+          c->round += 1;
+          est_syms = 0;
+          if (c->progress) c->progress(ctl.nodes_total, 8ull * n, c->progress_user);
+          decaying = ctl.next_nodes <= cur_nodes && c->round > 16;
+          cur_nodes = ctl.next_nodes;
+          if (ctl.done_round != 0xFFFFFFFFu) break;
+          continue;
+        }
         BCE_TRY(k3_grow_symbols(c, want));
         continue;
       }
@@ -875,7 +978,8 @@ static int scan_body(bce_hip_ctx *c, uint8_t *config288, double *result_bytes) {
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   c->coder->drain();
   c->scan_mode = true;
-  struct Reset { bce_hip_ctx *c; ~Reset() { c->scan_mode = false; } } reset{c};
+  c->phase = 3;
+  struct Reset { bce_hip_ctx *c; ~Reset() { c->scan_mode = false; c->phase = 0; } } reset{c};
   BCE_TRY(k4_prepare(c));
   BCE_TRY(k3_begin(c));
   c->stats.t_coder = 0;

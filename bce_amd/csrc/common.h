@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <exception>
@@ -41,8 +42,7 @@ struct EnumCtl {
   uint32_t skip_round;       // first skipped round
   uint32_t done_round;       // first round whose successor is empty (0xFFFFFFFF while running)
   uint32_t overflow;         // node buffer overflow (fatal)
-  uint32_t next_nodes;       // node total of the next round (after the last executed round)
-  uint32_t pad;
+  uint64_t next_nodes;       // node total of the next round (after the last executed round): up to 8 (n/2) = 2^33
   uint64_t want_syms;        // symbol records of the skipped round (to grow the buffer when one round exceeds it)
   uint32_t ticket;           // k3_scan_kernel: arrival counter of its 8 plane blocks (last one runs the epilogue)
   uint32_t pad1;
@@ -50,7 +50,7 @@ struct EnumCtl {
   uint64_t symbase[8];       // symbol-buffer base of each plane's records in this round
   uint32_t tail_rounds;      // rounds executed by the last k3_tail_kernel launch
   uint32_t small_bail;       // k3_small_kernel: the round (skip_round) does not fit its grid / tile table: run it wide
-  uint32_t sm_ticket;        // (unused: k3_small_kernel took its tiles from this counter; one address takes ~88 atomics per us)
+  uint32_t want_list;        // with `overflow`: the longest list the skipped round would write (the host makes that room: k3_grow_lists)
   uint32_t stalled;          // a single-launch round waited K3_SPIN_LIMIT polls for a predecessor tile's word: fatal, loud (see wait_word)
 };
 
@@ -150,6 +150,9 @@ struct bce_hip_ctx {
 
   uint32_t n = 0;
   int stage = 0;  // 0 empty, 1 loaded, 2 bwt, 3 planes, 4 encoded
+  int phase = 0;  // what is running: 1 K1, 2 K2, 3 the enumeration / model (-c, -s), 4 a decode; 0 nothing.  ctx_trim() gives back the
+                  // buffers the running phase does not use when the device runs out of memory (the context keeps every stage's
+                  // buffers for its next input; at n ~ 2^31 they do not all fit together)
   uint32_t offset = 0;
   uint8_t config[9][32];
   bce::PlaneCfg cfg[8];
@@ -173,7 +176,11 @@ struct bce_hip_ctx {
   bce::DevBuf ptmp[2];                           // K2 byte ping-pong
   bce::DevBuf gran;                              // 8 planes x ngran x 16 B
   uint32_t ngran = 0;                            // granules per plane
-  bce::DevBuf nodes;                             // 2 parities x 8 planes x capP nodes
+  // node lists: one buffer per round parity, 8 planes x capL[parity] nodes each (a round reads one parity and writes the
+  // other; the one about to be written holds nothing and can be replaced by a larger one without a copy: k3_grow_lists).
+  // The decoder keeps both parities in nlist[0]: 2 x 8 planes x capP nodes.
+  bce::DevBuf nlist[2];
+  uint32_t capL[2] = {0, 0};
   uint32_t capP = 0;
   bce::DevBuf ctl, tilecnt, tileoff, runs;       // K3 control
   bce::DevBuf smwords;                           // k3_small_kernel: one published count word per tile
@@ -256,6 +263,15 @@ inline int set_err(bce_hip_ctx *c, hipError_t e, const char *what, int line) {
     if (_rc != BCE_HIP_OK) return _rc; \
   } while (0)
 
+size_t ctx_trim(bce_hip_ctx *c);                   // api.hip: bytes given back (0: nothing left to give)
+// BCE_HIP_TEST_OOM=k (test hook): every k-th device allocation of the process is treated as "out of memory" at its first attempt,
+// so that the give-back-and-retry path runs in every phase without a 288 GB input.
+inline bool test_oom_now() {
+  static const char *e = getenv("BCE_HIP_TEST_OOM");
+  static const unsigned long k = e ? strtoul(e, nullptr, 10) : 0;
+  static std::atomic<unsigned long> count{0};
+  return k && (count.fetch_add(1) + 1) % k == 0;
+}
 inline int ensure(bce_hip_ctx *c, DevBuf &b, size_t bytes) {
   if (bytes <= b.cap) return BCE_HIP_OK;
   if (b.p) {
@@ -267,7 +283,16 @@ inline int ensure(bce_hip_ctx *c, DevBuf &b, size_t bytes) {
     b.p = nullptr; b.cap = 0;
   }
   const double t0 = now_s();
-  BCE_HIP_TRY(c, hipMalloc(&b.p, bytes));
+  hipError_t e = hipMalloc(&b.p, bytes);
+  const bool pretend = e == hipSuccess && test_oom_now();
+  if (pretend) { (void)hipFree(b.p); e = hipErrorOutOfMemory; }
+  if (e == hipErrorOutOfMemory) {
+    // the buffers of the stages that are not running go back, then once more
+    (void)hipGetLastError();
+    b.p = nullptr;
+    if (ctx_trim(c) || pretend) e = hipMalloc(&b.p, bytes);
+  }
+  if (e != hipSuccess) { b.p = nullptr; BCE_HIP_TRY(c, e); }
   c->alloc_s += now_s() - t0; c->alloc_bytes += bytes; c->alloc_calls++;
   if (now_s() - t0 > 0.02 && getenv("BCE_ALLOC_TRACE")) fprintf(stderr, "alloc: hipMalloc of %.1f MB took %.3f s\n", bytes / 1e6, now_s() - t0);
   b.cap = bytes;
@@ -340,6 +365,8 @@ int k2_rank1(bce_hip_ctx *c, int plane, const uint32_t *idx, uint32_t count, uin
 int k3_begin(bce_hip_ctx *c);                       // k3_enumerate.hip
 int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint);
 int k3_rounds_small(bce_hip_ctx *c, uint32_t count, uint64_t cur_nodes, bool growing);   // one launch per round, narrow rounds
+int k3_round_masked(bce_hip_ctx *c, uint32_t mask, bool repeat);   // one round, three launches, symbols of the planes in `mask` only
+int k3_clear_need_flush(bce_hip_ctx *c);
 int k3_clear_small_bail(bce_hip_ctx *c);   // queue `count` rounds from c->round (no sync)
 int k3_dfs_tail(bce_hip_ctx *c, const EnumCtl &ctl, uint32_t enter, bool *done);   // k3_dfs.hip: finish the enumeration depth-first
 int k3_tail(bce_hip_ctx *c, uint32_t max_rounds = K3_TAIL_MAXROUNDS);   // queue the persistent narrow-round kernel from c->round (no sync)

@@ -67,22 +67,34 @@ struct TileOut {
   uint32_t raw[K3_NPT][3];   // scan mode: kw = sym, ew = k, raw = c1, c2, cs
 };
 
-// node q of a plane's list (child0 part grows up from 0, child1 part down from capP-1): 32-bit byte offset from the
-// plane's (uniform) base -- capP * 12 < 2^32
+// node q of a plane's list (child0 part grows up from 0, child1 part down from cap-1): 32-bit byte offset from the
+// plane's (uniform) base while a list is below 4 GB (cap * 12 < 2^32: every input up to ~7 * 10^8 bytes, and larger ones
+// until a round needs more); a 64-bit index beyond that (lists of up to n/2 + 2 = 2^30 + 1 nodes, 12.9 GB)
 __device__ __forceinline__ Node node_at(const Node *src, uint32_t idx) {
   return *reinterpret_cast<const Node *>(reinterpret_cast<const char *>(src) + ((idx << 3) + (idx << 2)));
 }
+constexpr uint32_t K3_CAP32 = 0xFFFFFFFFu / (uint32_t)sizeof(Node) - 16u;     // lists up to here use the 32-bit offsets
 
 __device__ __forceinline__ void k3_load_nodes(const K3Args &a, uint32_t p, uint32_t tile_in_plane, uint32_t c0n, uint32_t c1n,
                                               Node (&nd)[K3_NPT]) {
   const uint32_t M = c0n + c1n;
   const Node *src = plane_nodes(a, a.par, p);
+  const uint32_t cap = list_cap(a, a.par);
+  if (cap <= a.cap32) {                                         // (uniform)
 #pragma unroll
-  for (int it = 0; it < K3_NPT; ++it) {
-    const uint32_t q = tile_in_plane * K3_TILE + (uint32_t)it * K3_T + threadIdx.x;
-    // out-of-range lanes re-read the tile's first node (always valid when the tile exists); their results are masked
-    const uint32_t qq = q < M ? q : tile_in_plane * K3_TILE;
-    nd[it] = node_at(src, qq < c0n ? qq : (a.capP - 1u - (qq - c0n)));
+    for (int it = 0; it < K3_NPT; ++it) {
+      const uint32_t q = tile_in_plane * K3_TILE + (uint32_t)it * K3_T + threadIdx.x;
+      // out-of-range lanes re-read the tile's first node (always valid when the tile exists); their results are masked
+      const uint32_t qq = q < M ? q : tile_in_plane * K3_TILE;
+      nd[it] = node_at(src, qq < c0n ? qq : (cap - 1u - (qq - c0n)));
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < K3_NPT; ++it) {
+      const uint32_t q = tile_in_plane * K3_TILE + (uint32_t)it * K3_T + threadIdx.x;
+      const uint32_t qq = q < M ? q : tile_in_plane * K3_TILE;
+      nd[it] = src[qq < c0n ? qq : (cap - 1u - (qq - c0n))];
+    }
   }
 }
 
@@ -153,6 +165,7 @@ __device__ __forceinline__ void k3_place(const K3Args &a, uint32_t p, const Tile
   const uint32_t w = threadIdx.x >> 6;
   const uint32_t pn = (p + 1u) & 7u;
   Node *dst = plane_nodes(a, a.par ^ 1u, pn);
+  const uint32_t capo = list_cap(a, a.par ^ 1u);
   uint32_t run0 = 0, run1 = 0, runs_ = 0;   // counts of earlier (it, wave) groups
 #pragma unroll
   for (int it = 0; it < K3_NPT; ++it) {
@@ -164,7 +177,7 @@ __device__ __forceinline__ void k3_place(const K3Args &a, uint32_t p, const Tile
       run0 += x0; run1 += x1; runs_ += xs;
     }
     if (t.has0[it]) dst[o0 + b0 + pre0[it]] = t.c0[it];
-    if (t.has1[it]) dst[a.capP - 1u - (o1 + b1 + pre1[it])] = t.c1[it];
+    if (t.has1[it]) dst[capo - 1u - (o1 + b1 + pre1[it])] = t.c1[it];
     if (t.hassym[it]) {
       if (SCAN) {
         a.scanrec[os + bs + pres[it]] = scan_pack(t.kw[it], t.ew[it], t.raw[it][0], t.raw[it][1], t.raw[it][2]);
@@ -296,15 +309,17 @@ __global__ __launch_bounds__(1024) void k3_scan_kernel(K3Args a) {
   if (tid != 0) return;
   ctl->ticket = 0;
   uint64_t symsum = 0, nextn = 0, curn = 0;
+  uint32_t want_list = 0;
   bool ovf = false;
   const uint32_t (*pt)[3] = s_pt;
   for (int q = 0; q < 8; ++q) {
     symsum += pt[q][2];
     nextn += (uint64_t)pt[q][0] + pt[q][1];
     curn += (uint64_t)s_cnt[q][0] + s_cnt[q][1];
-    if ((uint64_t)pt[q][0] + pt[q][1] > a.capP) ovf = true;
+    if ((uint64_t)pt[q][0] + pt[q][1] > list_cap(a, a.par ^ 1u)) ovf = true;
+    if ((uint64_t)pt[q][0] + pt[q][1] > want_list) want_list = (uint32_t)(pt[q][0] + pt[q][1]);
   }
-  if (ovf) { ctl->overflow = 1; ctl->skip_round = a.round; return; }       // (the host grows the lists and runs the round again: k3_grow_lists)
+  if (ovf) { ctl->overflow = 1; ctl->skip_round = a.round; ctl->want_list = want_list; return; }       // (the host grows the lists and runs the round again: k3_grow_lists)
   if (s_sym[0] + symsum > s_sym[1]) { ctl->need_flush = 1; ctl->skip_round = a.round; ctl->want_syms = symsum; return; }
   uint64_t acc = s_sym[0];
   for (uint32_t q = 0; q < 8; ++q) {
@@ -317,8 +332,8 @@ __global__ __launch_bounds__(1024) void k3_scan_kernel(K3Args a) {
     acc += pt[q][2];
   }
   ctl->sym_total = acc;
-  atomicAdd((unsigned long long *)&ctl->nodes_total, (unsigned long long)curn);
-  ctl->next_nodes = (uint32_t)nextn;
+  if (!a.repeat) atomicAdd((unsigned long long *)&ctl->nodes_total, (unsigned long long)curn);
+  ctl->next_nodes = nextn;
   if (nextn == 0 && s_done == 0xFFFFFFFFu) ctl->done_round = a.round + 1u;
 }
 
@@ -496,16 +511,21 @@ __global__ __launch_bounds__(K3_T) void k3_count2_kernel(K3Args a) {
         __syncthreads();
         if (tid == 0) {
           uint64_t symsum = 0, nextn = 0, curn = 0;
+          uint32_t want_list = 0;
           bool ovf = false;
           for (int q = 0; q < 8; ++q) {
             symsum += s_pt[q][2];
             nextn += (uint64_t)s_pt[q][0] + s_pt[q][1];
             curn += (uint64_t)cn[q][0] + cn[q][1];
-            if ((uint64_t)s_pt[q][0] + s_pt[q][1] > a.capP) ovf = true;
+            if ((uint64_t)s_pt[q][0] + s_pt[q][1] > list_cap(a, a.par ^ 1u)) ovf = true;
+            if (s_pt[q][0] + s_pt[q][1] > want_list) want_list = s_pt[q][0] + s_pt[q][1];
           }
           const uint64_t sym0 = ctl->sym_total;
-          if (ovf) { ctl->overflow = 1; ctl->skip_round = a.round; }
-          else if (sym0 + symsum > ctl->sym_cap) { ctl->need_flush = 1; ctl->skip_round = a.round; ctl->want_syms = symsum; }
+          if (ovf) { ctl->overflow = 1; ctl->skip_round = a.round; ctl->want_list = want_list; }
+          else if (sym0 + symsum > ctl->sym_cap) {
+            for (int q = 0; q < 8; ++q) ctl->ptot[q][2] = s_pt[q][2];     // (per plane: a round that is too large for one flush goes plane group by plane group)
+            ctl->need_flush = 1; ctl->skip_round = a.round; ctl->want_syms = symsum;
+          }
           else {
             uint64_t acc = sym0;
             for (uint32_t q = 0; q < 8; ++q) {
@@ -519,7 +539,7 @@ __global__ __launch_bounds__(K3_T) void k3_count2_kernel(K3Args a) {
             }
             ctl->sym_total = acc;
             atomicAdd((unsigned long long *)&ctl->nodes_total, (unsigned long long)curn);
-            ctl->next_nodes = (uint32_t)nextn;
+            ctl->next_nodes = nextn;
             if (nextn == 0 && ctl->done_round == 0xFFFFFFFFu) ctl->done_round = a.round + 1u;
           }
         }
@@ -561,7 +581,7 @@ __global__ __launch_bounds__(K3_T) void k3_small_kernel(K3Args a, unsigned long 
   for (int q = 0; q < 8; ++q) {
     const uint64_t m = (uint64_t)ctl->cnt[a.par][q][0] + ctl->cnt[a.par][q][1];
     M += m;
-    if (2 * m > a.capP) fits = false;                        // children could overflow a list: let the wide path decide
+    if (2 * m > list_cap(a, a.par ^ 1u)) fits = false;       // children could overflow a list: let the wide path decide
   }
   if (M >= (1u << 21)) fits = false;
   const uint64_t sym0 = ctl->sym_total;
@@ -670,7 +690,7 @@ __global__ __launch_bounds__(K3_T) void k3_small_kernel(K3Args a, unsigned long 
   }
   ctl->sym_total = acc;
   atomicAdd((unsigned long long *)&ctl->nodes_total, (unsigned long long)M);
-  ctl->next_nodes = (uint32_t)nextn;
+  ctl->next_nodes = nextn;
   if (nextn == 0 && ctl->done_round == 0xFFFFFFFFu) ctl->done_round = a.round + 1u;
 }
 
@@ -730,7 +750,7 @@ __global__ __launch_bounds__(KT_T) void k3_tail_kernel(K3Args a, RunEntry *truns
 #pragma unroll
     for (int k = 1; k < 8; ++k) p += (q >= off[k]) ? 1u : 0u;
     const uint32_t i = q - off[p], c0 = cnt[par][p][0];
-    buf[0][q] = plane_nodes(a, par, p)[i < c0 ? i : (a.capP - 1u - (i - c0))];
+    buf[0][q] = plane_nodes(a, par, p)[i < c0 ? i : (list_cap(a, par) - 1u - (i - c0))];
   }
   uint64_t sym_total = ctl->sym_total, nodes_total = ctl->nodes_total;
   const uint64_t sym_cap = ctl->sym_cap;
@@ -864,7 +884,7 @@ __global__ __launch_bounds__(KT_T) void k3_tail_kernel(K3Args a, RunEntry *truns
 #pragma unroll
     for (int k = 1; k < 8; ++k) p += (q >= off[k]) ? 1u : 0u;
     const uint32_t i = q - off[p], c0 = cnt[par][p][0];
-    plane_nodes(a, par, p)[i < c0 ? i : (a.capP - 1u - (i - c0))] = buf[cur][q];
+    plane_nodes(a, par, p)[i < c0 ? i : (list_cap(a, par) - 1u - (i - c0))] = buf[cur][q];
   }
   if (tid < 16) ctl->cnt[par][tid >> 1][tid & 1] = cnt[par][tid >> 1][tid & 1];
   if (tid == 0) {
@@ -880,7 +900,7 @@ __global__ __launch_bounds__(KT_T) void k3_tail_kernel(K3Args a, RunEntry *truns
 K3Args k3_make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot) {
   K3Args a;
   a.ctl = c->ctl.as<EnumCtl>();
-  a.nodes = c->nodes.as<Node>();
+  a.nodes[0] = c->nlist[0].as<Node>(); a.nodes[1] = c->nlist[1].as<Node>();
   a.gran = c->gran.as<Granule>();
   a.cfg = c->dcfg.as<PlaneCfg>();
   a.symkey = c->skey[0].as<uint32_t>();
@@ -899,55 +919,45 @@ K3Args k3_make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot) {
     a.goff = reinterpret_cast<uint32_t *>(base + ng * 16);
   }
   a.fused = 0;
-  a.capP = c->capP; a.ngran = c->ngran; a.n = c->n;
+  a.cap[0] = c->capL[0]; a.cap[1] = c->capL[1]; a.ngran = c->ngran; a.n = c->n;
   for (int i = 0; i < 8; ++i) a.zeros[i] = c->zeros[i];
   a.par = round & 1u; a.round = round; a.run_slot = run_slot;
+  a.repeat = 0;
+  {
+    static const char *e = getenv("BCE_HIP_CAP32");             // (test knob: the 64-bit list indexing from this many nodes per list on)
+    static const uint32_t v = e ? (uint32_t)strtoul(e, nullptr, 10) : K3_CAP32;
+    a.cap32 = v < K3_CAP32 ? v : K3_CAP32;
+  }
   a.pmask = (c->scan_mode || !c->coder) ? 0xFFu : (c->coder->plane_mask & 0xFFu);
   return a;
 }
 
-// The largest lists this context may have for an input of n bytes.
-static uint32_t full_capP(bce_hip_ctx *c, uint32_t n) {
-  // worst case is n/2 nodes per plane-round (disjoint intervals of width >= 2): text peaks at 0.06-0.09 n, random
-  // bytes at ~0.3 n.  All 16 lists (2 parities x 8 planes) can have the worst case when it fits in 60 % of the HBM that is
-  // free now (K1's and K2's buffers are already allocated), at least 192 M nodes per list (36.9 GB) otherwise.  A round
-  // that overflows even those ends the compression with BCE_HIP_E_OVERFLOW (loud, never a wrong archive): see the
-  // capacity note in include/bce_hip.h.
-  const uint64_t worst = (uint64_t)n / 2 + 2;
-  uint64_t soft = (uint64_t)192 << 20;
-  if (worst > soft) {
-    size_t free_b = 0, total_b = 0;
-    const size_t have = c->nodes.cap;                             // (a buffer of an earlier compression is reused)
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      const uint64_t budget = (uint64_t)((free_b + have) * 0.6);
-      const uint64_t fit = budget / (16 * sizeof(Node));
-      if (fit > soft) soft = fit;
-      const uint64_t addressable = 0xFFFFFFFFull / sizeof(Node) - 16;       // node_at: 32-bit byte offsets inside one list
-      if (soft > addressable) soft = addressable;
-    }
-  }
-  return (uint32_t)(worst < soft ? worst : soft);
-}
+// The largest list an input of n bytes can need: n/2 nodes per plane-round (disjoint intervals of width >= 2; text peaks at
+// 0.06-0.09 n, random bytes at ~0.3 n).  Two consecutive rounds of a plane hold at most 3n/4 nodes together (n/4 nodes of width
+// 4 with n/2 children of width 2), i.e. 72 n bytes in all sixteen lists: 155 GB at n = 2^31 - 1, beside the 13 n bytes of text,
+// BWT, planes, suffix array and inverse that stay -- K1's sort scratch goes back first when that is what it takes (ctx_trim).
+static uint32_t full_capP(uint32_t n) { return (uint32_t)((uint64_t)n / 2 + 2); }
 
 // What a compression STARTS with: n / 8 nodes per list (at n / 2 + 2, the worst case, the lists were 55 % of a context's 17.6 GB at
 // 10^8 bytes, twenty times what text ever fills; memory the driver has to clear before it hands it out -- 27 ms per GB whenever an earlier process has used
 // it), or whatever a buffer the context has already holds.  A round that does not fit is not run (the epilogue checks before
-// anything is written); the host doubles the lists, moves the current round's lists over and runs it again (k3_grow_lists).
-// BCE_HIP_CAPP_DIV=d / test knob 12: start with n / d + 4096 nodes per list.
-static uint32_t initial_capP(bce_hip_ctx *c, uint32_t n, uint32_t full) {
+// anything is written); the host replaces the lists the round would WRITE -- the other parity's, which hold nothing -- by larger
+// ones and runs it again (k3_grow_lists).  BCE_HIP_CAPP_DIV=d / test knob 12: start with n / d + 4096 nodes per list.
+static uint32_t initial_capP(bce_hip_ctx *c, uint32_t n, uint32_t full, int par) {
   uint64_t div = 8;
   bool forced = false;                                         // (a test asks for small lists: also in a context that holds larger ones)
   if (c->dbg_capp_div) { div = c->dbg_capp_div; forced = true; }
   if (const char *e = getenv("BCE_HIP_CAPP_DIV")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1) { div = v; forced = true; } }
   uint64_t cap = (uint64_t)n / div + 4096;
-  const uint64_t held = c->nodes.cap / (16 * sizeof(Node));
+  const uint64_t held = c->nlist[par].cap / (8 * sizeof(Node));
   if (held > cap && !forced) cap = held;
   return (uint32_t)(cap < full ? cap : full);
 }
 
-// everything that is sized by the lists' capacity, for the capacity c->capP
+// everything that is sized by the lists' capacity (the larger of the two parities')
 static int k3_size_tile_arrays(bce_hip_ctx *c) {
-  const size_t tiles = (size_t)8 * ((c->capP + K3_TILE - 1) / K3_TILE) + 8;
+  const uint32_t capm = c->capL[0] > c->capL[1] ? c->capL[0] : c->capL[1];
+  const size_t tiles = (size_t)8 * ((capm + K3_TILE - 1) / K3_TILE) + 8;
   BCE_TRY(ensure(c, c->tilecnt, tiles * 16));
   BCE_TRY(ensure(c, c->tileoff, tiles * 16));
   // two-launch rounds: a count word per tile; per group of 256 tiles: two words and four offsets (32 B)
@@ -959,32 +969,40 @@ static int k3_size_tile_arrays(bce_hip_ctx *c) {
   return BCE_HIP_OK;
 }
 
-// A round found its children would not fit the lists (ctl.overflow, ctl.skip_round = c->round: nothing of it was written).
-// Twice the room (at most full_capP), the lists of the round's parity moved over -- child0 lists from the front, child1 lists
-// from the back --, the flag cleared: the caller queues the round again.  BCE_HIP_E_OVERFLOW when the lists are at their largest.
+// A round found its children would not fit the lists (ctl.overflow, ctl.skip_round = c->round, ctl.want_list = the longest list
+// it would write: nothing of it was written).  The lists it writes are the OTHER parity's, and those hold nothing now -- their
+// nodes were this round's parents one round ago --, so they are given back and allocated anew, no copy and never old and new
+// side by side: twice what the round needs (the next rounds of a growing enumeration need more), at most the worst case, and
+// exactly what it needs (+ 1/16) when the device cannot give more.  BCE_HIP_E_NOMEM only when even that does not fit.
 int k3_grow_lists(bce_hip_ctx *c, const EnumCtl &ctl) {
-  const uint32_t full = full_capP(c, c->n);
-  if (c->capP >= full) { snprintf(c->err, sizeof c->err, "node buffer overflow (capP=%u)", c->capP); return BCE_HIP_E_OVERFLOW; }
-  const uint64_t want = (uint64_t)c->capP * 2;
-  const uint32_t ncap = (uint32_t)(want < full ? want : full);
-  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  DevBuf fresh;
-  BCE_TRY(ensure(c, fresh, (size_t)16 * ncap * sizeof(Node)));
-  const uint32_t par = c->round & 1u;
-  for (uint32_t p = 0; p < 8; ++p) {
-    const uint32_t c0 = ctl.cnt[par][p][0], c1 = ctl.cnt[par][p][1];
-    const Node *src = c->nodes.as<Node>() + (size_t)(par * 8u + p) * c->capP;
-    Node *dst = fresh.as<Node>() + (size_t)(par * 8u + p) * ncap;
-    if (c0) BCE_HIP_TRY(c, hipMemcpyAsync(dst, src, (size_t)c0 * sizeof(Node), hipMemcpyDeviceToDevice, c->stream));
-    if (c1) BCE_HIP_TRY(c, hipMemcpyAsync(dst + (ncap - c1), src + (c->capP - c1), (size_t)c1 * sizeof(Node), hipMemcpyDeviceToDevice, c->stream));
+  const uint32_t full = full_capP(c->n);
+  const int out = (int)((c->round & 1u) ^ 1u);
+  const uint64_t need = ctl.want_list;
+  if (need <= c->capL[out] || need > full) {
+    snprintf(c->err, sizeof c->err, "k3: round %u reports a list of %llu nodes (lists hold %u, an input of %u bytes needs at most %u)", c->round,
+             (unsigned long long)need, c->capL[out], c->n, full);
+    return BCE_HIP_E_INTERNAL;
   }
   BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  release(c->nodes);
-  c->nodes = fresh;
-  c->capP = ncap;
+  for (hipStream_t st : {c->k4_stream, c->copy_stream}) if (st) BCE_HIP_TRY(c, hipStreamSynchronize(st));
+  release(c->nlist[out]);
+  c->capL[out] = 0;
+  uint64_t want = need * 2 + 4096;
+  if (want > full) want = full;
+  int rc = ensure(c, c->nlist[out], (size_t)8 * want * sizeof(Node));
+  if (rc == BCE_HIP_E_NOMEM) {
+    want = need + need / 16 + 4096;
+    if (want > full) want = full;
+    rc = ensure(c, c->nlist[out], (size_t)8 * want * sizeof(Node));
+  }
+  if (rc != BCE_HIP_OK) {
+    if (rc == BCE_HIP_E_NOMEM) snprintf(c->err, sizeof c->err, "k3: no device memory for node lists of %llu nodes (round %u, n = %u)", (unsigned long long)want, c->round, c->n);
+    return rc;
+  }
+  c->capL[out] = (uint32_t)want;
   c->stats.list_grows += 1.0;
-  c->stats.list_nodes = ncap;
-  if (getenv("BCE_ALLOC_TRACE")) fprintf(stderr, "k3: round %u does not fit the node lists: %u -> %u nodes per list (n = %u)\n", c->round, (uint32_t)(want / 2), ncap, c->n);
+  c->stats.list_nodes = c->capL[0] > c->capL[1] ? c->capL[0] : c->capL[1];
+  if (getenv("BCE_ALLOC_TRACE")) fprintf(stderr, "k3: round %u needs lists of %llu nodes: parity %d now holds %u per list, parity %d %u (n = %u)\n", c->round, (unsigned long long)need, out, c->capL[out], out ^ 1, c->capL[out ^ 1], c->n);
   BCE_TRY(k3_size_tile_arrays(c));
   BCE_HIP_TRY(c, hipMemsetAsync(&c->ctl.as<EnumCtl>()->overflow, 0, sizeof(uint32_t), c->stream));
   return BCE_HIP_OK;
@@ -1004,9 +1022,12 @@ uint64_t k3_symbol_capacity(const bce_hip_ctx *c, uint32_t n) {
 
 int k3_begin(bce_hip_ctx *c) {
   const uint32_t n = c->n;
-  c->capP = initial_capP(c, n, full_capP(c, n));
-  c->stats.list_grows = 0; c->stats.list_nodes = c->capP;
-  BCE_TRY(ensure(c, c->nodes, (size_t)16 * c->capP * sizeof(Node)));
+  for (int par = 0; par < 2; ++par) {
+    // (a buffer the decoder left in nlist[0] holds both of ITS parities: as one parity's lists here it is simply larger)
+    c->capL[par] = initial_capP(c, n, full_capP(n), par);
+    BCE_TRY(ensure(c, c->nlist[par], (size_t)8 * c->capL[par] * sizeof(Node)));
+  }
+  c->stats.list_grows = 0; c->stats.list_nodes = c->capL[0] > c->capL[1] ? c->capL[0] : c->capL[1];
   BCE_TRY(k3_size_tile_arrays(c));
   BCE_TRY(ensure(c, c->ctl, sizeof(EnumCtl)));
   BCE_TRY(ensure(c, c->runs, (size_t)K3_MAXBATCH * 8 * sizeof(RunEntry)));
@@ -1031,7 +1052,7 @@ int k3_begin(bce_hip_ctx *c) {
     const uint32_t C = c->zeros[(i + 7) & 7];
     if (C && n - C) {
       Node root = {0u, C, n - C};
-      BCE_HIP_TRY(c, hipMemcpyAsync(c->nodes.as<Node>() + (size_t)i * c->capP, &root, sizeof root,
+      BCE_HIP_TRY(c, hipMemcpyAsync(c->nlist[0].as<Node>() + (size_t)i * c->capL[0], &root, sizeof root,
                                     hipMemcpyHostToDevice, c->stream));
       BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));   // `root` is a stack temporary
       ctl.cnt[0][i][0] = 1;
@@ -1084,6 +1105,28 @@ int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint) {
   }
   BCE_HIP_TRY(c, hipGetLastError());
   c->stats.k3_launches += (fused ? 2.0 : 3.0) * count;
+  return BCE_HIP_OK;
+}
+
+// ONE round (c->round) in three launches, recording the symbols of the planes in `mask` only; `repeat`: a further pass of a round
+// that has been counted already.  For rounds whose symbols do not fit one model flush (api.hip, split_round): every pass
+// classifies all nodes and writes all children (identical each time), the symbol records and the run table are the pass's own.
+int k3_round_masked(bce_hip_ctx *c, uint32_t mask, bool repeat) {
+  K3Args a = k3_make_args(c, c->round, 0);
+  a.fused = 0;
+  a.pmask &= mask;
+  a.repeat = repeat ? 1u : 0u;
+  const uint32_t grid = 2048;
+  hipLaunchKernelGGL((k3_tiles_kernel<false, false>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+  hipLaunchKernelGGL(k3_scan_kernel, dim3(8), dim3(1024), 0, c->stream, a);
+  if (c->scan_mode) hipLaunchKernelGGL((k3_tiles_kernel<true, true>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+  else hipLaunchKernelGGL((k3_tiles_kernel<true, false>), dim3(grid), dim3(K3_T), 0, c->stream, a);
+  BCE_HIP_TRY(c, hipGetLastError());
+  c->stats.k3_launches += 3.0;
+  return BCE_HIP_OK;
+}
+int k3_clear_need_flush(bce_hip_ctx *c) {
+  BCE_HIP_TRY(c, hipMemsetAsync(&c->ctl.as<EnumCtl>()->need_flush, 0, sizeof(uint32_t), c->stream));
   return BCE_HIP_OK;
 }
 
@@ -1192,12 +1235,13 @@ int k3_get_nodes(bce_hip_ctx *c, int plane, uint32_t *out, uint32_t cap, uint32_
   const uint32_t c0 = ctl.cnt[par][plane][0], c1 = ctl.cnt[par][plane][1];
   *count = c0 + c1;
   if (c0 + c1 > cap) return BCE_HIP_E_OVERFLOW;
-  const Node *src = c->nodes.as<Node>() + (size_t)(par * 8u + (uint32_t)plane) * c->capP;
+  const uint32_t capl = c->capL[par];
+  const Node *src = c->nlist[par].as<Node>() + (size_t)plane * capl;
   if (c0) BCE_HIP_TRY(c, hipMemcpy(out, src, (size_t)c0 * sizeof(Node), hipMemcpyDeviceToHost));
   if (c1) {
     std::vector<Node> tmp(c1);
-    BCE_HIP_TRY(c, hipMemcpy(tmp.data(), src + (c->capP - c1), (size_t)c1 * sizeof(Node), hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < c1; ++i) {   // stored downwards from capP-1
+    BCE_HIP_TRY(c, hipMemcpy(tmp.data(), src + (capl - c1), (size_t)c1 * sizeof(Node), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < c1; ++i) {   // stored downwards from cap-1
       const Node &nd = tmp[c1 - 1 - i];
       out[3 * (size_t)(c0 + i) + 0] = nd.s; out[3 * (size_t)(c0 + i) + 1] = nd.x0; out[3 * (size_t)(c0 + i) + 2] = nd.x1;
     }

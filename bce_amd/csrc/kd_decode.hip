@@ -1664,15 +1664,12 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
   return BCE_HIP_OK;
 }
 
-// The node lists of a decode: at most n / 2 + 2 nodes each (the worst case; 192 M beyond 4 * 10^8 bytes), and to begin with an
+// The node lists of a decode: at most n / 2 + 2 nodes each (the worst case: disjoint intervals of width >= 2), and to begin with an
 // eighth of n (what k3_begin starts the encoder with: text fills 0.02-0.03 n, random bytes 0.15-0.3 n) or what the context's
 // buffer already holds.  A round whose children would not fit stops the decode before it writes them (the scan of the
 // children pass checks; the one-launch kernel, which checks afterwards, is only used where twice the round's nodes fit) and
 // the decode starts again with twice the room (decompress_device_body).  Test knob 12 / BCE_HIP_CAPP_DIV as for the encoder.
-uint32_t dec_full_capP(uint32_t n) {
-  const uint64_t worst = (uint64_t)n / 2 + 2, soft = (uint64_t)192 << 20;
-  return (uint32_t)(worst < soft ? worst : soft);
-}
+uint32_t dec_full_capP(uint32_t n) { return (uint32_t)((uint64_t)n / 2 + 2); }
 uint32_t dec_capP(const bce_hip_ctx *c, uint32_t n) {
   const uint64_t full = dec_full_capP(n);
   uint64_t div = 8;
@@ -1683,7 +1680,7 @@ uint32_t dec_capP(const bce_hip_ctx *c, uint32_t n) {
   // (the one-launch rounds need twice a round's nodes to fit: 4 M nodes per list at least, i.e. the worst case up to 8 MB of
   //  input -- with n / 8 a 1 MB input left them for its widest rounds and decoded in 32 ms instead of 16)
   if (!forced && cap < ((uint64_t)4 << 20)) cap = (uint64_t)4 << 20;
-  const uint64_t held = c->nodes.cap / (16 * sizeof(Node));
+  const uint64_t held = c->nlist[0].cap / (16 * sizeof(Node));
   if (held > cap && !forced) cap = held;
   if (c->dec_cap_next > cap) cap = c->dec_cap_next;             // (a decode that ran out of room: this much the next time)
   return (uint32_t)(cap < full ? cap : full);
@@ -1731,6 +1728,8 @@ static int decompress_device_once(bce_hip_ctx *c, const uint8_t *archive, size_t
   BCE_HIP_TRY(c, hipSetDevice(c->device));
   c->coder->drain();
   c->stage = 0; c->enum_active = false; c->k1_valid = false;   // the scratch buffers below belong to the decoder now
+  c->phase = 4;
+  struct PhaseEnd { bce_hip_ctx *c; ~PhaseEnd() { c->phase = 0; } } phase_end{c};
   const uint32_t n = hd.n;
   const bool timing = getenv("BCE_DEC_TIMING") != nullptr;
   double tp0 = now_s();
@@ -1738,7 +1737,7 @@ static int decompress_device_once(bce_hip_ctx *c, const uint8_t *archive, size_t
   // ---- buffers ----
   const size_t rstride = (size_t)n + 1;
   c->capP = dec_capP(c, n);
-  BCE_TRY(ensure(c, c->nodes, (size_t)16 * c->capP * sizeof(Node)));
+  BCE_TRY(ensure(c, c->nlist[0], (size_t)16 * c->capP * sizeof(Node)));
   BCE_TRY(ensure(c, c->ctl, sizeof(DecCtl) > sizeof(EnumCtl) ? sizeof(DecCtl) : sizeof(EnumCtl)));
   const size_t max_tiles = (size_t)8 * ((c->capP + K3_TILE - 1) / K3_TILE + 1);
   BCE_TRY(ensure(c, c->tilecnt, max_tiles * 16));
@@ -1756,7 +1755,7 @@ static int decompress_device_once(bce_hip_ctx *c, const uint8_t *archive, size_t
     BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));            // stack temporaries
     if (hd.C[i] && n - hd.C[i]) {                               // :1214-1216
       const Node root = {0u, hd.C[i], n - hd.C[i]};
-      BCE_HIP_TRY(c, hipMemcpyAsync(c->nodes.as<Node>() + (size_t)i * c->capP, &root, sizeof root, hipMemcpyHostToDevice, c->stream));
+      BCE_HIP_TRY(c, hipMemcpyAsync(c->nlist[0].as<Node>() + (size_t)i * c->capP, &root, sizeof root, hipMemcpyHostToDevice, c->stream));
       BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
       ctl.cnt[0][i][0] = 1;
     }
@@ -1782,7 +1781,7 @@ static int decompress_device_once(bce_hip_ctx *c, const uint8_t *archive, size_t
   DecArgs a;
   a.ctl = c->ctl.as<DecCtl>();
   a.info = info;                                                // pinned host memory is device-accessible at the same address
-  a.nodes = c->nodes.as<Node>();
+  a.nodes = c->nlist[0].as<Node>();
   a.R = R;
   a.tilecnt = c->tilecnt.as<uint32_t>();
   a.tileoff = c->tileoff.as<uint32_t>();

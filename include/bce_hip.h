@@ -82,12 +82,14 @@ int bce_hip_debug_set(bce_hip_ctx *ctx, int knob, uint32_t value);
 /* ---- stage 0: input ---------------------------------------------------------------------------- */
 /* File::File (bce.cpp:842-856): take the n input bytes.  _host copies host->HBM, _device copies
  * HBM->HBM from a device pointer of the same GPU (input already resident). 1 <= n < 2^31.
- * Capacity: device memory is ~45 n bytes for the suffix sort and planes plus the enumeration's node lists: 16 lists that start
- * with n/8 nodes each (text fills 0.02-0.03 n, random bytes 0.15-0.3 n) and are doubled when a round does not fit (the round is
- * not run before: bce_hip_stats.list_grows), up to n/2 + 2 nodes -- the worst case -- whenever 16 such lists fit in 60 % of the
- * free HBM and a list stays below 4 GB (357 M nodes) -- n <= ~7 * 10^8 on an otherwise idle 288 GB MI355X -- and up to 192 M to
- * 357 M nodes beyond that: a high-entropy input of more than ~1.3 GB can exceed even those, and bce_hip_encode then fails with
- * BCE_HIP_E_OVERFLOW after the BWT has been built (never with a wrong archive). */
+ * Capacity: device memory is ~45 n bytes for the suffix sort and planes plus the enumeration's node lists: 16 lists (8 planes x
+ * the two parities of a round) that start with n/8 nodes each (text fills 0.02-0.03 n, random bytes 0.15-0.3 n).  A round whose
+ * children do not fit is not run: the lists it would write -- the other parity's, empty at that moment -- are replaced by larger
+ * ones (bce_hip_stats.list_grows; no copy, never old and new side by side), up to the worst case of n/2 + 2 nodes, and when the
+ * device runs out of memory the buffers of the stages that are not running (the suffix sort's scratch) go back first.  Every
+ * valid input -- any 1 <= n < 2^31, as the reference (bce.cpp:173,374,901) -- fits an otherwise idle 288 GB MI355X: the worst
+ * case is 72 n bytes of lists beside 13 n bytes that stay.  A round that emits more symbols than one model flush takes (2^31
+ * records) is run plane group by plane group (bce_hip_stats.split_rounds). */
 int bce_hip_load_host(bce_hip_ctx *ctx, const uint8_t *in, uint32_t n);
 int bce_hip_load_device(bce_hip_ctx *ctx, const void *d_in, uint32_t n);
 
@@ -192,7 +194,8 @@ typedef struct bce_hip_stats {
   double k3_ms, k3_launches;   /* HIP-event time and launch count of the interval-count kernels */
   double t_coder_busy;         /* busiest host coder thread (t_coder is only the part not hidden behind GPU work) */
   double list_grows;           /* times a round did not fit the node lists and they were doubled (k3_grow_lists) */
-  double list_nodes;           /* nodes per list at the end */
+  double list_nodes;           /* nodes per list at the end (the larger of the two parities) */
+  double split_rounds;         /* rounds whose symbols did not fit one model flush and were run plane group by plane group */
   /* since the context was created (not reset by a load): */
   double reg_maps;             /* host mappings registered with the runtime (flush slots, the decoder's boundary ranks) */
   double reg_unmaps;           /* ... and given back (after waiting for the work that touches them) */

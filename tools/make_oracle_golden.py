@@ -43,6 +43,11 @@ JOBS = [
     # `bce -s` (oracle.scan) finds for it.  The 288-byte table itself is stored so that compress parity can be checked
     # apart from scan parity.
     ("mixed-2e8-scanned", "mixed", 200_000_000),
+    # The reference's full input range (any 1 <= n < 2^31: saidx_t at bce.cpp:901, getv's 31-bit path :374, Rank :173): the
+    # largest even-sized text input, and a high-entropy input whose node lists pass 357 M nodes (the former cap of a list)
+    # and whose widest rounds emit more than 2^31 symbols.  ~25 and ~40 minutes of oracle, ~28 / ~22 GB.
+    ("synth-text-2p31m2", "synth_text", (1 << 31) - 2),
+    ("synth-rand-1.5e9", "synth_rand", 1_500_000_000),
 ]
 # BASELINE configs[3] stand-in: ONE input (synth-text v1 seed 1, 10^9 B) cut into N contiguous blocks (sharding.block_range),
 # one archive per block as the reference would write it for that block alone (bce.cpp:1151-1157: one block per archive).
