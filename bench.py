@@ -44,8 +44,9 @@ from bce_amd import sharding  # noqa: E402
 
 REF_ENCODE_RATIO = 1.82  # reference encode-stage seconds / oracle encode-stage seconds (BASELINE.md, round 3 calibration)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-TRAFFIC_FILE = "r04_k3_traffic.json"          # tools/profile.sh + tools/pmc_summary.py (per-launch-unit HBM bytes of K3)
-TRAFFIC_FILE_1E9 = "r04_k3_traffic_1e9.json"
+TRAFFIC_FILE = "r05_k3_traffic.json"          # tools/profile.sh + tools/pmc_summary.py (per-launch-unit HBM bytes of K3)
+TRAFFIC_FILE_1E9 = "r05_k3_traffic_1e9.json"
+FAMILY_FILE = "r05_family_traffic.json"       # the same passes, summed per kernel family (K1, K2, K3, K4)
 K3_KERNELS = ("K3 interval-count (k3_count2_kernel + k3_tiles_kernel<write> for wide rounds, k3_small_kernel for narrow ones, "
               "k3_local_kernel / k3_dfs_kernel / k3_tail_kernel for the ends; all rounds of one compression = one launch unit)")
 
@@ -129,6 +130,36 @@ def roofline(n, sts):
             "frac": round(alg_bytes / k3_s / 1e9 / HBM_PEAK_GBS, 5) if k3_s > 0 else None,
             "traffic": None, "algorithmic_bytes": alg_bytes, "k3_ms_per_step": round(k3_s * 1e3, 3),
             "k3_launches_per_step": st["k3_launches"]}
+
+
+def roofline_families(n, sts, arch_sha):
+    """SURVEY 8d's other kernel families beside K3, per compression: algorithmic bytes (K1 6n, K2 17n, K4 22 x symbols) over the
+    family's time in the timed steps -- K1 / K2: host seconds around the stage, which ends with a sync (t_bwt, t_planes: launch
+    gaps and read-backs included); K4: HIP events around every flush's kernels + its device-to-host copy (t_model) -- and the
+    counter bytes of profiles/FAMILY_FILE (static: separate rocprofv3 --pmc passes on this workload) when that file is this
+    archive's."""
+    st = sts[-1]
+    avg = lambda k: sum(s[k] for s in sts) / len(sts)
+    spec = {"K1": (6.0 * n, avg("t_bwt"), "k1_* + radix-sort kernels: rotation sort + BWT (File::rotate / divbwt)"),
+            "K2": (17.0 * n, avg("t_planes"), "k2_*: 8 planes + rank granules (RankFile)"),
+            "K4": (22.0 * st["symbols"], avg("t_model"), "k4_* + slot sort + device-to-host copy of the model records (AdaptiveCoder::set, model half)")}
+    fam_traffic = {}
+    try:
+        fj = json.load(open(os.path.join(ROOT, "profiles", FAMILY_FILE)))
+        if fj.get("archive_sha256") == arch_sha and fj.get("bytes_per_gpu") == n:
+            fam_traffic = fj["families"]
+    except Exception:
+        pass
+    out = {}
+    for k, (alg, sec, what) in spec.items():
+        t = fam_traffic.get(k)
+        out[k] = {"bound": "hbm", "kernels": what, "algorithmic_bytes": alg, "ms_per_step": round(sec * 1e3, 3),
+                  "achieved": round(alg / sec / 1e9, 2) if sec > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(alg / sec / 1e9 / HBM_PEAK_GBS, 5) if sec > 0 else None,
+                  "traffic": t["traffic_bytes"] if t else None,
+                  "traffic_over_algorithmic": t["over_algorithmic"] if t else None,
+                  "traffic_source": ("profiles/%s (static)" % FAMILY_FILE) if t else None}
+    return out
 
 
 def timed_steps(ctx, t_in, n, steps, warmup, config=None):
@@ -563,6 +594,7 @@ def main():
             "oracle_golden_blocks": blocks_verdict, "oracle_golden_per_block": blocks_detail, "container_bytes": container_bytes,
             "ratio": round(total_arch / total_bytes, 5),
             "roofline": roof,
+            "roofline_families": roofline_families(n, sts, hashlib.sha256(arch).hexdigest()) if n_gpus == 1 else None,
             "breakdown_s": {k: round(st[k], 4) for k in ("t_load", "t_bwt", "t_planes", "t_enum", "t_model", "t_coder", "t_coder_busy")},
             "counts": {"nodes": st["nodes"], "symbols": st["symbols"], "rounds": st["rounds"], "sort_rounds": st["sort_rounds"], "flushes": st["flushes"]},
             "ms_per_step_per_rank": [round(t / steps * 1e3, 2) for t in per_rank],
@@ -582,13 +614,19 @@ def main():
             for _ in range(2):
                 a2 = bce_amd.compress(data, config=config, ctx=ctx)
             te = (time.perf_counter() - t0) / 2
+            out["value_host_buffer_to_archive"] = round(n / te / 1e6, 3)      # SURVEY 8d's metric as ONE number beside `value` (see metric_scope)
             out["value_end_to_end"] = {"value": round(n / te / 1e6, 3), "unit": "MB/s", "ms_per_step": round(te * 1e3, 2),
                                        "identical_to_headline": bool(bytes(a2) == bytes(arch)),
                                        "note": "host buffer -> archive bytes on the host: the H2D copy of the input is inside the timed region (PCIe); not `value`"}
         if cli is not None:
             if "error" not in cli:
                 cli["archive_identical_to_headline"] = bool(cli_arch == bytes(arch)) and cli.pop("all_runs_ok")
+                out["value_cli_cold"] = cli["value"]
             out["cli"] = cli
+        out["metric_scope"] = ("`value`: input resident in HBM when the clock starts, archive bytes on the host when it stops (this round's bench "
+                               "contract: a host-buffer rate is never `value`).  SURVEY 8d's metric -- file / host buffer -> archive bytes, the scope of "
+                               "the reference's own timer (bce.cpp:1404-1422) -- stands beside it as `value_host_buffer_to_archive` (warm context, H2D "
+                               "inside) and `value_cli_cold` (a fresh `bce -c` process: start-up, allocations, file read and write inside)")
         pool = None
         if n_gpus == 1 and not args.no_stream:
             try:

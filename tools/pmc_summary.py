@@ -28,6 +28,32 @@ def sums(outdir, sub, counter):
     return acc, calls
 
 
+def family_sums(outdir, sub, counter):
+    """Counter sums per kernel FAMILY of one compression: K1 (k1_* and the radix-sort kernels dispatched before K2), K2 (k2_*),
+    K3 (k3_*), K4 (k4_* and the radix-sort kernels dispatched after K2: the model's slot sort and the tail's tagged symbols)."""
+    rows = []
+    for f in glob.glob(os.path.join(outdir, sub, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] == counter:
+                    rows.append((int(row["Dispatch_Id"]), short(row["Kernel_Name"]), float(row["Counter_Value"])))
+    rows.sort()
+    k2_ids = [d for d, k, _ in rows if "k2_" in k]
+    k2_first = min(k2_ids) if k2_ids else None
+    acc, calls = defaultdict(float), defaultdict(int)
+    for d, k, v in rows:
+        fam = None
+        if "k1_" in k: fam = "K1"
+        elif "k2_" in k: fam = "K2"
+        elif "k3_" in k or "kd_jobs" in k: fam = "K3"
+        elif "k4_" in k: fam = "K4"
+        elif "rs_" in k or "radix" in k: fam = "K1" if (k2_first is not None and d < k2_first) else "K4"
+        if fam:
+            acc[fam] += v * 1024.0
+            calls[fam] += 1
+    return acc, calls
+
+
 def main():
     outdir, tag = sys.argv[1], sys.argv[2]
     sfx = sys.argv[3] if len(sys.argv) > 3 else ""          # e.g. "_1e9": passes in fetch_1e9/ write_1e9/, log fetch_1e9.log
@@ -79,6 +105,22 @@ def main():
     }
     with open(os.path.join(outdir, "%s_k3_traffic%s.json" % (tag, sfx)), "w") as f:
         json.dump(tj, f, indent=1)
+    # SURVEY 8d's other families, same passes: algorithmic bytes K1 6n, K2 17n, K4 22 x symbols
+    ff, fc = family_sums(outdir, "fetch" + sfx, "FETCH_SIZE")
+    fw, _ = family_sums(outdir, "write" + sfx, "WRITE_SIZE")
+    nb = line.get("config", {}).get("bytes_per_gpu") or 0
+    syms = line.get("counts", {}).get("symbols") or 0
+    alg = {"K1": 6.0 * nb, "K2": 17.0 * nb, "K3": 384.0 * nb + 16.0 * syms, "K4": 22.0 * syms}
+    fam = {"archive_sha256": line.get("archive_sha256"), "bytes_per_gpu": nb, "symbols": syms,
+           "note": "per compression; reads corrected x2 (FETCH_SIZE counts half of a wide coalesced stream on gfx950); radix-sort kernels "
+                   "belong to K1 before the first K2 kernel and to K4 (slot sort, tagged tail symbols) after it",
+           "families": {}}
+    for k in ("K1", "K2", "K3", "K4"):
+        fam["families"][k] = {"dispatches": fc.get(k, 0), "fetch_size_bytes_raw": ff.get(k, 0.0), "write_size_bytes": fw.get(k, 0.0),
+                              "traffic_bytes": 2.0 * ff.get(k, 0.0) + fw.get(k, 0.0), "algorithmic_bytes": alg[k],
+                              "over_algorithmic": round((2.0 * ff.get(k, 0.0) + fw.get(k, 0.0)) / alg[k], 3) if alg[k] else None}
+    with open(os.path.join(outdir, "%s_family_traffic%s.json" % (tag, sfx)), "w") as f:
+        json.dump(fam, f, indent=1)
     print(json.dumps({k: tj[k] for k in ("traffic_bytes_raw", "traffic_bytes_corrected", "algorithmic_bytes")}))
 
 
