@@ -314,67 +314,6 @@ int flush_symbols(bce_hip_ctx *c, uint64_t nsym) {
   return k3_reset_symbols(c);
 }
 
-
-// A flush of the two pipelines' records (enumerate_wide_dual): lane 0's lie in [0, nA), lane 1's in [baseB, baseB + nB) of the
-// record arrays.  The (round, plane) runs of both are listed in stream order -- round, then plane; a plane at a round belongs to
-// one lane -- for K4's gather (k4_flush_dual_async), and plane by plane for the coder threads, whose record indices count
-// lane 1's records behind lane 0's (K4 writes its outputs compactly).  Both lanes are idle and at the same round.
-int flush_symbols_dual(bce_hip_ctx *c, uint64_t nA, uint64_t nB) {
-  const uint64_t nsym = nA + nB;
-  K3Lane &A = c->lane[0], &B = c->lane[1];
-  if (nsym) {
-    if (nsym >= (1ull << 31)) { snprintf(c->err, sizeof c->err, "dual flush of %llu records", (unsigned long long)nsym); return BCE_HIP_E_INTERNAL; }
-    FlushSlot &slot = c->slot[c->slot_next];
-    c->slot_next = (c->slot_next + 1) % 3;
-    double t0 = now_s();
-    const bool handover = c->gate_held && slot.batch.pending.load() != 0;
-    if (handover) gate_release(c);
-    c->coder->wait(&slot.batch);
-    if (handover) { gate_acquire(c); BCE_HIP_TRY(c, hipSetDevice(c->device)); }
-    c->stats.t_coder += now_s() - t0;
-    account_slot(c, slot);
-    struct R { uint32_t round; uint32_t plane; uint32_t lane; uint32_t count; uint64_t start; };
-    std::vector<R> all;
-    all.reserve(A.runs_log.size() + B.runs_log.size());
-    for (int l = 0; l < 2; ++l) {
-      const K3Lane &L = c->lane[l];
-      for (size_t i = 0; i < L.runs_log.size(); ++i) all.push_back(R{L.runs_log[i].round, L.runs_plane[i], (uint32_t)l, L.runs_log[i].count, L.runs_log[i].start});
-    }
-    std::sort(all.begin(), all.end(), [](const R &x, const R &y) { return x.round != y.round ? x.round < y.round : x.plane < y.plane; });
-    std::vector<GatherRun> gr;
-    gr.reserve(all.size());
-    for (int p = 0; p < 8; ++p) slot.batch.runs[p].clear();
-    uint64_t dst = 0, seenA = 0, seenB = 0;
-    for (const R &r : all) {
-      const uint64_t src = r.lane ? B.sym_base + r.start : r.start;
-      gr.push_back(GatherRun{(uint32_t)src, (uint32_t)dst});
-      slot.batch.runs[r.plane].push_back(SymRun{r.lane ? nA + r.start : r.start, r.count, r.round});
-      dst += r.count;
-      (r.lane ? seenB : seenA) += r.count;
-    }
-    if (seenA != nA || seenB != nB) { snprintf(c->err, sizeof c->err, "dual flush: run tables hold %llu + %llu records, control blocks %llu + %llu", (unsigned long long)seenA, (unsigned long long)seenB, (unsigned long long)nA, (unsigned long long)nB); return BCE_HIP_E_INTERNAL; }
-    RoctxRange range("bce K4 model flush (two pipelines)");
-    BCE_TRY(k4_flush_dual_async(c, gr, (uint32_t)nsym, nA, B.sym_base, nB, slot));
-    // lane 1's next rounds write its region again: not before the flush's kernels have read it (lane 0's are queued behind them)
-    BCE_HIP_TRY(c, hipStreamWaitEvent(B.stream, c->ev_k4, 0));
-    if (c->sync_flush) BCE_HIP_TRY(c, hipEventSynchronize(slot.ev_copy));
-    slot.batch.out = slot.h_out;
-    slot.once = std::make_shared<std::once_flag>();
-    {
-      std::shared_ptr<std::once_flag> once = slot.once;
-      hipEvent_t ev = slot.ev_copy;
-      slot.batch.wait_ready = [once, ev]() { std::call_once(*once, [ev]() { (void)hipEventSynchronize(ev); }); };
-    }
-    c->coder->submit(&slot.batch);
-    c->stats.flushes++;
-    c->stats.symbols += nsym;
-    gate_lend(c);
-  }
-  BCE_TRY(k3_lane_reset_symbols(c, 0));
-  BCE_TRY(k3_lane_reset_symbols(c, 1));
-  return BCE_HIP_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -520,7 +459,6 @@ int bce_hip_debug_set(bce_hip_ctx *c, int knob, uint32_t value) {
     case 10: c->dbg_tail_round = value; break;
     case 11: c->overlap = value != 0; break;
     case 12: c->dbg_capp_div = value; break;
-    case 13: c->dbg_dual = value; break;
     case 2: c->dbg_no_tail = value; break;
     case 3: c->dbg_no_skip = value; break;
     default: return BCE_HIP_E_ARG;
@@ -717,7 +655,6 @@ int bce_hip_enum_model(bce_hip_ctx *c, uint32_t *out, uint64_t cap_records, uint
 static int encode_body(bce_hip_ctx *c);
 static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(uint64_t)> &sink);
 static int split_round(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(uint64_t)> &sink, bool *executed);
-static int enumerate_wide_dual(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(uint64_t)> &sink, bool *decaying_io, uint64_t *cur_nodes_io, bool forced);
 int bce_hip_encode(bce_hip_ctx *c) { return gate_on_error(c, bce_guarded(c, [&] { return encode_body(c); })); }
 static int encode_body(bce_hip_ctx *c) {
   BCE_TRY(check_stage(c, 3));
@@ -812,154 +749,8 @@ static int split_round(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(uin
   return BCE_HIP_OK;
 }
 
-// The wide rounds as TWO half-width pipelines: the eight tries are independent, so tries 0-3 and tries 4-7
-// run their rounds on two streams, each with a control block, tile arrays, run table and symbol region of its own (K3Lane), on
-// node lists indexed by trie.  A wide round is ~100 us of which ~45 us are fixed latency (prologue, the scan's owner chain,
-// the epilogue, the launch gap to the write pass) during which its own tiles do not run: the other pipeline's tiles do.
-// Both lanes always execute the same rounds: the batch is sized so that neither the symbol regions nor the node lists CAN
-// overflow (a round's symbols are at most its nodes, its children at most twice its nodes), so no lane ever stops early, a
-// flush takes both lanes' records up to the same round, and the merge back into the one control block happens between rounds.
-// Leaves when the rounds have become narrow (the one-launch rounds and the tail take over), when the lists would have to
-// grow, or at the end.  Records of a plane alternate between the lanes every four rounds: K4 gathers them into stream order.
-static int enumerate_wide_dual(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(uint64_t)> &sink, bool *decaying_io, uint64_t *cur_nodes_io, bool forced) {
-  const uint32_t n = c->n;
-  const uint32_t early_max = 4;
-  BCE_TRY(sink(ctl.sym_total));                      // what the rounds so far have recorded goes first
-  BCE_TRY(gate_regain(c));
-  ctl.sym_total = 0;
-  uint32_t round = c->round;
-  const uint64_t F = c->sym_cap / 2 > 4096 ? c->sym_cap / 2 : 4096;      // a lane's records at which a flush is due
-  auto lane_of = [&](uint32_t p, uint32_t r) { return (((p - r) & 7u) < 4u) ? 0 : 1; };
-  EnumCtl lc[2];
-  uint64_t m[2] = {0, 0};
-  {
-    const uint32_t par = round & 1u;
-    for (int l = 0; l < 2; ++l) {
-      memset(&lc[l], 0, sizeof(EnumCtl));
-      lc[l].done_round = 0xFFFFFFFFu;
-    }
-    for (uint32_t p = 0; p < 8; ++p) {
-      const int l = lane_of(p, round);
-      lc[l].cnt[par][p][0] = ctl.cnt[par][p][0];
-      lc[l].cnt[par][p][1] = ctl.cnt[par][p][1];
-      m[l] += (uint64_t)ctl.cnt[par][p][0] + ctl.cnt[par][p][1];
-    }
-    lc[0].nodes_total = ctl.nodes_total;
-  }
-  uint64_t mm = m[0] > m[1] ? m[0] : m[1];
-  uint64_t region = F + 7 * mm + 4096;
-  if (region < 2 * F) region = 2 * F;
-  if (region >= (1ull << 30)) return BCE_HIP_OK;     // (too wide for two regions: the one pipeline goes on)
-  BCE_TRY(k3_lanes_prepare(c, region));
-  for (int l = 0; l < 2; ++l) {
-    lc[l].sym_cap = region;
-    lc[l].next_nodes = m[l];
-    BCE_TRY(k3_lane_set_ctl(c, l, lc[l]));
-  }
-  bool decaying = *decaying_io;
-  uint64_t cur = m[0] + m[1];
-  int rc = BCE_HIP_OK;
-  for (;;) {
-    const uint32_t par = round & 1u;
-    // ---- how many rounds can NOT fail: lists (children <= 2 x nodes per plane and round), symbol regions (symbols <= nodes) ----
-    uint64_t maxp = 0;
-    for (int l = 0; l < 2; ++l)
-      for (uint32_t p = 0; p < 8; ++p) { const uint64_t v = (uint64_t)lc[l].cnt[par][p][0] + lc[l].cnt[par][p][1]; if (v > maxp) maxp = v; }
-    uint32_t k = cur > (1u << 22) ? 4u : (cur > (1u << 20) ? K3_BATCH_MID : (cur > (1u << 14) ? 16u : 64u));
-    if (k > 20) k = 20;
-    if (!decaying && c->stats.flushes < early_max) {           // as the one pipeline does: the first batches go to the coders early
-      const uint64_t want = (uint64_t)1 << (20 + c->stats.flushes);
-      uint64_t est = lc[0].sym_total + lc[1].sym_total, nn = cur;
-      uint32_t b = 0;
-      while (b < k && est < want) { est += nn; nn *= 2; ++b; }
-      k = b ? b : 1u;
-    }
-    const uint64_t mincap = c->capL[0] < c->capL[1] ? c->capL[0] : c->capL[1];
-    while (k >= 1 && (maxp << k) > mincap) --k;
-    if (k == 0) break;                               // the lists may have to grow: the one pipeline does that
-    while (k >= 1 && (lc[0].sym_total + m[0] * ((1ull << k) - 1) > region || lc[1].sym_total + m[1] * ((1ull << k) - 1) > region)) --k;
-    if (k == 0) {
-      if (lc[0].sym_total + lc[1].sym_total) {
-        BCE_TRY(flush_symbols_dual(c, lc[0].sym_total, lc[1].sym_total));
-        BCE_TRY(gate_regain(c));
-        lc[0].sym_total = lc[1].sym_total = 0;
-        continue;
-      }
-      break;                                         // one round alone is wider than a region
-    }
-    // ---- the batch: k rounds on both streams, lane 0's stream ends behind lane 1's so that its events span both ----
-    BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    BCE_HIP_TRY(c, hipStreamWaitEvent(c->lane[1].stream, c->ev0, 0));
-    for (int l = 0; l < 2; ++l) BCE_TRY(k3_lane_rounds(c, l, round, k, decaying ? m[l] : 0));
-    for (int l = 0; l < 2; ++l) BCE_TRY(k3_lane_post(c, l, k));
-    BCE_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->lane[1].ev_end, 0));
-    BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    for (int l = 0; l < 2; ++l) BCE_TRY(k3_lane_collect(c, l, &lc[l], k));
-    BCE_HIP_TRY(c, hipEventSynchronize(c->ev1));
-    { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms; }
-    for (int l = 0; l < 2; ++l) {
-      if (lc[l].stalled) return k3_stalled(c);
-      if (lc[l].need_flush || lc[l].overflow) {
-        snprintf(c->err, sizeof c->err, "k3: pipeline %d stopped at round %u (%s) inside a batch sized so that it could not", l, lc[l].skip_round, lc[l].overflow ? "node lists" : "symbol region");
-        return BCE_HIP_E_INTERNAL;
-      }
-    }
-    round += k;
-    const uint32_t npar = round & 1u;
-    m[0] = m[1] = 0;
-    for (int l = 0; l < 2; ++l)
-      for (uint32_t p = 0; p < 8; ++p) m[l] += (uint64_t)lc[l].cnt[npar][p][0] + lc[l].cnt[npar][p][1];
-    const uint64_t next = m[0] + m[1];
-    if (c->progress) c->progress(lc[0].nodes_total + lc[1].nodes_total, 8ull * n, c->progress_user);
-    decaying = next <= cur && round > 16;
-    if (c->dbg_tail_round && round >= c->dbg_tail_round) decaying = true;
-    cur = next;
-    const uint64_t st = lc[0].sym_total + lc[1].sym_total;
-    const bool early = c->stats.flushes < early_max && st >= ((uint64_t)1 << (20 + c->stats.flushes));
-    if (lc[0].sym_total >= F || lc[1].sym_total >= F || early) {
-      BCE_TRY(flush_symbols_dual(c, lc[0].sym_total, lc[1].sym_total));
-      BCE_TRY(gate_regain(c));
-      lc[0].sym_total = lc[1].sym_total = 0;
-    }
-    if (next == 0) break;                                            // the end of the enumeration
-    if (next <= (forced ? 2048u : K3_SMALL_NODES)) break;            // narrow again: one-launch rounds, then the tail
-  }
-  // ---- back into the one control block ----
-  BCE_TRY(flush_symbols_dual(c, lc[0].sym_total, lc[1].sym_total));
-  BCE_TRY(gate_regain(c));
-  for (int l = 0; l < 2; ++l) BCE_HIP_TRY(c, hipStreamSynchronize(c->lane[l].stream));
-  {
-    const uint32_t par = round & 1u;
-    EnumCtl mg;
-    memset(&mg, 0, sizeof mg);
-    for (uint32_t p = 0; p < 8; ++p)
-      for (int sgm = 0; sgm < 2; ++sgm) mg.cnt[par][p][sgm] = lc[0].cnt[par][p][sgm] + lc[1].cnt[par][p][sgm];
-    mg.sym_cap = c->sym_cap;
-    mg.nodes_total = lc[0].nodes_total + lc[1].nodes_total;
-    mg.next_nodes = m[0] + m[1];
-    mg.done_round = 0xFFFFFFFFu;
-    if (mg.next_nodes == 0) {
-      // the first round whose successor is empty: the later of the two pipelines' (a pipeline that had no node at all never says)
-      uint32_t d = 0;
-      for (int l = 0; l < 2; ++l) if (lc[l].done_round != 0xFFFFFFFFu && lc[l].done_round > d) d = lc[l].done_round;
-      mg.done_round = d ? d : round;
-    }
-    BCE_HIP_TRY(c, hipMemcpyAsync(c->ctl.p, &mg, sizeof mg, hipMemcpyHostToDevice, c->stream));
-    BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    ctl = mg;
-  }
-  c->round = round;
-  for (int p = 0; p < 8; ++p) c->run_log[p].clear();
-  *decaying_io = decaying;
-  *cur_nodes_io = ctl.next_nodes;
-  c->stats.dual_rounds += 1.0;
-  return rc;
-}
-
 static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(uint64_t)> &sink) {
   const uint32_t n = c->n;
-  static const bool no_dual_env = getenv("BCE_HIP_NO_DUAL") != nullptr;
-  bool dual_ok = !c->scan_mode && !c->overlap && c->dbg_dual != 2 && !(no_dual_env && c->dbg_dual != 1) && c->coder != nullptr;
   uint64_t split_limit = 1ull << 31;
   if (const char *e = getenv("BCE_HIP_SPLIT_SYMS")) { const uint64_t v = strtoull(e, nullptr, 10); if (v && v < split_limit) split_limit = v; }
   uint64_t cur_nodes = 0;
@@ -1064,17 +855,6 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
     } else {
       // wide rounds: sync often (the round dominates); medium rounds: queue many per sync
       wide_once = false;
-      if (dual_ok && have_ctl && !ctl.need_flush && ctl.done_round == 0xFFFFFFFFu && cur_nodes && (cur_nodes > K3_SMALL_NODES || c->dbg_dual == 1)) {
-        // ... as two half-width pipelines on two streams, for as long as the rounds stay wide
-        const uint32_t r0 = c->round;
-        BCE_TRY(enumerate_wide_dual(c, ctl, sink, &decaying, &cur_nodes, c->dbg_dual == 1));
-        if (c->round != r0) {
-          est_syms = 0;
-          if (ctl.done_round != 0xFFFFFFFFu) break;
-          continue;
-        }
-        dual_ok = false;                             // (it could not run a single round -- lists at their limit, a round wider than a region: the one pipeline from here on)
-      }
       uint32_t batch = cur_nodes > (1u << 22) ? 4u : (cur_nodes > (1u << 20) ? K3_BATCH_MID : (cur_nodes > (1u << 14) ? 16u : 64u));
       // ramp-up: the node count doubles per round; once a round or two reach the next early-flush size, stop there so
       // that the coders get their first (small) batches as early as possible

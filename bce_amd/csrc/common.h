@@ -126,20 +126,6 @@ inline void slot_free_host(FlushSlot &s, uint32_t *unmaps = nullptr) {
 
 struct RunEntry { uint64_t start; uint32_t count; uint32_t round; };  // symbols of (round, plane): [start, start+count)
 
-// One of the two half-width pipelines of the wide rounds (api.hip, enumerate_wide_dual): the tries are independent, so the rounds
-// of tries 0-3 and of tries 4-7 run on two streams, each with a control block, tile arrays, run table and symbol region of its
-// own, on the node lists they share (at every round the two groups occupy disjoint planes).
-struct K3Lane {
-  DevBuf ctl, tilecnt, tileoff, k3tw, k3grp, runs;
-  size_t groups = 0;
-  void *h_ctl = nullptr, *h_runs = nullptr;
-  hipStream_t stream = nullptr;          // lane 0: the context's main stream; lane 1: one of its own
-  hipEvent_t ev_end = nullptr;
-  uint64_t sym_base = 0, sym_cap = 0;    // its region of the symbol record arrays [sym_base, sym_base + sym_cap)
-  std::vector<RunEntry> runs_log;        // (round, plane) runs since the last flush, starts relative to sym_base, in launch order
-  std::vector<uint8_t> runs_plane;       // ... and the plane of each
-};
-
 }  // namespace bce
 
 struct bce_hip_ctx {
@@ -210,12 +196,6 @@ struct bce_hip_ctx {
   bool scan_mode = false;                        // `bce -s`: K3 emits scan_pack words (bce_core.h) into scanrec
   bce::DevBuf scanrec;
   bce::DevBuf stat, dcfg, k4w;                   // K4 counters, device copy of PlaneCfg[8], per-window work arrays
-  bce::K3Lane lane[2];                           // the two half-width pipelines of the wide rounds
-  bool lanes_ready = false;
-  bce::DevBuf skey_g, gruns;                     // dual flushes: the records' keys gathered into stream order; the run list of the gather
-  void *h_gruns = nullptr;
-  size_t h_gruns_cap = 0;
-  uint32_t dbg_dual = 0;                         // debug knob 13: 1 = wide rounds of any width go through the two pipelines, 2 = never
   uint32_t stat_off[8] = {0};
 
   // pinned host staging
@@ -385,14 +365,6 @@ int k2_rank1(bce_hip_ctx *c, int plane, const uint32_t *idx, uint32_t count, uin
 int k3_begin(bce_hip_ctx *c);                       // k3_enumerate.hip
 int k3_rounds(bce_hip_ctx *c, uint32_t count, uint64_t nodes_hint);
 int k3_rounds_small(bce_hip_ctx *c, uint32_t count, uint64_t cur_nodes, bool growing);   // one launch per round, narrow rounds
-int k3_lanes_prepare(bce_hip_ctx *c, uint64_t region_records);       // the two pipelines' buffers, streams, symbol regions
-int k3_lane_rounds(bce_hip_ctx *c, int lane, uint32_t first_round, uint32_t count, uint64_t nodes_hint);   // queue (no sync)
-int k3_lane_post(bce_hip_ctx *c, int lane, uint32_t rounds);       // behind the batch: control block + run table come over, ev_end recorded
-int k3_lane_collect(bce_hip_ctx *c, int lane, EnumCtl *out, uint32_t rounds);   // syncs the lane's stream; runs appended to its log
-int k3_lane_reset_symbols(bce_hip_ctx *c, int lane);
-int k3_lane_set_ctl(bce_hip_ctx *c, int lane, const EnumCtl &ctl);
-struct GatherRun { uint32_t src; uint32_t dst; };                     // a run of records: first source index, first position in stream order
-int k4_flush_dual_async(bce_hip_ctx *c, const std::vector<GatherRun> &runs, uint32_t nsym, uint64_t nA, uint64_t baseB, uint64_t nB, FlushSlot &slot);
 int k3_round_masked(bce_hip_ctx *c, uint32_t mask, bool repeat);   // one round, three launches, symbols of the planes in `mask` only
 int k3_clear_need_flush(bce_hip_ctx *c);
 int k3_clear_small_bail(bce_hip_ctx *c);   // queue `count` rounds from c->round (no sync)

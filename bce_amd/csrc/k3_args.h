@@ -14,7 +14,7 @@ constexpr uint32_t K3_MAXBATCH = 256;           // rounds per run-table batch
 
 struct K3Args {
   EnumCtl *ctl;
-  Node *nodes[2];         // [parity] -> [8 tries][cap[parity]]: the two parities' lists are buffers of their own (a round reads one
+  Node *nodes[2];         // [parity] -> [8][cap[parity]]: the two parities' lists are buffers of their own (a round reads one
                           // parity and writes the other, so the one that is written can be replaced by a larger one without a copy)
   const Granule *gran;    // [8][ngran]
   const PlaneCfg *cfg;    // [8]
@@ -43,12 +43,8 @@ struct K3Args {
 };
 
 __device__ __forceinline__ uint32_t list_cap(const K3Args &a, uint32_t par) { return par ? a.cap[1] : a.cap[0]; }
-// The lists of plane p as they stand at `round` (parity par = round & 1).  A buffer's eight lists are indexed by TRIE, not by
-// plane: trie t is in plane (t + round) & 7 at every round, so a trie's nodes and their children always use list t of the
-// two parities -- and two pipelines that own disjoint tries (common.h, K3Lane) never touch each other's lists, however far
-// apart their rounds are.
-__device__ __forceinline__ Node *plane_nodes(const K3Args &a, uint32_t par, uint32_t p, uint32_t round) {
-  return (par ? a.nodes[1] : a.nodes[0]) + (size_t)((p - round) & 7u) * list_cap(a, par);
+__device__ __forceinline__ Node *plane_nodes(const K3Args &a, uint32_t par, uint32_t p) {
+  return (par ? a.nodes[1] : a.nodes[0]) + (size_t)p * list_cap(a, par);
 }
 
 K3Args k3_make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot);   // k3_enumerate.hip

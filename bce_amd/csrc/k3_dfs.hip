@@ -929,7 +929,7 @@ __global__ __launch_bounds__(UNI ? KD_T * KD_HELP : KD_T) void k3_dfs_kernel(Dfs
 #pragma unroll
     for (uint32_t j = 1; j < 8; ++j) p += q >= pbase[j] ? 1u : 0u;
     const uint32_t idx = q - pbase[p], c0 = ctl->cnt[k.par][p][0];
-    const Node nd = plane_nodes(k, k.par, p, k.round)[idx < c0 ? idx : (list_cap(k, k.par) - 1u - (idx - c0))];
+    const Node nd = plane_nodes(k, k.par, p)[idx < c0 ? idx : (list_cap(k, k.par) - 1u - (idx - c0))];
     return uni_node(DNode{nd.s, nd.x0, nd.x1, p, a.round0});
   };
   uint32_t next = gid;                                        // my next queued node
@@ -1241,7 +1241,7 @@ __global__ __launch_bounds__(LB_T) void k3_local_kernel(DfsArgs a) {
 #pragma unroll
       for (uint32_t j = 1; j < 8; ++j) p += g >= pbase[j] ? 1u : 0u;
       const uint32_t idx = g - pbase[p], c0 = ctl->cnt[k.par][p][0];
-      const Node nd = plane_nodes(k, k.par, p, k.round)[idx < c0 ? idx : (list_cap(k, k.par) - 1u - (idx - c0))];
+      const Node nd = plane_nodes(k, k.par, p)[idx < c0 ? idx : (list_cap(k, k.par) - 1u - (idx - c0))];
       buf[0][q] = LNode{nd.s, nd.x0, nd.x1, p};
     }
   }

@@ -78,7 +78,7 @@ constexpr uint32_t K3_CAP32 = 0xFFFFFFFFu / (uint32_t)sizeof(Node) - 16u;     //
 __device__ __forceinline__ void k3_load_nodes(const K3Args &a, uint32_t p, uint32_t tile_in_plane, uint32_t c0n, uint32_t c1n,
                                               Node (&nd)[K3_NPT]) {
   const uint32_t M = c0n + c1n;
-  const Node *src = plane_nodes(a, a.par, p, a.round);
+  const Node *src = plane_nodes(a, a.par, p);
   const uint32_t cap = list_cap(a, a.par);
   if (cap <= a.cap32) {                                         // (uniform)
 #pragma unroll
@@ -164,7 +164,7 @@ __device__ __forceinline__ void k3_place(const K3Args &a, uint32_t p, const Tile
                                          uint32_t (*lds_cnt)[4][3], uint32_t o0, uint32_t o1, uint64_t os) {
   const uint32_t w = threadIdx.x >> 6;
   const uint32_t pn = (p + 1u) & 7u;
-  Node *dst = plane_nodes(a, a.par ^ 1u, pn, a.round + 1u);
+  Node *dst = plane_nodes(a, a.par ^ 1u, pn);
   const uint32_t capo = list_cap(a, a.par ^ 1u);
   uint32_t run0 = 0, run1 = 0, runs_ = 0;   // counts of earlier (it, wave) groups
 #pragma unroll
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(KT_T) void k3_tail_kernel(K3Args a, RunEntry *truns
 #pragma unroll
     for (int k = 1; k < 8; ++k) p += (q >= off[k]) ? 1u : 0u;
     const uint32_t i = q - off[p], c0 = cnt[par][p][0];
-    buf[0][q] = plane_nodes(a, par, p, round)[i < c0 ? i : (list_cap(a, par) - 1u - (i - c0))];
+    buf[0][q] = plane_nodes(a, par, p)[i < c0 ? i : (list_cap(a, par) - 1u - (i - c0))];
   }
   uint64_t sym_total = ctl->sym_total, nodes_total = ctl->nodes_total;
   const uint64_t sym_cap = ctl->sym_cap;
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(KT_T) void k3_tail_kernel(K3Args a, RunEntry *truns
 #pragma unroll
     for (int k = 1; k < 8; ++k) p += (q >= off[k]) ? 1u : 0u;
     const uint32_t i = q - off[p], c0 = cnt[par][p][0];
-    plane_nodes(a, par, p, round)[i < c0 ? i : (list_cap(a, par) - 1u - (i - c0))] = buf[cur][q];
+    plane_nodes(a, par, p)[i < c0 ? i : (list_cap(a, par) - 1u - (i - c0))] = buf[cur][q];
   }
   if (tid < 16) ctl->cnt[par][tid >> 1][tid & 1] = cnt[par][tid >> 1][tid & 1];
   if (tid == 0) {
@@ -930,131 +930,6 @@ K3Args k3_make_args(bce_hip_ctx *c, uint32_t round, uint32_t run_slot) {
   }
   a.pmask = (c->scan_mode || !c->coder) ? 0xFFu : (c->coder->plane_mask & 0xFFu);
   return a;
-}
-
-// ---- the two half-width pipelines of the wide rounds (api.hip: enumerate_wide_dual) ----------------------------------------------
-// Lane 0 works on the context's main stream, lane 1 on a stream of its own; each has its control block, tile arrays, run
-// table and its region [sym_base, sym_base + sym_cap) of the symbol record arrays.  The node lists are shared: they are indexed
-// by trie (k3_args.h, plane_nodes), and the lanes own disjoint tries.
-static int lane_size_tile_arrays(bce_hip_ctx *c, K3Lane &L) {
-  const uint32_t capm = c->capL[0] > c->capL[1] ? c->capL[0] : c->capL[1];
-  const size_t tiles = (size_t)8 * ((capm + K3_TILE - 1) / K3_TILE) + 8;
-  BCE_TRY(ensure(c, L.tilecnt, tiles * 16));
-  BCE_TRY(ensure(c, L.tileoff, tiles * 16));
-  L.groups = tiles / 256 + 16;
-  BCE_TRY(ensure(c, L.k3tw, tiles * 8));
-  BCE_TRY(ensure(c, L.k3grp, L.groups * 32 + 64));
-  BCE_HIP_TRY(c, hipMemsetAsync(L.k3tw.p, 0, tiles * 8, c->stream));
-  BCE_HIP_TRY(c, hipMemsetAsync(L.k3grp.p, 0, L.groups * 32 + 64, c->stream));
-  return BCE_HIP_OK;
-}
-
-int k3_lanes_prepare(bce_hip_ctx *c, uint64_t region_records) {
-  if (region_records >= (1ull << 30)) return BCE_HIP_E_OVERFLOW;
-  for (int i = 0; i < 2; ++i) {
-    K3Lane &L = c->lane[i];
-    if (!L.stream) {
-      if (i == 0) L.stream = c->stream;
-      else BCE_HIP_TRY(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-    }
-    if (!L.ev_end) BCE_HIP_TRY(c, hipEventCreateWithFlags(&L.ev_end, hipEventDisableTiming));
-    if (!L.h_ctl) BCE_TRY(pin_alloc(c, &L.h_ctl, sizeof(EnumCtl)));
-    if (!L.h_runs) BCE_TRY(pin_alloc(c, &L.h_runs, (size_t)K3_MAXBATCH * 8 * sizeof(RunEntry)));
-    BCE_TRY(ensure(c, L.ctl, sizeof(EnumCtl)));
-    BCE_TRY(ensure(c, L.runs, (size_t)K3_MAXBATCH * 8 * sizeof(RunEntry)));
-    BCE_TRY(lane_size_tile_arrays(c, L));
-    L.sym_base = (uint64_t)i * region_records;
-    L.sym_cap = region_records;
-    L.runs_log.clear(); L.runs_plane.clear();
-  }
-  BCE_TRY(ensure(c, c->skey[0], (size_t)region_records * 8));          // 2 regions x 4 B
-  BCE_TRY(ensure(c, c->sesc, (size_t)region_records * 8));
-  BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->lanes_ready = true;
-  return BCE_HIP_OK;
-}
-
-static K3Args lane_args(bce_hip_ctx *c, int lane, uint32_t round, uint32_t run_slot) {
-  K3Args a = k3_make_args(c, round, run_slot);
-  const K3Lane &L = c->lane[lane];
-  a.ctl = L.ctl.as<EnumCtl>();
-  a.symkey = c->skey[0].as<uint32_t>() + L.sym_base;
-  a.symesc = c->sesc.as<uint32_t>() + L.sym_base;
-  a.tilecnt = L.tilecnt.as<uint32_t>();
-  a.tileoff = L.tileoff.as<uint32_t>();
-  a.runs = L.runs.as<RunEntry>();
-  a.tw = L.k3tw.as<unsigned long long>();
-  uint8_t *base = L.k3grp.as<uint8_t>();
-  a.gwa = reinterpret_cast<unsigned long long *>(base);
-  a.gwb = reinterpret_cast<unsigned long long *>(base + L.groups * 8);
-  a.goff = reinterpret_cast<uint32_t *>(base + L.groups * 16);
-  return a;
-}
-
-int k3_lane_set_ctl(bce_hip_ctx *c, int lane, const EnumCtl &ctl) {
-  K3Lane &L = c->lane[lane];
-  memcpy(L.h_ctl, &ctl, sizeof ctl);
-  BCE_HIP_TRY(c, hipMemcpyAsync(L.ctl.p, L.h_ctl, sizeof ctl, hipMemcpyHostToDevice, L.stream));
-  BCE_HIP_TRY(c, hipStreamSynchronize(L.stream));
-  return BCE_HIP_OK;
-}
-
-// `count` rounds of one lane from `first_round`, queued on its stream (no sync).  Two launches per round, the grid half of
-// what is resident together: both lanes' count kernels run side by side and every block of either must have its slot.
-int k3_lane_rounds(bce_hip_ctx *c, int lane, uint32_t first_round, uint32_t count, uint64_t nodes_hint) {
-  if (count > K3_MAXBATCH) count = K3_MAXBATCH;
-  K3Lane &L = c->lane[lane];
-  uint64_t want = nodes_hint ? (nodes_hint * 2 + K3_TILE - 1) / K3_TILE + 16 : 1024;
-  const uint32_t grid = (uint32_t)(want < 1024 ? want : 1024);
-  const bool fused = !c->dbg_no_fused;
-  if (fused && !c->k3_count2_grid) {
-    int per_cu = 0, cus = 0;
-    BCE_HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_count2_kernel<false>, K3_T, 0));
-    BCE_HIP_TRY(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-    c->k3_count2_grid = (uint32_t)(per_cu > 0 && cus > 0 ? per_cu * cus : 1024);
-  }
-  const uint32_t half = c->k3_count2_grid / 2 ? c->k3_count2_grid / 2 : 1;
-  const uint32_t grid2 = fused ? (grid < half ? grid : half) : grid;
-  for (uint32_t i = 0; i < count; ++i) {
-    K3Args a = lane_args(c, lane, first_round + i, i);
-    a.fused = fused ? 1u : 0u;
-    if (fused) hipLaunchKernelGGL((k3_count2_kernel<false>), dim3(grid2), dim3(K3_T), 0, L.stream, a);
-    else {
-      hipLaunchKernelGGL((k3_tiles_kernel<false, false>), dim3(grid), dim3(K3_T), 0, L.stream, a);
-      hipLaunchKernelGGL(k3_scan_kernel, dim3(8), dim3(1024), 0, L.stream, a);
-    }
-    hipLaunchKernelGGL((k3_tiles_kernel<true, false>), dim3(grid), dim3(K3_T), 0, L.stream, a);
-  }
-  BCE_HIP_TRY(c, hipGetLastError());
-  c->stats.k3_launches += (fused ? 2.0 : 3.0) * count;
-  return BCE_HIP_OK;
-}
-
-// Behind a lane's batch: its control block and the batch's run table rows come over; ev_end marks the lane's end.
-int k3_lane_post(bce_hip_ctx *c, int lane, uint32_t rounds) {
-  K3Lane &L = c->lane[lane];
-  BCE_HIP_TRY(c, hipMemcpyAsync(L.h_ctl, L.ctl.p, sizeof(EnumCtl), hipMemcpyDeviceToHost, L.stream));
-  if (rounds) BCE_HIP_TRY(c, hipMemcpyAsync(L.h_runs, L.runs.p, (size_t)rounds * 8 * sizeof(RunEntry), hipMemcpyDeviceToHost, L.stream));
-  BCE_HIP_TRY(c, hipEventRecord(L.ev_end, L.stream));
-  return BCE_HIP_OK;
-}
-// ... and once its stream has been waited for: the control block, and the runs appended to the lane's log.
-int k3_lane_collect(bce_hip_ctx *c, int lane, EnumCtl *out, uint32_t rounds) {
-  K3Lane &L = c->lane[lane];
-  BCE_HIP_TRY(c, hipStreamSynchronize(L.stream));
-  memcpy(out, L.h_ctl, sizeof(EnumCtl));
-  if (out->need_flush || out->overflow || out->stalled) return BCE_HIP_OK;      // (the caller reports it; the run table is not complete)
-  const RunEntry *r = reinterpret_cast<const RunEntry *>(L.h_runs);
-  for (uint32_t i = 0; i < rounds; ++i)
-    for (int p = 0; p < 8; ++p)
-      if (r[(size_t)i * 8 + p].count) { L.runs_log.push_back(r[(size_t)i * 8 + p]); L.runs_plane.push_back((uint8_t)p); }
-  return BCE_HIP_OK;
-}
-int k3_lane_reset_symbols(bce_hip_ctx *c, int lane) {
-  K3Lane &L = c->lane[lane];
-  BCE_HIP_TRY(c, hipMemsetAsync(&L.ctl.as<EnumCtl>()->sym_total, 0, sizeof(uint64_t), L.stream));
-  L.runs_log.clear(); L.runs_plane.clear();
-  return BCE_HIP_OK;
 }
 
 // The largest list an input of n bytes can need: n/2 nodes per plane-round (disjoint intervals of width >= 2; text peaks at
@@ -1177,7 +1052,7 @@ int k3_begin(bce_hip_ctx *c) {
     const uint32_t C = c->zeros[(i + 7) & 7];
     if (C && n - C) {
       Node root = {0u, C, n - C};
-      BCE_HIP_TRY(c, hipMemcpyAsync(c->nlist[0].as<Node>() + (size_t)i * c->capL[0], &root, sizeof root,      // (list = trie i: k3_args.h)
+      BCE_HIP_TRY(c, hipMemcpyAsync(c->nlist[0].as<Node>() + (size_t)i * c->capL[0], &root, sizeof root,
                                     hipMemcpyHostToDevice, c->stream));
       BCE_HIP_TRY(c, hipStreamSynchronize(c->stream));   // `root` is a stack temporary
       ctl.cnt[0][i][0] = 1;
@@ -1361,7 +1236,7 @@ int k3_get_nodes(bce_hip_ctx *c, int plane, uint32_t *out, uint32_t cap, uint32_
   *count = c0 + c1;
   if (c0 + c1 > cap) return BCE_HIP_E_OVERFLOW;
   const uint32_t capl = c->capL[par];
-  const Node *src = c->nlist[par].as<Node>() + (size_t)(((uint32_t)plane - c->round) & 7u) * capl;   // (lists are indexed by trie)
+  const Node *src = c->nlist[par].as<Node>() + (size_t)plane * capl;
   if (c0) BCE_HIP_TRY(c, hipMemcpy(out, src, (size_t)c0 * sizeof(Node), hipMemcpyDeviceToHost));
   if (c1) {
     std::vector<Node> tmp(c1);

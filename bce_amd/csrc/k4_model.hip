@@ -60,28 +60,11 @@ struct K4Args {
   uint32_t *qcount;
   uint32_t stat_off[8];
   uint32_t nsym;
-  // dual flushes (two symbol regions): a record of the second region writes its output behind the first region's records,
-  // so that the outputs of a flush are one compact array: index >= xbase -> index - xsub
-  uint32_t xbase, xsub;
 };
 
 __global__ __launch_bounds__(K4_T) void k4_iota_kernel(uint32_t nsym, uint32_t *__restrict__ vals) {
   for (uint64_t i = (uint64_t)blockIdx.x * K4_T + threadIdx.x; i < nsym; i += (uint64_t)gridDim.x * K4_T)
     vals[i] = (uint32_t)i;
-}
-
-// Dual flushes: the records of a flush lie in two regions, run by run; `runs` lists the (round, plane) runs in stream order
-// (first source index, first position).  Position j of the sort's input <- the record that stands there: key word gathered,
-// its index as the value (what k4_iota_kernel writes when the records lie in stream order already).
-__global__ __launch_bounds__(K4_T) void k4_gather_kernel(uint32_t nsym, const GatherRun *__restrict__ runs, uint32_t nruns,
-                                                         const uint32_t *__restrict__ symkey, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-  for (uint64_t j = (uint64_t)blockIdx.x * K4_T + threadIdx.x; j < nsym; j += (uint64_t)gridDim.x * K4_T) {
-    uint32_t lo = 0, hi = nruns;                       // the last run with dst <= j
-    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (runs[mid].dst <= (uint32_t)j) lo = mid; else hi = mid; }
-    const uint32_t src = runs[lo].src + ((uint32_t)j - runs[lo].dst);
-    keys[j] = symkey[src];
-    vals[j] = src;
-  }
 }
 
 __device__ __forceinline__ uint8_t *k4_counters(const K4Args &a, uint32_t hkey) {
@@ -153,7 +136,7 @@ __device__ __forceinline__ uint64_t k4_replay(const K4Args &a, uint64_t pos, uin
     const bool commit = lane < nc;
     if (commit) {
       const uint32_t cum = Ps + ltb + s, total = T + lane + k, freq = before + 1u;
-      a.out[idx >= a.xbase ? idx - a.xsub : idx] = pack_model_out(cum, freq, total, esc_possible ? a.esc[idx] : 0u);
+      a.out[idx] = pack_model_out(cum, freq, total, esc_possible ? a.esc[idx] : 0u);
     }
     const uint64_t cm = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);
     C += k4_symbol_counts(s, eq, cm, commit, cb, lane);
@@ -406,14 +389,7 @@ int k4_prepare(bce_hip_ctx *c) {
   return BCE_HIP_OK;
 }
 
-struct K4Dual { const std::vector<GatherRun> *runs; uint64_t nA, baseB, nB; };
-static int k4_flush_impl(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot, const K4Dual *dual);
-int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) { return k4_flush_impl(c, nsym64, slot, nullptr); }
-int k4_flush_dual_async(bce_hip_ctx *c, const std::vector<GatherRun> &runs, uint32_t nsym, uint64_t nA, uint64_t baseB, uint64_t nB, FlushSlot &slot) {
-  const K4Dual d{&runs, nA, baseB, nB};
-  return k4_flush_impl(c, nsym, slot, &d);
-}
-static int k4_flush_impl(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot, const K4Dual *dual) {
+int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   if (nsym64 == 0) return BCE_HIP_OK;
   if (nsym64 >= (1ull << 31)) return BCE_HIP_E_OVERFLOW;
   const uint32_t nsym = (uint32_t)nsym64;
@@ -455,23 +431,6 @@ static int k4_flush_impl(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot, const
   uint32_t *val[2] = {c->sval[0].as<uint32_t>(), c->sval[1].as<uint32_t>()};
   uint64_t gb = ((uint64_t)nsym + K4_T - 1) / K4_T;
   const uint32_t grid = (uint32_t)(gb < 8192 ? gb : 8192);
-  if (dual) {
-    // the records lie in two regions of skey[0]: their keys are gathered into stream order (skey_g, the sort's first buffer)
-    const uint32_t nruns = (uint32_t)dual->runs->size();
-    BCE_TRY(ensure(c, c->skey_g, b4));
-    BCE_TRY(ensure(c, c->gruns, (size_t)nruns * sizeof(GatherRun) + 16));
-    if (c->h_gruns_cap < (size_t)nruns * sizeof(GatherRun)) {
-      if (c->h_gruns) { BCE_HIP_TRY(c, hipStreamSynchronize(ks)); (void)hipHostFree(c->h_gruns); c->h_gruns = nullptr; c->h_gruns_cap = 0; }
-      const size_t want = ((size_t)nruns * sizeof(GatherRun)) * 2 + 65536;
-      BCE_TRY(pin_alloc(c, &c->h_gruns, want));
-      c->h_gruns_cap = want;
-    } else BCE_HIP_TRY(c, hipStreamSynchronize(ks));       // (the staging of the flush before this one has been read)
-    memcpy(c->h_gruns, dual->runs->data(), (size_t)nruns * sizeof(GatherRun));
-    BCE_HIP_TRY(c, hipMemcpyAsync(c->gruns.p, c->h_gruns, (size_t)nruns * sizeof(GatherRun), hipMemcpyHostToDevice, ks));
-    hipLaunchKernelGGL(k4_gather_kernel, dim3(grid), dim3(K4_T), 0, ks, nsym, c->gruns.as<GatherRun>(), nruns,
-                       c->skey[0].as<uint32_t>(), c->skey_g.as<uint32_t>(), val[0]);
-    key[0] = c->skey_g.as<uint32_t>();
-  } else
   hipLaunchKernelGGL(k4_iota_kernel, dim3(grid), dim3(K4_T), 0, ks, nsym, val[0]);
   int res = 0;
   BCE_TRY(radix_sort_pairs_on(c, ks, own ? c->rs_hist_k4 : c->rs_hist, key, val, nsym, kSymRunShift, kSymRunBits, &res, 10));
@@ -497,8 +456,6 @@ static int k4_flush_impl(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot, const
   a.qcount = reinterpret_cast<uint32_t *>(wbuf + o_qc);
   for (int p = 0; p < 8; ++p) a.stat_off[p] = c->stat_off[p];
   a.nsym = nsym;
-  a.xbase = 0xFFFFFFFFu; a.xsub = 0;
-  if (dual) { a.xbase = (uint32_t)dual->baseB; a.xsub = (uint32_t)(dual->baseB - dual->nA); }
   BCE_HIP_TRY(c, hipMemsetAsync(a.qcount, 0, 16, ks));
   uint64_t wb = ((uint64_t)nwin + (K4_T / 64) - 1) / (K4_T / 64);
   const uint32_t sgrid = (uint32_t)(wb < 16384 ? (wb ? wb : 1) : 16384);

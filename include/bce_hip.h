@@ -75,8 +75,7 @@ int bce_hip_set_progress(bce_hip_ctx *ctx, bce_hip_progress_fn fn, void *user);
  * 8 = live nodes below which the walkers take over from the workgroup-local rounds (default 16 384; the tail itself starts at 1 M live nodes with the local rounds, at 65 536 without them: BCE_HIP_DFS_ENTER), 9 = rounds a workgroup runs per pass before it hands on (default 192),
  * 10 = round from which the tail may start although the node count still grows (exercises the spill path),
  * 11 = model flushes (K4) on a stream of their own beside the next K3 rounds, double-buffered symbol records (also BCE_HIP_OVERLAP=1),
- * 12 = d: the node lists start with n / d + 4096 nodes instead of n / 8 + 4096 (also BCE_HIP_CAPP_DIV=d; large d: the lists grow many times),
- * 13 = the wide rounds' two half-width pipelines: 1 = every wide-path round takes them, however narrow; 2 = never (also BCE_HIP_NO_DUAL=1).
+ * 12 = d: the node lists start with n / d + 4096 nodes instead of n / 8 + 4096 (also BCE_HIP_CAPP_DIV=d; large d: the lists grow many times).
  * The archive never depends on them. */
 int bce_hip_debug_set(bce_hip_ctx *ctx, int knob, uint32_t value);
 
@@ -196,7 +195,6 @@ typedef struct bce_hip_stats {
   double t_coder_busy;         /* busiest host coder thread (t_coder is only the part not hidden behind GPU work) */
   double list_grows;           /* times a round did not fit the node lists and they were doubled (k3_grow_lists) */
   double list_nodes;           /* nodes per list at the end (the larger of the two parities) */
-  double dual_rounds;          /* stretches of wide rounds run as two half-width pipelines on two streams (0 = never) */
   double split_rounds;         /* rounds whose symbols did not fit one model flush and were run plane group by plane group */
   /* since the context was created (not reset by a load): */
   double reg_maps;             /* host mappings registered with the runtime (flush slots, the decoder's boundary ranks) */
