@@ -251,7 +251,7 @@ def extra_workloads(ctx, dev, table, pool=None, stream_steps=12, decode=True):
     return out
 
 
-def big_workload(local, dev, table, n=1_000_000_000):
+def big_workload(local, dev, table, n=1_000_000_000, stream_contexts=3):
     """BASELINE configs[2] stand-in: 10^9 bytes of synth-text v1 seed 1 on ONE GPU, everything resident in HBM (SA and
     rank arrays 36 n, node lists, symbol records).  1 warm-up + 1 timed step in a context of its own (closed afterwards:
     its buffers are ~70 GB).  The archive is pinned to the ORACLE's (tests/golden/oracle_fullsize.json, synth-text-1e9:
@@ -266,6 +266,15 @@ def big_workload(local, dev, table, n=1_000_000_000):
             dt, arch, sts = timed_steps(ctx, t_in, n, 1, 1)
         finally:
             ctx.close()
+        # a stream of such inputs through three gated contexts (~86 GB each: what fits beside the input; a context that runs out
+        # of device memory gives its idle stages' buffers back, api.hip ctx_trim)
+        stream = None
+        if stream_contexts:
+            try:
+                with bce_amd.ContextPool(stream_contexts, local) as pool:
+                    stream = stream_leg(pool, t_in, n, 2 * stream_contexts, arch)
+            except Exception as e:
+                stream = {"error": "%s: %s" % (type(e).__name__, e)}
         del t_in
         torch.cuda.empty_cache()
         r = roofline(n, sts)
@@ -287,7 +296,7 @@ def big_workload(local, dev, table, n=1_000_000_000):
                 "k1_ms": round(st["t_bwt"] * 1e3, 2), "k2_ms": round(st["t_planes"] * 1e3, 2), "k4_ms": round(st["t_model"] * 1e3, 2),
                 "coder_busy_ms": round(st["t_coder_busy"] * 1e3, 2),
                 "archive_bytes": len(arch), "archive_sha256": hashlib.sha256(arch).hexdigest(),
-                "oracle_golden": golden_verdict(table, data, arch)}
+                "oracle_golden": golden_verdict(table, data, arch), "stream": stream}
     except Exception as e:
         return {"workload": desc, "error": "%s: %s" % (type(e).__name__, e)}
 
@@ -654,7 +663,7 @@ def main():
                 pool = None
             if not args.no_big:
                 out["workloads"].append(scanned_workload(local, dev, table))     # BASELINE configs[4] stand-in
-                out["workloads"].append(big_workload(local, dev, table))         # BASELINE configs[2] stand-in (10^9 B)
+                out["workloads"].append(big_workload(local, dev, table, stream_contexts=0 if args.no_stream else 3))   # BASELINE configs[2] stand-in (10^9 B)
         if pool is not None:
             pool.close()
         if "workloads" in out:
