@@ -196,9 +196,11 @@ def timed_decode(arch, ctx, data):
     are the input's."""
     n = len(data)
     buf = np.zeros(n + 64, dtype=np.uint8)
+    r0 = bce_amd.stats_of(ctx)["dec_restarts"]
     t0 = time.perf_counter()
     got = bce_amd.decompress_device(arch, ctx=ctx, out=buf)
     td = time.perf_counter() - t0
+    timed_decode.restarts = int(bce_amd.stats_of(ctx)["dec_restarts"] - r0)     # decodes started again with larger node lists (0 in a warm context)
     return td, bool(got == n and np.array_equal(buf[:n], np.asarray(data).reshape(-1)))
 
 
@@ -236,7 +238,8 @@ def extra_workloads(ctx, dev, table, pool=None, stream_steps=12, decode=True):
                 try:
                     timed_decode(arch, ctx, data)               # (warm-up: this workload's decoder buffers, as for the headline)
                     td, same = timed_decode(arch, ctx, data)
-                    dec = {"seconds": round(td, 3), "value": round(n / td / 1e6, 2), "unit": "MB/s", "roundtrip_identical": same}
+                    dec = {"seconds": round(td, 3), "value": round(n / td / 1e6, 2), "unit": "MB/s", "roundtrip_identical": same,
+                           "list_restarts": timed_decode.restarts}
                 except Exception as e:
                     dec = {"error": "%s: %s" % (type(e).__name__, e)}
             out.append({"workload": desc, "decode": dec, "bytes": n, "input_sha256": hashlib.sha256(data.tobytes()).hexdigest()[:16],
@@ -655,6 +658,7 @@ def main():
             timed_decode(arch, ctx, data)
             td, same = timed_decode(arch, ctx, data)
             out["decode"] = {"value": round(n / td / 1e6, 3), "unit": "MB/s", "seconds": round(td, 3), "roundtrip_identical": same,
+                             "list_restarts": timed_decode.restarts,
                              "note": "bce_hip_decompress_device(archive -> caller's buffer) in a warm context: GPU passes + 8 host range decoders; not part of `value`"}
         if n_gpus == 1 and not args.no_workloads and not args.file and args.workload == "synth-text":
             out["workloads"] = extra_workloads(ctx, dev, table, pool, args.stream_steps or 12, decode=not args.no_decode)

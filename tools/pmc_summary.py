@@ -43,9 +43,9 @@ def family_sums(outdir, sub, counter):
     acc, calls = defaultdict(float), defaultdict(int)
     for d, k, v in rows:
         fam = None
-        if "k1_" in k: fam = "K1"
+        if "k1_" in k or "rw_" in k: fam = "K1"              # (rw_*: the wide sort of 64-bit keys, K1's alone)
         elif "k2_" in k: fam = "K2"
-        elif "k3_" in k or "kd_jobs" in k: fam = "K3"
+        elif "k3_" in k or "kd_" in k: fam = "K3"              # (kd_*: the depth-first tail's helpers)
         elif "k4_" in k: fam = "K4"
         elif "rs_" in k or "radix" in k: fam = "K1" if (k2_first is not None and d < k2_first) else "K4"
         if fam:
