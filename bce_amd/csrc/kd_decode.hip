@@ -1670,7 +1670,7 @@ int dec_host_tail(bce_hip_ctx *c, const DecArgs &a, const DecCtl &ctl, std::vect
 // children pass checks; the one-launch kernel, which checks afterwards, is only used where twice the round's nodes fit) and
 // the decode starts again with twice the room (decompress_device_body).  Test knob 12 / BCE_HIP_CAPP_DIV as for the encoder.
 uint32_t dec_full_capP(uint32_t n) { return (uint32_t)((uint64_t)n / 2 + 2); }
-uint32_t dec_capP(const bce_hip_ctx *c, uint32_t n) {
+uint32_t dec_capP(const bce_hip_ctx *c, uint32_t n, size_t archive_bytes) {
   const uint64_t full = dec_full_capP(n);
   uint64_t div = 8;
   bool forced = false;
@@ -1680,6 +1680,10 @@ uint32_t dec_capP(const bce_hip_ctx *c, uint32_t n) {
   // (the one-launch rounds need twice a round's nodes to fit: 4 M nodes per list at least, i.e. the worst case up to 8 MB of
   //  input -- with n / 8 a 1 MB input left them for its widest rounds and decoded in 32 ms instead of 16)
   if (!forced && cap < ((uint64_t)4 << 20)) cap = (uint64_t)4 << 20;
+  // How full the lists get goes with how well the input compresses -- text (archive = 0.23 n) fills 0.03 n per list, random
+  // bytes (1.0 n) 0.2-0.3 n -- and the archive's size is known before the first round: 0.35 x archive bytes nodes per list
+  // spares a high-entropy archive the decodes that run out of room and start again (1.5 * 10^9 random bytes: one of 40 s).
+  if (!forced) { const uint64_t by_ratio = (uint64_t)(0.35 * (double)archive_bytes) + 4096; if (by_ratio > cap) cap = by_ratio; }
   const uint64_t held = c->nlist[0].cap / (16 * sizeof(Node));
   if (held > cap && !forced) cap = held;
   if (c->dec_cap_next > cap) cap = c->dec_cap_next;             // (a decode that ran out of room: this much the next time)
@@ -1736,7 +1740,7 @@ static int decompress_device_once(bce_hip_ctx *c, const uint8_t *archive, size_t
 
   // ---- buffers ----
   const size_t rstride = (size_t)n + 1;
-  c->capP = dec_capP(c, n);
+  c->capP = dec_capP(c, n, len);
   BCE_TRY(ensure(c, c->nlist[0], (size_t)16 * c->capP * sizeof(Node)));
   BCE_TRY(ensure(c, c->ctl, sizeof(DecCtl) > sizeof(EnumCtl) ? sizeof(DecCtl) : sizeof(EnumCtl)));
   const size_t max_tiles = (size_t)8 * ((c->capP + K3_TILE - 1) / K3_TILE + 1);
