@@ -109,7 +109,11 @@ size_t ctx_trim(bce_hip_ctx *c) {
             &c->sval[1], &c->sout, &c->sesc, &c->skey_alt, &c->sesc_alt, &c->scanrec, &c->k4w};
     if (c->phase == 1) give.push_back(&c->gran);
   } else if (c->phase == 4) {
-    give = {&c->nlist[1], &c->sout, &c->k4w, &c->scanrec, &c->skey_alt, &c->sesc_alt};
+    // a decode uses the suffix arrays, the low key words, the rank array, the record arrays and nlist[0] as its scratch; the rest
+    // of the encoder's buffers it never touches
+    give = {&c->nlist[1], &c->sout, &c->k4w, &c->scanrec, &c->skey_alt, &c->sesc_alt, &c->khi[0], &c->khi[1], &c->k2, &c->nrk, &c->act[0], &c->act[1],
+            &c->actv[0], &c->actv[1], &c->kflag, &c->dl[0], &c->dl[1], &c->dl[2], &c->dl[3], &c->ptmp[0], &c->ptmp[1], &c->sval[0], &c->sval[1],
+            &c->k3tw, &c->k3grp};
   }
   size_t freed = 0;
   bool synced = false;

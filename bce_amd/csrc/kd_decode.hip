@@ -1681,9 +1681,9 @@ uint32_t dec_capP(const bce_hip_ctx *c, uint32_t n, size_t archive_bytes) {
   //  input -- with n / 8 a 1 MB input left them for its widest rounds and decoded in 32 ms instead of 16)
   if (!forced && cap < ((uint64_t)4 << 20)) cap = (uint64_t)4 << 20;
   // How full the lists get goes with how well the input compresses -- text (archive = 0.23 n) fills 0.03 n per list, random
-  // bytes (1.0 n) 0.2-0.3 n -- and the archive's size is known before the first round: 0.35 x archive bytes nodes per list
+  // bytes (1.0 n) 0.2-0.3 n -- and the archive's size is known before the first round: 0.25 x archive bytes nodes per list
   // spares a high-entropy archive the decodes that run out of room and start again (1.5 * 10^9 random bytes: one of 40 s).
-  if (!forced) { const uint64_t by_ratio = (uint64_t)(0.35 * (double)archive_bytes) + 4096; if (by_ratio > cap) cap = by_ratio; }
+  if (!forced) { const uint64_t by_ratio = (uint64_t)(0.25 * (double)archive_bytes) + 4096; if (by_ratio > cap) cap = by_ratio; }
   const uint64_t held = c->nlist[0].cap / (16 * sizeof(Node));
   if (held > cap && !forced) cap = held;
   if (c->dec_cap_next > cap) cap = c->dec_cap_next;             // (a decode that ran out of room: this much the next time)
