@@ -34,7 +34,7 @@ class Stats(C.Structure):
                 ("t_model", C.c_double), ("t_coder", C.c_double), ("t_total", C.c_double),
                 ("k3_ms", C.c_double), ("k3_launches", C.c_double), ("t_coder_busy", C.c_double),
                 ("list_grows", C.c_double), ("list_nodes", C.c_double), ("split_rounds", C.c_double),
-                ("reg_maps", C.c_double), ("reg_unmaps", C.c_double), ("dec_restarts", C.c_double)]
+                ("reg_maps", C.c_double), ("reg_unmaps", C.c_double), ("dec_restarts", C.c_double), ("t_model_kernels", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -266,6 +266,7 @@ void account_slot(bce_hip_ctx *c, FlushSlot &slot) {
   if (!slot.timed) return;
   float ms = 0;
   if (hipEventElapsedTime(&ms, slot.ev_start, slot.ev_copy) == hipSuccess) c->stats.t_model += ms * 1e-3;
+  if (slot.ev_kend && hipEventElapsedTime(&ms, slot.ev_start, slot.ev_kend) == hipSuccess) c->stats.t_model_kernels += ms * 1e-3;
   slot.timed = false;
 }
 
@@ -406,6 +407,7 @@ void bce_hip_destroy(bce_hip_ctx *c) {
     slot_free_host(sl, &c->reg_unmaps);
     if (sl.ev_start) (void)hipEventDestroy(sl.ev_start);
     if (sl.ev_copy) (void)hipEventDestroy(sl.ev_copy);
+    if (sl.ev_kend) (void)hipEventDestroy(sl.ev_kend);
   }
   if (c->ev_k4) (void)hipEventDestroy(c->ev_k4);
   if (c->ev_k3_batch) (void)hipEventDestroy(c->ev_k3_batch);
@@ -675,7 +677,7 @@ static int encode_body(bce_hip_ctx *c) {
   uint32_t C[8];
   for (int i = 0; i < 8; ++i) C[i] = c->zeros[(i + 7) & 7];   // bce.cpp:1128
   c->coder->begin(c->config, C, n);
-  c->stats.symbols = 0; c->stats.flushes = 0; c->stats.t_model = 0; c->stats.t_coder = 0;
+  c->stats.symbols = 0; c->stats.flushes = 0; c->stats.t_model = 0; c->stats.t_model_kernels = 0; c->stats.t_coder = 0;
 
   EnumCtl ctl;
   BCE_TRY(enumerate_body(c, ctl, [&](uint64_t nsym) { return flush_symbols(c, nsym); }));

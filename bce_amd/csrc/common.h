@@ -60,6 +60,7 @@ struct FlushSlot {
   size_t cap = 0;
   CoderBatch batch;
   hipEvent_t ev_start = nullptr, ev_copy = nullptr;   // K4 start (compute stream), outputs in h_out (copy stream)
+  hipEvent_t ev_kend = nullptr;                       // K4's last kernel (compute stream): the kernels' own time, without the copy
   bool timed = false;            // the events of the last flush have not been added to stats.t_model yet
   std::shared_ptr<std::once_flag> once;   // the first coder thread to arrive waits for ev_copy, the others for it
   bool registered = false;       // h_out is a private mapping under hipHostRegister (k4_prepin), not hipHostMalloc's

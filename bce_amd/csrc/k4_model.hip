@@ -423,6 +423,7 @@ int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
     BCE_HIP_TRY(c, hipStreamWaitEvent(ks, c->ev_k3_batch, 0));
   }
   if (!slot.ev_start) BCE_HIP_TRY(c, hipEventCreate(&slot.ev_start));
+  if (!slot.ev_kend) BCE_HIP_TRY(c, hipEventCreate(&slot.ev_kend));
   // blocking sync: the coder thread that waits for the copy sleeps instead of spinning next to the busy coders
   if (!slot.ev_copy) BCE_HIP_TRY(c, hipEventCreateWithFlags(&slot.ev_copy, hipEventBlockingSync));
   if (c->copy_busy) BCE_HIP_TRY(c, hipStreamWaitEvent(ks, c->copy_busy, 0));   // `sout` is still being copied out
@@ -490,6 +491,7 @@ int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   BCE_HIP_TRY(c, hipGetLastError());
   // the copy runs on its own stream so that the next rounds (K3) overlap it
   BCE_HIP_TRY(c, hipEventRecord(c->ev_k4, ks));
+  BCE_HIP_TRY(c, hipEventRecord(slot.ev_kend, ks));
   if (own) { BCE_HIP_TRY(c, hipEventRecord(c->ev_k4_done[c->flush_seq & 1u], ks)); ++c->flush_seq; }   // ... and have been read
   BCE_HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_k4, 0));
   BCE_HIP_TRY(c, hipMemcpyAsync(slot.h_out, c->sout.p, (size_t)nsym * 8, hipMemcpyDeviceToHost, c->copy_stream));

@@ -142,7 +142,8 @@ def roofline_families(n, sts, arch_sha):
     avg = lambda k: sum(s[k] for s in sts) / len(sts)
     spec = {"K1": (6.0 * n, avg("t_bwt"), "k1_* + radix-sort kernels: rotation sort + BWT (File::rotate / divbwt)"),
             "K2": (17.0 * n, avg("t_planes"), "k2_*: 8 planes + rank granules (RankFile)"),
-            "K4": (22.0 * st["symbols"], avg("t_model"), "k4_* + slot sort + device-to-host copy of the model records (AdaptiveCoder::set, model half)")}
+            "K4": (22.0 * st["symbols"], avg("t_model_kernels"), "k4_* + the slot sort (AdaptiveCoder::set, model half); HIP events around every flush's kernels, "
+                                                                "without the device-to-host copies of the records (with them: breakdown_s.t_model)")}
     fam_traffic = {}
     try:
         fj = json.load(open(os.path.join(ROOT, "profiles", FAMILY_FILE)))

@@ -200,6 +200,7 @@ typedef struct bce_hip_stats {
   double reg_maps;             /* host mappings registered with the runtime (flush slots, the decoder's boundary ranks) */
   double reg_unmaps;           /* ... and given back (after waiting for the work that touches them) */
   double dec_restarts;         /* GPU-assisted decodes started again with larger node lists (kd_decode.hip) */
+  double t_model_kernels;      /* of t_model: GPU seconds of K4's kernels alone (sort, window, long, emit), without the device-to-host copies */
 } bce_hip_stats;
 int bce_hip_get_stats(const bce_hip_ctx *ctx, bce_hip_stats *out);
 
