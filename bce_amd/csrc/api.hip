@@ -717,11 +717,20 @@ static int encode_body(bce_hip_ctx *c) {
 // small, they have been grown and the caller runs the round again.
 static int split_round(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(uint64_t)> &sink, bool *executed) {
   *executed = false;
+  // (K3's event time covers the passes' launches only: the flushes between them wait for coder threads)
+  auto pass = [&](uint32_t mask, bool repeat) -> int {
+    BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    BCE_TRY(k3_clear_need_flush(c));
+    BCE_TRY(k3_round_masked(c, mask, repeat));
+    BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    BCE_TRY(k3_sync_ctl(c, &ctl));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms;
+    return BCE_HIP_OK;
+  };
   // pass 0, all planes, three launches: either the round fits after all (the one-launch rounds only know an upper bound), or
   // the per-plane counts are in the control block afterwards
-  BCE_TRY(k3_clear_need_flush(c));
-  BCE_TRY(k3_round_masked(c, 0xFFu, false));
-  BCE_TRY(k3_sync_ctl(c, &ctl));
+  BCE_TRY(pass(0xFFu, false));
   if (ctl.stalled) return k3_stalled(c);
   if (ctl.overflow) { BCE_TRY(k3_grow_lists(c, ctl)); ctl.overflow = 0; return BCE_HIP_OK; }
   if (!ctl.need_flush) {
@@ -739,9 +748,7 @@ static int split_round(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(uin
     uint32_t mask = 0;
     uint64_t acc = 0;
     while (q < 8 && (mask == 0 || acc + cnt[q] <= c->sym_cap)) { mask |= 1u << q; acc += cnt[q]; ++q; }
-    BCE_TRY(k3_clear_need_flush(c));
-    BCE_TRY(k3_round_masked(c, mask, !first));
-    BCE_TRY(k3_sync_ctl(c, &ctl));
+    BCE_TRY(pass(mask, !first));
     if (ctl.stalled) return k3_stalled(c);
     if (ctl.need_flush || ctl.overflow) { snprintf(c->err, sizeof c->err, "k3: pass of planes %#x of round %u does not fit (%llu symbols, room for %llu)", mask, c->round, (unsigned long long)acc, (unsigned long long)c->sym_cap); return BCE_HIP_E_INTERNAL; }
     BCE_TRY(k3_fetch_runs(c, c->round, 1));
@@ -931,11 +938,7 @@ static int enumerate_body(bce_hip_ctx *c, EnumCtl &ctl, const std::function<int(
         uint64_t want = ctl.want_syms + (ctl.want_syms >> 3) + 1024;
         if (want >= split_limit) {
           bool executed_round = false;
-          BCE_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
           BCE_TRY(split_round(c, ctl, sink, &executed_round));
-          BCE_HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-          BCE_HIP_TRY(c, hipEventSynchronize(c->ev1));
-          { float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.k3_ms += ms; }
           if (!executed_round) continue;           // (the lists were too small for it: grown, the round comes again)
           c->round += 1;
           est_syms = 0;

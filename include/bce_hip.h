@@ -89,7 +89,9 @@ int bce_hip_debug_set(bce_hip_ctx *ctx, int knob, uint32_t value);
  * device runs out of memory the buffers of the stages that are not running (the suffix sort's scratch) go back first.  Every
  * valid input -- any 1 <= n < 2^31, as the reference (bce.cpp:173,374,901) -- fits an otherwise idle 288 GB MI355X: the worst
  * case is 72 n bytes of lists beside 13 n bytes that stay.  A round that emits more symbols than one model flush takes (2^31
- * records) is run plane group by plane group (bce_hip_stats.split_rounds). */
+ * records) is run plane group by plane group (bce_hip_stats.split_rounds).  (The GPU-assisted DECODER, bce_hip_decompress_device,
+ * holds 32 n bytes of boundary ranks beside its lists and a round's queries: a high-entropy archive of more than ~1.6 * 10^9 bytes
+ * ends in BCE_HIP_E_NOMEM there -- never in wrong bytes -- and is decoded by bce_hip_decompress, `bce -ds`.) */
 int bce_hip_load_host(bce_hip_ctx *ctx, const uint8_t *in, uint32_t n);
 int bce_hip_load_device(bce_hip_ctx *ctx, const void *d_in, uint32_t n);
 

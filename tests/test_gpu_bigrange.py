@@ -107,12 +107,12 @@ def _sha_file(path):
 
 
 @pytest.mark.timeout(2400)
-@pytest.mark.parametrize("name", ["synth-rand-1.5e9", "synth-text-2p31m2"])
+@pytest.mark.parametrize("name", ["synth-rand-1.5e9", "synth-text-2p31m2", "synth-rand-2p31m2"])
 def test_inputs_that_used_to_fail_match_the_oracle(name):
     """1.5 * 10^9 random bytes: lists of ~0.3 n = 450 M nodes (beyond the old 357 M cap: 64-bit indexing, a list above 4 GB; its
     widest round stays below 2^31 symbols -- the plane groups are tested at small sizes above).  2^31 - 2 bytes of text: the largest even input (the reference's own limit
     is n < 2^31), 8n - 8 nodes.  Archives against the oracle's (tools/make_oracle_golden.py: 25-40 minutes of CPU each), then the
-    GPU-assisted decoder brings the input back."""
+    GPU-assisted decoder brings the input back.  2^31 - 2 random bytes: compress only (see below)."""
     v = GOLD.get(name)
     if v is None:
         pytest.skip("no oracle-made known answer for %s in tests/golden/oracle_fullsize.json" % name)
@@ -127,6 +127,13 @@ def test_inputs_that_used_to_fail_match_the_oracle(name):
         assert len(arch) == v["archive_bytes"] and hashlib.sha256(arch).hexdigest() == v["archive_sha256"]
         if name.startswith("synth-rand"):
             assert st["list_nodes"] > 357_000_000 and st["list_grows"] >= 1, st     # (a list beyond 4 GB: the 64-bit list reads)
+        if name == "synth-rand-2p31m2":
+            # the worst realistic input at the largest even size: three of its rounds emit more than 2^31 symbols (plane groups at
+            # full scale) and the lists only fit once K1's sort scratch has gone back.  Its 1.3 * 10^10 queries are beyond what the
+            # GPU-assisted decoder holds in 288 GB (32 n of boundary ranks + lists + a round's queries: BCE_HIP_E_NOMEM, loudly; `bce -ds`
+            # decodes it on the host): the archive's identity with the oracle's is the check here.
+            assert st["split_rounds"] >= 1, st
+            return
         del data
         out = np.empty(v["n"], dtype=np.uint8)
         assert bce_amd.decompress_device(arch, ctx=ctx, out=out) == v["n"]
