@@ -438,7 +438,11 @@ int main(int argc, char **argv) {
       rc = first_rc.load();
       for (bce_hip_ctx *c : ctxs) { if (rc != 0 && bce_hip_last_error(c)[0]) printf("%s\n", bce_hip_last_error(c)); bce_hip_destroy(c); }
     }
-    if (rc != 0) { printf("Decompression failed: %s\n", bce_hip_strerror(rc)); return -4; }
+    if (rc != 0) {
+      printf("Decompression failed: %s\n", bce_hip_strerror(rc));
+      if (rc == BCE_HIP_E_NOMEM && use_gpu) printf("(the GPU-assisted decoder holds 32 bytes of boundary ranks per input byte beside its node lists; `bce -ds` decodes on the host)\n");
+      return -4;
+    }
     auto end = std::chrono::high_resolution_clock::now();
     std::chrono::duration<double> duration = end - start;
     if (prefault.joinable()) prefault.join();
