@@ -170,7 +170,7 @@ def test_gather_streams_ragged_sizes_world3():
     assert q.get(timeout=5) is True
 
 
-def _run_bench_ranks(world, total, extra=(), timeout=900):
+def _run_bench_ranks(world, total, extra=(), timeout=900, backend="gloo"):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), rehearsed on ONE GPU with
     the gloo backend.  -> (the JSON line, the BCEM container rank 0 wrote)."""
     import json
@@ -181,7 +181,7 @@ def _run_bench_ranks(world, total, extra=(), timeout=900):
         cpath = os.path.join(td, "blocks.bcem")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
-               "--total-size", str(total), "--backend", "gloo", "--no-cpu", "--container-out", cpath] + list(extra)
+               "--total-size", str(total), "--backend", backend, "--no-cpu", "--container-out", cpath] + list(extra)
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -270,6 +270,21 @@ def test_bench_two_ranks_full_size_blocks_against_the_oracle_goldens():
     import hashlib
     for r in range(2):
         assert hashlib.sha256(archives[r]).hexdigest() == gold["synth-text-1e9-b%dof2" % r]["archive_sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_over_rccl_on_as_many_gpus_as_the_box_has(world):
+    """The real thing, for a box that HAS several GPUs (the pool's boxes have one: skipped there, and the driver's 8-GPU SCALE run
+    is this command at full size): bench.py under torch.distributed.run, one rank per GPU, backend nccl = RCCL over xGMI -- every
+    gathered block == the oracle's archive of it, the container decodes back to the input."""
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip("%d GPUs on this box, %d ranks need one each (RCCL does not share a device between ranks)" % (torch.cuda.device_count(), world))
+    total = 24_000_003
+    j, blob = _run_bench_ranks(world, total, backend="nccl")
+    assert j["n_gpus"] == world and j["comm"]["backend"] == "nccl" and j["comm"]["world"] == world
+    _check_blocks_against_oracle(j, blob, world, total)
 
 
 def test_block_goldens_cover_the_stated_config():
