@@ -107,12 +107,12 @@ def _sha_file(path):
 
 
 @pytest.mark.timeout(2400)
-@pytest.mark.parametrize("name", ["synth-rand-1.5e9", "synth-text-2p31m2", "synth-rand-2p31m2"])
+@pytest.mark.parametrize("name", ["synth-rand-1.5e9", "synth-text-2p31m2"])
 def test_inputs_that_used_to_fail_match_the_oracle(name):
     """1.5 * 10^9 random bytes: lists of ~0.3 n = 450 M nodes (beyond the old 357 M cap: 64-bit indexing, a list above 4 GB; its
     widest round stays below 2^31 symbols -- the plane groups are tested at small sizes above).  2^31 - 2 bytes of text: the largest even input (the reference's own limit
     is n < 2^31), 8n - 8 nodes.  Archives against the oracle's (tools/make_oracle_golden.py: 25-40 minutes of CPU each), then the
-    GPU-assisted decoder brings the input back.  2^31 - 2 random bytes: compress only (see below)."""
+    GPU-assisted decoder brings the input back."""
     v = GOLD.get(name)
     if v is None:
         pytest.skip("no oracle-made known answer for %s in tests/golden/oracle_fullsize.json" % name)
@@ -127,16 +127,41 @@ def test_inputs_that_used_to_fail_match_the_oracle(name):
         assert len(arch) == v["archive_bytes"] and hashlib.sha256(arch).hexdigest() == v["archive_sha256"]
         if name.startswith("synth-rand"):
             assert st["list_nodes"] > 357_000_000 and st["list_grows"] >= 1, st     # (a list beyond 4 GB: the 64-bit list reads)
-        if name == "synth-rand-2p31m2":
-            # the worst realistic input at the largest even size: three of its rounds emit more than 2^31 symbols (plane groups at
-            # full scale) and the lists only fit once K1's sort scratch has gone back.  Its 1.3 * 10^10 queries are beyond what the
-            # GPU-assisted decoder holds in 288 GB (32 n of boundary ranks + lists + a round's queries: BCE_HIP_E_NOMEM, loudly; `bce -ds`
-            # decodes it on the host): the archive's identity with the oracle's is the check here.
-            assert st["split_rounds"] >= 1, st
-            return
         del data
         out = np.empty(v["n"], dtype=np.uint8)
         assert bce_amd.decompress_device(arch, ctx=ctx, out=out) == v["n"]
         assert hashlib.sha256(out).hexdigest() == v["input_sha256"]
     finally:
         ctx.close()
+
+
+@pytest.mark.timeout(2400)
+def test_the_worst_realistic_input_at_the_largest_even_size(monkeypatch):
+    """2^31 - 2 random bytes: 1.3 * 10^10 symbols, lists of 858 M nodes that only fit once K1's sort scratch has gone back (ctx_trim),
+    and three rounds that emit more than 2^31 symbols -- the plane groups at full scale.  The oracle cannot make a known answer
+    here (it needs more than the build container's 62 GB at this size) and the GPU-assisted decoder cannot hold the archive's
+    1.3 * 10^10 queries beside 32 n bytes of boundary ranks (BCE_HIP_E_NOMEM, loudly; `bce -ds` decodes on the host), so the check is
+    size-independent: every node visited exactly once, and the SAME archive when the rounds are cut into plane groups
+    differently (BCE_HIP_SPLIT_SYMS = 2^30: more rounds take the path, in smaller groups) -- the path whose small-scale archives
+    are the oracle's (test_round_too_large_for_one_flush_goes_plane_group_by_plane_group)."""
+    n = (1 << 31) - 2
+    data = bce_amd.synth_rand(1, n)
+    shas, splits = [], []
+    for limit in (None, str(1 << 30)):
+        if limit:
+            monkeypatch.setenv("BCE_HIP_SPLIT_SYMS", limit)
+        ctx = bce_amd.api._Ctx(0)
+        try:
+            rf = bce_amd.RankFile(data, ctx=ctx)
+            arch = bce_amd.BCE().encode(rf)
+            st = bce_amd.stats(rf)
+        finally:
+            ctx.close()
+        assert st["nodes"] == 8 * n - 8 and st["symbols"] > 6 * n * 0.99
+        assert st["list_nodes"] > 357_000_000
+        shas.append(hashlib.sha256(arch).hexdigest())
+        splits.append(st["split_rounds"])
+        assert n < len(arch) < n + n // 64                      # (random bytes do not compress: a little above n)
+        del arch
+    assert splits[0] >= 1 and splits[1] > splits[0], splits
+    assert shas[0] == shas[1]
