@@ -412,7 +412,37 @@ int k4_flush_async(bce_hip_ctx *c, uint64_t nsym64, FlushSlot &slot) {
   if (slot.cap < nsym) {
     slot_free_host(slot, &c->reg_unmaps);
     size_t cap = (size_t)c->sym_cap > nsym ? (size_t)c->sym_cap : nsym;
-    BCE_TRY(pin_alloc(c, (void **)&slot.h_out, cap * 8 + 16));
+    // A slot that has to grow in the middle of a compression (the symbol buffer grew: a high-entropy input of GBs has rounds of
+    // 10^9 records, 8-17 GB of staging per slot): from the registered-mapping size on, a mapping of its own, touched by four
+    // threads and registered where it is (common.h) -- hipHostMalloc takes ~0.15 s per GB, this 0.015.
+    const size_t bytes = slot_map_bytes(cap);
+    void *q = bytes >= reg_min_bytes((size_t)8 << 20) ? huge_map(bytes) : nullptr;
+    if (q) {
+      const double t0 = now_s();
+      constexpr unsigned nt = 4;
+      auto touch = [q, bytes](unsigned t) {
+        const size_t lo = bytes / nt * t, hi = t + 1 == nt ? bytes : bytes / nt * (t + 1);
+        for (size_t o = lo & ~(size_t)4095; o < hi; o += 4096) static_cast<volatile uint8_t *>(q)[o] = 0;
+      };
+      std::vector<std::thread> th;
+      try { for (unsigned t = 1; t < nt; ++t) th.emplace_back(touch, t); } catch (...) {}
+      const unsigned started = (unsigned)th.size() + 1;
+      touch(0);
+      for (unsigned t = started; t < nt; ++t) touch(t);
+      for (auto &x : th) x.join();
+      reg_map_settle(q, bytes);
+      if (hipHostRegister(q, bytes, hipHostRegisterDefault) == hipSuccess) {
+        slot.h_out = static_cast<uint64_t *>(q);
+        slot.registered = true;
+        c->reg_maps++;
+        c->pin_s += now_s() - t0; c->pin_bytes += bytes; c->pin_calls++;
+      } else {
+        (void)hipGetLastError();
+        huge_unmap(q, bytes);
+        q = nullptr;
+      }
+    }
+    if (!q) BCE_TRY(pin_alloc(c, (void **)&slot.h_out, cap * 8 + 16));
     slot.cap = cap;
   }
   // the stream the flush runs on: its own (beside the next K3 rounds) or the main one
