@@ -287,6 +287,23 @@ def test_bench_over_rccl_on_as_many_gpus_as_the_box_has(world):
     _check_blocks_against_oracle(j, blob, world, total)
 
 
+@pytest.mark.gpu
+def test_bench_four_ranks_full_size_blocks_against_the_oracle_goldens():
+    """N = 4 at FULL size (four blocks of 2.5 x 10^8 B, four rank processes on the one GPU: the box allows six): bench.py's own
+    per-block verdicts against synth-text-1e9-bRof4, and the container's archives hashed here as well."""
+    import hashlib
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_fullsize.json")) as f:
+        gold = {v["name"]: v for v in json.load(f)["vectors"]}
+    total = 1_000_000_000
+    j, blob = _run_bench_ranks(4, total, timeout=1500)
+    assert j["oracle_golden_blocks"] == "identical" and j["oracle_golden_per_block"] == ["identical"] * 4
+    assert j["config"]["bytes_per_gpu"] == [250_000_000] * 4
+    from bce_amd import container
+    archives, raws = container.unpack_blocks(blob)
+    assert [hashlib.sha256(a).hexdigest() for a in archives] == [gold["synth-text-1e9-b%dof4" % r]["archive_sha256"] for r in range(4)]
+
+
 def test_block_goldens_cover_the_stated_config():
     """BASELINE configs[3] (enwik9-sized input cut over 2 / 4 / 8 GPUs): an oracle-made archive hash for every block."""
     import json
