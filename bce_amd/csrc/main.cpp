@@ -217,7 +217,7 @@ static int usage() {
   printf("  bce -s config.bcc file\n");
   printf("   Scan \"file\" and generate a config file \"config.bcc\" to improve the AdaptiveCoder (uses a lot of memory)\n");
   printf("\n");
-  printf("  bce -cN archive.bcem file [config.bcc]      (extension: N = 2..64 blocks, one container, all GPUs of the node)\n");
+  printf("  bce -cN archive.bcem file [config.bcc]      (extension: N = 2..64 blocks, one container, all GPUs of the node; every block < 2^31 bytes)\n");
   return 0;
 }
 
@@ -229,7 +229,10 @@ int main(int argc, char **argv) {
   if ((argc == 4 || argc == 5) && argv[1][0] == '-' && argv[1][1] == 'c') {
     auto start = std::chrono::high_resolution_clock::now();
     HostFile data;
-    std::thread reader(read_whole_file, argv[3], &data, kMaxInput);  // File::File, bce.cpp:842-856 -- beside the runtime's start-up
+    // (-cN, the extension: every BLOCK obeys the reference's n < 2^31, the file may be N times that)
+    const uint32_t nb_arg = (uint32_t)atoi(argv[1] + 2);
+    const size_t file_limit = nb_arg >= 2 && nb_arg <= 64 ? (size_t)nb_arg * (kMaxInput - 1) + 1 : kMaxInput;
+    std::thread reader(read_whole_file, argv[3], &data, file_limit);  // File::File, bce.cpp:842-856 -- beside the runtime's start-up
     bce_hip_ctx *ctx = nullptr;
     uint64_t expect = 0;                                          // the file's size, if it says: what the context prepares for
     { struct stat st; if (stat(argv[3], &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) expect = (uint64_t)st.st_size; }
@@ -261,7 +264,7 @@ int main(int argc, char **argv) {
       }
     }
     reader.join();
-    if (data.status != 0 || data.size() == 0 || data.size() >= kMaxInput) {   // also covers the empty file, on which the reference crashes
+    if (data.status != 0 || data.size() == 0 || data.size() >= file_limit) {   // also covers the empty file, on which the reference crashes
       printf("Error loading file\n");
       bce_hip_destroy(ctx);
       return -1;
@@ -418,25 +421,47 @@ int main(int argc, char **argv) {
       const size_t workers = use_gpu ? ctxs.size() : std::min<size_t>(blocks.size(), 8);
       std::atomic<size_t> next_block{0};
       std::atomic<int> first_rc{0};
+      // as in compress_blocks: a context that runs out of device memory (blocks of a GB and more, two contexts per device) gives
+      // its memory back and leaves its block to ONE context that has the device to itself at the end
+      std::vector<char> done(blocks.size(), 0);
+      auto decode_block = [&](bce_hip_ctx *c, size_t b) -> int {
+        const uint8_t *ap = adata.data() + blocks[b].first;
+        size_t n = 0;
+        const size_t want = at[b + 1] - at[b];
+        int r = c ? bce_hip_decompress_device(c, ap, blocks[b].second, out.get() + at[b], want, &n)
+                  : bce_hip_decompress(ap, blocks[b].second, out.get() + at[b], want, &n);
+        if (r == 0 && n != want) r = BCE_HIP_E_INTERNAL;         // the table and the block's own header disagree
+        return r;
+      };
       std::vector<std::thread> th;
       for (size_t w = 0; w < workers; ++w)
         th.emplace_back([&, w] {
-          bce_hip_ctx *c = use_gpu ? ctxs[w] : nullptr;
           while (first_rc.load() == 0) {
             const size_t b = next_block.fetch_add(1);
             if (b >= blocks.size()) break;
-            const uint8_t *ap = adata.data() + blocks[b].first;
-            size_t n = 0;
-            const size_t want = at[b + 1] - at[b];
-            int r = c ? bce_hip_decompress_device(c, ap, blocks[b].second, out.get() + at[b], want, &n)
-                      : bce_hip_decompress(ap, blocks[b].second, out.get() + at[b], want, &n);
-            if (r == 0 && n != want) r = BCE_HIP_E_INTERNAL;       // the table and the block's own header disagree
-            if (r != 0) { int z = 0; first_rc.compare_exchange_strong(z, r); }
+            bce_hip_ctx *c = use_gpu ? ctxs[w] : nullptr;
+            const int r = decode_block(c, b);
+            if (r == 0) { done[b] = 1; continue; }
+            if (r == BCE_HIP_E_NOMEM && use_gpu) { bce_hip_destroy(ctxs[w]); ctxs[w] = nullptr; return; }   // (its block stays undone)
+            int z = 0;
+            first_rc.compare_exchange_strong(z, r);
           }
         });
       for (auto &t : th) t.join();
       rc = first_rc.load();
-      for (bce_hip_ctx *c : ctxs) { if (rc != 0 && bce_hip_last_error(c)[0]) printf("%s\n", bce_hip_last_error(c)); bce_hip_destroy(c); }
+      for (bce_hip_ctx *&c : ctxs) { if (!c) continue; if (rc != 0 && bce_hip_last_error(c)[0]) printf("%s\n", bce_hip_last_error(c)); bce_hip_destroy(c); c = nullptr; }
+      if (rc == 0 && use_gpu) {
+        bce_hip_ctx *c = nullptr;
+        for (size_t b = 0; rc == 0 && b < blocks.size(); ++b) {
+          if (done[b]) continue;
+          if (!c) rc = bce_hip_create(&c, 0);
+          if (rc == 0) rc = decode_block(c, b);
+          if (rc == 0) done[b] = 1;
+        }
+        if (rc != 0 && c && bce_hip_last_error(c)[0]) printf("%s\n", bce_hip_last_error(c));
+        if (c) bce_hip_destroy(c);
+      }
+      if (rc == 0) for (size_t b = 0; b < blocks.size(); ++b) if (!done[b]) rc = BCE_HIP_E_INTERNAL;
     }
     if (rc != 0) {
       printf("Decompression failed: %s\n", bce_hip_strerror(rc));

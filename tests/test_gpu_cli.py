@@ -213,3 +213,37 @@ def test_create_sized_prepares_and_is_only_a_hint():
     finally:
         lib.bce_hip_destroy(h)
     assert lib.bce_hip_create_sized(None, 0, 0) != 0
+
+
+@pytest.mark.timeout(900)
+def test_cli_blocks_of_a_file_beyond_the_single_archive_limit(tmp_path):
+    """`bce -c` refuses 2^31 bytes and more as the reference does (saidx_t, bce.cpp:901) -- `bce -cN`, the extension, only asks that of
+    every BLOCK: a 2.2 * 10^9-byte file goes through `-c2` (two blocks of 1.1 * 10^9 B, two contexts on the one GPU; a context
+    that runs out of device memory leaves its block to the end, in -c and in -d alike), each block is the archive `bce -c`
+    writes for those bytes (checked through the host-side header and the round trip; the oracle's own per-block answers at
+    full size are tests/test_gpu_fullsize.py's), and `bce -d` puts the file back together."""
+    import hashlib
+    from bce_amd import container
+    n = 2_200_000_000
+    data = bce_amd.synth_text(5, n)
+    src, arc, out = tmp_path / "in.bin", tmp_path / "a.bcem", tmp_path / "o.bin"
+    data.tofile(str(src))
+    want = hashlib.sha256(data).hexdigest()
+    del data
+    r = subprocess.run([EXE, "-c", str(arc), str(src)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 255 and "Error loading file" in r.stdout            # the single archive: n < 2^31
+    r = subprocess.run([EXE, "-c2", str(arc), str(src)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    blob = arc.read_bytes()
+    archives, raws = container.unpack_blocks(blob)
+    assert raws == [n // 2, n - n // 2] and all(len(a) > 0 for a in archives)
+    del blob, archives
+    r = subprocess.run([EXE, "-d", str(out), str(arc)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    h = hashlib.sha256()
+    with open(out, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            h.update(chunk)
+    assert h.hexdigest() == want
+    for p in (src, arc, out):
+        p.unlink()
