@@ -7,9 +7,11 @@
 // lists of the next plane) + one compaction of symbol records.  The gamma-coded pArray queues
 // (bce.cpp:226-356) do not exist here.
 //
-// Node lists of a plane live in one buffer of capP nodes: the child0 list (positions < zeros, the
-// reference's Q[i][0]) grows up from index 0, the child1 list (Q[i][1]) grows DOWN from capP-1, so the
-// two lists share the capacity whatever their split is.
+// Node lists of a plane live in one buffer of cap nodes: the child0 list (positions < zeros, the
+// reference's Q[i][0]) grows up from index 0, the child1 list (Q[i][1]) grows DOWN from cap-1, so the
+// two lists share the capacity whatever their split is.  The two parities of a round (the lists it reads, the
+// lists it writes) are buffers of their own with capacities of their own (K3Args::cap): the one a round is
+// about to write holds nothing and is replaced by a larger one when the round does not fit (k3_grow_lists).
 //
 // Wide rounds: count kernel -> per-plane scan (last block folds the totals into the control block) -> write
 // kernel, all parameterised by the round parity and driven by a device-resident control block, so the host can
